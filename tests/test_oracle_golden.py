@@ -1,0 +1,134 @@
+"""Pin the CPU oracle (oracle/) against every known-answer vector the reference's own tests hold
+for the `search` path and against fixtures produced by the reference's Python driver
+(tests/golden/make_golden.py).  CPU only."""
+import io
+
+import numpy as np
+import pytest
+
+from oracle import ref_driver as rd
+
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def genome_index():
+    return rd.OracleIndex.from_fasta(GOLDEN / "genome.fa")
+
+
+def test_kat_count_kmers(genome_index, golden_host):
+    k = golden_host["kat"]["count_kmers"]            # reference tests/test_count_kmers.py:21-25
+    kmers = [s.encode() for s in k["kmers"]]
+    assert genome_index.count_kmers(kmers) == k["expected"]
+    genome_index.enable_fm(4)
+    assert genome_index.count_kmers(kmers, fm=True) == k["expected"]
+
+
+def test_kat_count_from_sequence(genome_index, golden_host):
+    k = golden_host["kat"]["count_from_sequence"]    # reference tests/test_count_kmers.py:37-44
+    for fm in (False, True):
+        if fm:
+            genome_index.enable_fm(2)
+        got = genome_index.count_from_sequence(k["sequence"].encode(), k["starts"], k["lengths"], fm)
+        assert got.tolist() == k["expected"]
+
+
+def test_upper_search_bound_cases(golden_host):
+    for c in golden_host["upper_bound"]:             # reference tests/test_upper_search_bound_truncation.py
+        got = rd.upper_search_bound(np.array(c["mask"], dtype=bool), c["kmax"], c["buffer_len"])
+        assert got.tolist() == c["expected"], c
+    with pytest.raises(AssertionError):
+        rd.upper_search_bound(np.ones(4, bool), 50, 4 + 50)
+
+
+def test_sequence_segments_cases(golden_host):
+    for c in golden_host["segments"]:                # reference tests/test_sequence_buffer_iter.py
+        lines = io.BytesIO(c["text"].encode("latin-1")).readlines()
+        got = [[s.id.decode("latin-1"), s.data.decode("latin-1"), s.epilogue]
+               for s in rd.sequence_segments(lines, c["length"], c["overlap"])]
+        assert got == c["expected"], (c["name"], c["length"], c["overlap"])
+
+
+def _run_case(c, fm):
+    text = c["fasta"].encode("latin-1")
+    lines = io.BytesIO(text).readlines()
+    index = rd.OracleIndex([d for _, d in rd.read_records(lines)])
+    if fm:
+        index.enable_fm(5)
+    got = rd.unique_counts(lines, index, c["kmer_lengths"], c["is_binary"], c["batch"],
+                           c["use_reverse_complement"], c["initial_search_length"], fm)
+    return index, got
+
+
+@pytest.mark.parametrize("fm", [False, True], ids=["sa", "fmport"])
+def test_search_cases_match_reference_driver(golden_search, fm):
+    """The oracle restatement reproduces the reference driver's output files on every fixture,
+    including the batch-dependent lookahead quirk case."""
+    for c in golden_search:
+        _, got = _run_case(c, fm)
+        assert set(k.decode() for k in got) == set(c["expected"]), c["name"]
+        for rid, exp in c["expected"].items():
+            arr = got[rid.encode()]
+            assert arr.dtype == np.dtype(exp["dtype"]), c["name"]
+            assert arr.tolist() == exp["values"], (c["name"], rid)
+
+
+def test_c_port_matches_numpy_restatement(golden_search):
+    """or_ref_binary_search_segment (the code the CPU baseline times) == numpy restatement."""
+    for c in golden_search:
+        if not c["is_binary"]:
+            continue
+        text = c["fasta"].encode("latin-1")
+        lines = io.BytesIO(text).readlines()
+        index = rd.OracleIndex([d for _, d in rd.read_records(lines)])
+        index.enable_fm(6)
+        kmin, kmax = min(c["kmer_lengths"]), max(c["kmer_lengths"])
+        for seg in rd.sequence_segments(lines, c["batch"] + kmax - 1, kmax - 1):
+            n = rd.num_kmers_of(seg, kmax)
+            want, amb = rd.binary_search_segment(index, seg, kmin, kmax, np.uint32,
+                                                 c["use_reverse_complement"],
+                                                 c["initial_search_length"])
+            got, amb2, stats = rd.ref_binary_search_segment_c(
+                index, seg.data, n, kmin, kmax, c["use_reverse_complement"],
+                c["initial_search_length"], fm=True)
+            assert amb == amb2
+            assert got.tolist() == want.tolist(), c["name"]
+            assert stats["iterations"] <= int(np.ceil(np.log2(kmax - kmin) + 1))  # search.py:215-217
+
+
+def test_closed_form_equals_batched_driver_without_quirk(golden_search):
+    """Appendix A.2: away from the lookahead quirk the output does not depend on the batch."""
+    for c in golden_search:
+        if not c["is_binary"] or "quirk" in c["name"]:
+            continue
+        text = c["fasta"].encode("latin-1")
+        lines = io.BytesIO(text).readlines()
+        recs = rd.read_records(lines)
+        index = rd.OracleIndex([d for _, d in recs])
+        kmin, kmax = min(c["kmer_lengths"]), max(c["kmer_lengths"])
+        for rid, data in recs:
+            got = rd.closed_form_min_unique(data, index, kmin, kmax, c["use_reverse_complement"])
+            assert got.tolist() == c["expected"][rid.decode()]["values"], (c["name"], rid)
+
+
+def test_zero_count_guard():
+    index = rd.OracleIndex([b"ACGTACGTTTGACCA"])
+    seg = rd.Segment(b"x", b"GGGGGGGGGGGGGGGG", True)
+    with pytest.raises(RuntimeError, match="not found in the index"):
+        rd.binary_search_segment(index, seg, 4, 8, np.uint8)
+    with pytest.raises(RuntimeError, match="not found in the index"):
+        rd.ref_binary_search_segment_c(index, seg.data, len(seg.data), 4, 8, fm=False)
+
+
+def test_sa_and_fm_counters_agree_on_random_queries():
+    rng = np.random.default_rng(7)
+    recs = [bytes(np.frombuffer(b"ACGTN", np.uint8)[rng.choice(5, 4000, p=[.24, .24, .24, .24, .04])])
+            for _ in range(3)]
+    index = rd.OracleIndex(recs)
+    index.enable_fm(4)
+    seq = recs[1]
+    starts = rng.integers(0, len(seq) - 40, 3000)
+    lens = rng.integers(1, 40, 3000)
+    a = index.count_from_sequence(seq, starts, lens, fm=False)
+    b = index.count_from_sequence(seq, starts, lens, fm=True)
+    assert np.array_equal(a, b) and a.min() >= 1

@@ -1,0 +1,127 @@
+/*
+ * newmap_amd.h -- C-ABI of the MI355X-native engine behind newmap's `search` hot path.
+ *
+ * This is the drop-in boundary: plain pointers, sizes and int return codes, no exceptions, no
+ * torch / Python types.  It replaces the two CPython extension modules through which the
+ * reference reaches AvxWindowFmIndex (file:line relative to the reference checkout):
+ *
+ *   newmap._c_newmap_generate_index.generate_fm_index   src/newmap-generate-index.c:11-58,82-104
+ *   newmap._c_newmap_count_kmers.count_kmers            src/newmap-count.c:28-89
+ *   newmap._c_newmap_count_kmers.count_kmers_from_sequence
+ *                                                        src/newmap-count.c:91-206
+ * and hoists the per-segment search loop that sits on top of that seam
+ *   newmap.search.binary_search / linear_search          newmap/search.py:383-548, 551-644
+ *   (mask :744-766, upper bound :769-882, strand sum + zero guard :647-724)
+ * into one fused device launch per segment.
+ *
+ * Ownership: every buffer is caller-owned.  `nm_index*` is an opaque handle that owns the
+ * device-resident index (uploaded ONCE, unlike src/newmap-count.c:135-136 which re-reads the
+ * index file on every call).  One handle per device; calls on one handle are serialised by the
+ * caller.  All functions return NM_OK (0) or a positive NM_E* code; nm_last_error() gives the
+ * message of the last failure on the calling thread.
+ */
+#ifndef NEWMAP_AMD_H
+#define NEWMAP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nm_index nm_index;
+
+enum {
+    NM_OK = 0,
+    NM_E_FILE_OPEN = 1,      /* FileNotFoundError   (AwFmFileOpenFail,      newmap-generate-index.c:32-36) */
+    NM_E_ALLOC = 2,          /* MemoryError         (AwFmAllocationFailure, :38-42)                        */
+    NM_E_FILE_EXISTS = 3,    /* FileExistsError     (AwFmFileAlreadyExists, :44-48) -- never returned:
+                                like the reference at its pinned library version, build overwrites     */
+    NM_E_FILE_WRITE = 4,     /* OSError             (AwFmFileWriteFail,     :50-54)                        */
+    NM_E_FILE_FORMAT = 5,    /* OSError: not an index written by nm_index_build (newmap-count.c:13-16) */
+    NM_E_ARGUMENT = 6,       /* ValueError / IndexError raised by the Python wrapper                    */
+    NM_E_DEVICE = 7,         /* RuntimeError: HIP failure, no device, kernel fault                      */
+    NM_E_KMER_NOT_FOUND = 8, /* RuntimeError "k-mer was not found in the index" (search.py:699-722)     */
+    NM_E_TOO_LARGE = 9       /* text too large for this build                                           */
+};
+
+const char *nm_last_error(void);
+const char *nm_version(void);
+
+/* ---------------------------------------------------------------------------------- index ---
+ * Host-side build: FASTA -> both-strand text -> suffix array -> BWT -> rank blocks -> file.
+ * Replaces generate_fm_index(fasta, index, compression_ratio, seed_length)
+ * (src/newmap-generate-index.c:11-58).  `sa_ratio` is accepted and recorded for interface parity
+ * (counting never touches a sampled suffix array); `seed_len` is the default length of the
+ * device seed table built at nm_index_open time. */
+int nm_index_build(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len);
+
+/* Read an index file and upload it to HBM of `device` (>= 0).  seed_len_override < 0 keeps the
+ * length recorded in the file; 0 disables the seed table.  Replaces createIndex()
+ * (src/newmap-count.c:9-17) -- but returns an error instead of continuing with a bad handle. */
+int nm_index_open(const char *index_path, int device, int seed_len_override, nm_index **out);
+void nm_index_close(nm_index *ix);
+
+/* index facts: 0 n (BWT length), 1 forward text length, 2 separators, 3 records, 4 raw bases,
+ * 5 seed length in use, 6 device bytes held, 7 sa_ratio recorded */
+uint64_t nm_index_info(const nm_index *ix, int what);
+
+/* ------------------------------------------------------------------------- compat seam ------
+ * Forward-strand occurrence counts, exactly the two functions of src/newmap-count.c.
+ * k-mers may contain any byte: a k-mer with a non-ACGT byte counts 0. */
+int nm_count_kmers(nm_index *ix, const uint8_t *kmers, const uint64_t *offsets /* n+1 */,
+                   uint64_t n, uint32_t *counts_out);
+int nm_count_from_sequence(nm_index *ix, const uint8_t *seq, uint64_t seq_len,
+                           const uint64_t *starts, const uint64_t *lens, uint64_t n,
+                           uint32_t *counts_out);
+
+/* ----------------------------------------------------------------------- fused hot path -----
+ * One segment (bytes seq[0..seq_len), of which the first num_kmers are positions and the rest
+ * is lookahead): newmap/search.py:383-548 `binary_search` for range mode, :551-644
+ * `linear_search` for list mode.  out has num_kmers elements of elem_bytes (1, 2 or 4) bytes
+ * (search.py:204-212).  *n_ambiguous = positions whose own byte is not in ACGTacgt (:403).
+ * On NM_E_KMER_NOT_FOUND, *bad_pos is the first position whose k-mer is absent from the index. */
+int nm_min_unique_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
+                          uint32_t kmin, uint32_t kmax, uint32_t initial_len, int use_revcomp,
+                          int elem_bytes, void *out, uint64_t *n_ambiguous, uint64_t *bad_pos);
+int nm_fixed_k_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
+                       const uint32_t *ks, uint32_t nk, int use_revcomp, int elem_bytes, void *out,
+                       uint64_t *n_ambiguous, uint64_t *bad_pos);
+
+/* newmap/search.py:744-766 + :769-882 in one launch: out[p] (uint32) = per-position inclusive
+ * upper search length; ambiguous positions keep kmax. */
+int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
+                           uint32_t kmax, uint32_t *out);
+
+/* --------------------------------------------------------------- device-resident variants ---
+ * Same operations with seq/out already in HBM (pointers from hipMalloc or a torch tensor's
+ * data_ptr on the SAME device) and asynchronous on `stream` (hipStream_t, NULL = the handle's
+ * own stream).  `d_status` points to NM_STATUS_WORDS uint64 in device memory, reset by the
+ * call: [0] ambiguous positions, [1] 1 if some k-mer was absent, [2] first absent position
+ * (UINT64_MAX if none); and, only after nm_set_option(ix, NM_OPT_COUNT_STEPS, 1) -- the
+ * "counter build" of the kernel used for roofline accounting -- [3] LF steps executed,
+ * [4] distinct 32-byte rank blocks those steps read (lo and hi in one block count once),
+ * [5] seed-table lookups, [6] strand-block reads, [7] positions searched. */
+#define NM_STATUS_WORDS 8
+int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
+                              uint32_t kmin, uint32_t kmax, int use_revcomp, int elem_bytes,
+                              void *d_out, uint64_t *d_status, void *stream);
+int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
+                           const uint32_t *ks, uint32_t nk, int use_revcomp, int elem_bytes,
+                           void *d_out, uint64_t *d_status, void *stream);
+
+enum { NM_OPT_COUNT_STEPS = 1, NM_OPT_BLOCK_THREADS = 2 };
+int nm_set_option(nm_index *ix, int option, int64_t value);
+
+/* small device-memory helpers so a host program needs no other HIP binding */
+int nm_dev_alloc(int device, uint64_t bytes, void **out);
+int nm_dev_free(int device, void *p);
+int nm_dev_upload(int device, void *dst, const void *src, uint64_t bytes);
+int nm_dev_download(int device, void *dst, const void *src, uint64_t bytes);
+int nm_dev_sync(int device);
+int nm_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEWMAP_AMD_H */

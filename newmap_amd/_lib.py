@@ -1,0 +1,124 @@
+"""ctypes binding of libnewmap_amd.so (include/newmap_amd.h).  Fails loudly when the library
+is missing -- the package has no other compute path."""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libnewmap_amd.so"
+
+NM_OK = 0
+NM_E_FILE_OPEN, NM_E_ALLOC, NM_E_FILE_EXISTS, NM_E_FILE_WRITE, NM_E_FILE_FORMAT = 1, 2, 3, 4, 5
+NM_E_ARGUMENT, NM_E_DEVICE, NM_E_KMER_NOT_FOUND, NM_E_TOO_LARGE = 6, 7, 8, 9
+NM_STATUS_WORDS = 8
+NM_OPT_COUNT_STEPS = 1
+
+EXPORTS = [
+    "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_close",
+    "nm_index_info", "nm_count_kmers", "nm_count_from_sequence", "nm_min_unique_segment",
+    "nm_fixed_k_segment", "nm_upper_bound_segment", "nm_min_unique_segment_dev",
+    "nm_fixed_k_segment_dev", "nm_set_option", "nm_dev_alloc", "nm_dev_free", "nm_dev_upload",
+    "nm_dev_download", "nm_dev_sync", "nm_device_count",
+]
+
+_lib = None
+
+
+class EngineMissingError(ImportError):
+    pass
+
+
+def build(verbose: bool = False) -> Path:
+    """Compile the extension in-tree (g++ for the host builder, hipcc --offload-arch=gfx950)."""
+    import subprocess
+    cmd = ["make", "-C", str(_HERE / "csrc"), "all"]
+    subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise EngineMissingError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C newmap_amd/csrc`).  newmap_amd has no CPU fallback.")
+    # When torch is used in the same process its bundled HIP runtime (same SONAME,
+    # libamdhip64.so.7) must be the one this library binds to, so import it first.
+    if os.environ.get("NEWMAP_AMD_WITH_TORCH", "") == "1" and "torch" not in sys.modules:
+        import torch  # noqa: F401
+    L = ctypes.CDLL(str(LIB_PATH))
+    c = ctypes
+    vp, u64, u32, i32, u8 = c.c_void_p, c.c_uint64, c.c_uint32, c.c_int, c.c_uint8
+    pp = c.POINTER(c.c_void_p)
+    L.nm_last_error.restype = c.c_char_p
+    L.nm_version.restype = c.c_char_p
+    L.nm_index_build.restype = i32
+    L.nm_index_build.argtypes = [c.c_char_p, c.c_char_p, u8, u8]
+    L.nm_index_open.restype = i32
+    L.nm_index_open.argtypes = [c.c_char_p, i32, i32, pp]
+    L.nm_index_close.restype = None
+    L.nm_index_close.argtypes = [vp]
+    L.nm_index_info.restype = u64
+    L.nm_index_info.argtypes = [vp, i32]
+    L.nm_count_kmers.restype = i32
+    L.nm_count_kmers.argtypes = [vp, vp, vp, u64, vp]
+    L.nm_count_from_sequence.restype = i32
+    L.nm_count_from_sequence.argtypes = [vp, vp, u64, vp, vp, u64, vp]
+    L.nm_min_unique_segment.restype = i32
+    L.nm_min_unique_segment.argtypes = [vp, vp, u64, u64, u32, u32, u32, i32, i32, vp, vp, vp]
+    L.nm_fixed_k_segment.restype = i32
+    L.nm_fixed_k_segment.argtypes = [vp, vp, u64, u64, vp, u32, i32, i32, vp, vp, vp]
+    L.nm_upper_bound_segment.restype = i32
+    L.nm_upper_bound_segment.argtypes = [vp, vp, u64, u64, u32, vp]
+    L.nm_min_unique_segment_dev.restype = i32
+    L.nm_min_unique_segment_dev.argtypes = [vp, vp, u64, u64, u32, u32, i32, i32, vp, vp, vp]
+    L.nm_fixed_k_segment_dev.restype = i32
+    L.nm_fixed_k_segment_dev.argtypes = [vp, vp, u64, u64, vp, u32, i32, i32, vp, vp, vp]
+    L.nm_set_option.restype = i32
+    L.nm_set_option.argtypes = [vp, i32, c.c_int64]
+    L.nm_dev_alloc.restype = i32
+    L.nm_dev_alloc.argtypes = [i32, u64, pp]
+    L.nm_dev_free.restype = i32
+    L.nm_dev_free.argtypes = [i32, vp]
+    L.nm_dev_upload.restype = i32
+    L.nm_dev_upload.argtypes = [i32, vp, vp, u64]
+    L.nm_dev_download.restype = i32
+    L.nm_dev_download.argtypes = [i32, vp, vp, u64]
+    L.nm_dev_sync.restype = i32
+    L.nm_dev_sync.argtypes = [i32]
+    L.nm_device_count.restype = i32
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().nm_last_error().decode("utf-8", "replace")
+
+
+def raise_for(code: int, not_found_detail: str | None = None):
+    """Map a C-ABI return code to the exception class the reference raises for the same
+    condition (src/newmap-generate-index.c:32-54, src/newmap-count.c:13-16,
+    newmap/search.py:719-722)."""
+    if code == NM_OK:
+        return
+    msg = last_error()
+    if code == NM_E_FILE_OPEN:
+        raise FileNotFoundError(msg)
+    if code == NM_E_ALLOC:
+        raise MemoryError(msg)
+    if code == NM_E_FILE_EXISTS:
+        raise FileExistsError(msg)
+    if code in (NM_E_FILE_WRITE, NM_E_FILE_FORMAT):
+        raise OSError(msg)
+    if code == NM_E_ARGUMENT:
+        raise ValueError(msg)
+    if code == NM_E_KMER_NOT_FOUND:
+        raise RuntimeError(not_found_detail or msg)
+    if code == NM_E_TOO_LARGE:
+        raise OverflowError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,236 @@
+// nm_build.cpp -- host-side index construction for the MI355X engine.
+//
+// Replaces generate_fm_index() of the reference (src/newmap-generate-index.c:11-58,82-104 ->
+// awFmCreateIndexFromFasta): FASTA -> both-strand run text (nm_format.h) -> suffix array
+// (SA-IS, nm_sais.hpp) -> BWT -> 32-byte rank blocks + strand blocks + separator list -> file.
+// The reference indexes the forward strand only and searches the reverse complement as a
+// second query (newmap/search.py:677-697); indexing both strands turns that into one search
+// and lets the device extend a k-mer one base at a time.
+//
+// FASTA reading follows newmap/fasta.py:47,59,75 (the `search` side of the reference) so that
+// `index` and `search` agree on what a record is: lines are right-stripped, '>' or ';' opens a
+// record, everything else is sequence data; records without data do not exist.
+#include <algorithm>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <zlib.h>
+
+#include "../../include/newmap_amd.h"
+#include "nm_format.h"
+#include "nm_internal.h"
+#include "nm_sais.hpp"
+
+static thread_local char g_err[1024] = "";
+
+void nm_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *nm_last_error(void) { return g_err; }
+extern "C" const char *nm_version(void) { return "newmap_amd 0.1 (gfx950, index format 1)"; }
+
+namespace {
+
+// text symbols handed to the suffix sorter
+enum : uint8_t { SYM_END = 0, SYM_SEP = 1, SYM_A = 2 };   // A,C,G,T = 2..5
+
+struct Lut {
+    uint8_t code[256];
+    Lut() {
+        memset(code, 0xFF, sizeof code);
+        code[(int)'A'] = code[(int)'a'] = 0;
+        code[(int)'C'] = code[(int)'c'] = 1;
+        code[(int)'G'] = code[(int)'g'] = 2;
+        code[(int)'T'] = code[(int)'t'] = 3;
+    }
+};
+const Lut g_lut;
+
+inline bool is_space(unsigned char c) {      // what bytes.rstrip() removes
+    return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f';
+}
+
+struct FastaText {
+    std::vector<uint8_t> f;        // forward run text F: runs of SYM_A.. each followed by SYM_SEP
+    uint64_t n_records = 0, raw_bases = 0, n_runs = 0;
+    uint64_t base_count[4] = {0, 0, 0, 0};
+    bool in_run = false;
+    bool record_has_data = false;
+
+    void end_run() {
+        if (in_run) { f.push_back(SYM_SEP); n_runs++; in_run = false; }
+    }
+    void data(const unsigned char *p, size_t len) {
+        if (!len) return;
+        if (!record_has_data) { record_has_data = true; n_records++; }
+        raw_bases += len;
+        for (size_t i = 0; i < len; i++) {
+            uint8_t c = g_lut.code[p[i]];
+            if (c != 0xFF) { f.push_back((uint8_t)(SYM_A + c)); base_count[c]++; in_run = true; }
+            else end_run();
+        }
+    }
+    void header() { end_run(); record_has_data = false; }
+    void line(const unsigned char *p, size_t len) {
+        while (len && is_space(p[len - 1])) len--;
+        if (len && (p[0] == '>' || p[0] == ';')) header();
+        else data(p, len);
+    }
+    void finish() { end_run(); }
+};
+
+int read_fasta(const char *path, FastaText &ft) {
+    gzFile gz = gzopen(path, "rb");          // transparent for plain files
+    if (!gz) { nm_set_error("Could not open fasta file to create index: %s", path); return NM_E_FILE_OPEN; }
+    gzbuffer(gz, 1 << 20);
+    std::vector<unsigned char> buf(1 << 22);
+    std::vector<unsigned char> carry;
+    for (;;) {
+        int got = gzread(gz, buf.data(), (unsigned)buf.size());
+        if (got < 0) { gzclose(gz); nm_set_error("read error in %s", path); return NM_E_FILE_OPEN; }
+        if (got == 0) break;
+        size_t start = 0;
+        for (size_t i = 0; i < (size_t)got; i++) {
+            if (buf[i] != '\n') continue;
+            if (!carry.empty()) {
+                carry.insert(carry.end(), buf.begin() + start, buf.begin() + i);
+                ft.line(carry.data(), carry.size());
+                carry.clear();
+            } else {
+                ft.line(buf.data() + start, i - start);
+            }
+            start = i + 1;
+        }
+        carry.insert(carry.end(), buf.begin() + start, buf.begin() + got);
+    }
+    if (!carry.empty()) ft.line(carry.data(), carry.size());
+    ft.finish();
+    gzclose(gz);
+    return NM_OK;
+}
+
+template <class I>
+int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_ratio, uint8_t seed_len) {
+    const uint64_t nf = ft.f.size();
+    const uint64_t n = 2 * nf + 1;
+    // T = F . RC . '#'
+    std::vector<uint8_t> T(n);
+    if (nf) {
+        memcpy(T.data(), ft.f.data(), nf);
+        // reverse F without its trailing separator, complement the bases, close with a separator
+        for (uint64_t i = 0; i + 1 < nf; i++) {
+            uint8_t c = ft.f[nf - 2 - i];
+            T[nf + i] = c >= SYM_A ? (uint8_t)(SYM_A + 3 - (c - SYM_A)) : c;
+        }
+        T[2 * nf - 1] = SYM_SEP;
+    }
+    T[n - 1] = SYM_END;
+
+    std::vector<I> SA(n);
+    nm::sais<uint8_t, I>(T.data(), SA.data(), (I)n, (I)6);
+
+    nm_file_header h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, NM_MAGIC, 8);
+    h.version = NM_FORMAT_VERSION;
+    h.header_bytes = sizeof h;
+    h.n = n;
+    h.n_fwd = nf;
+    h.n_sep = 2 * ft.n_runs + 1;
+    for (int c = 0; c < 4; c++) h.base_count[c] = ft.base_count[c] + ft.base_count[3 - c];
+    h.n_rank_blocks = n / 64 + 1;
+    h.n_strand_blocks = n / 64 + 1;
+    h.n_records = ft.n_records;
+    h.raw_bases = ft.raw_bases;
+    h.n_runs = ft.n_runs;
+    h.sa_ratio = sa_ratio;
+    h.seed_len = seed_len;
+    h.n_super = (n >> NM_SUPER_SHIFT) + 1;
+    if (h.n_super > NM_MAX_SUPER) { nm_set_error("text of %llu symbols is too large", (unsigned long long)n); return NM_E_TOO_LARGE; }
+
+    std::vector<nm_rank_block> rank(h.n_rank_blocks);
+    std::vector<nm_strand_block> strand(h.n_strand_blocks);
+    std::vector<uint64_t> sep;
+    sep.reserve(h.n_sep);
+    memset(rank.data(), 0, rank.size() * sizeof(nm_rank_block));
+    memset(strand.data(), 0, strand.size() * sizeof(nm_strand_block));
+
+    uint64_t abs_cnt[4] = {0, 0, 0, 0}, sup_cnt[4] = {0, 0, 0, 0}, rc_before = 0;
+    for (uint64_t i = 0; i <= n; i++) {
+        if ((i & 63) == 0) {
+            if ((i & ((1ULL << NM_SUPER_SHIFT) - 1)) == 0) {
+                for (int c = 0; c < 4; c++) { sup_cnt[c] = abs_cnt[c]; h.super_cnt[i >> NM_SUPER_SHIFT][c] = abs_cnt[c]; }
+            }
+            nm_rank_block &b = rank[i >> 6];
+            for (int c = 0; c < 4; c++) b.cnt[c] = (uint32_t)(abs_cnt[c] - sup_cnt[c]);
+            strand[i >> 6].before = rc_before;
+        }
+        if (i == n) break;
+        const uint64_t p = (uint64_t)SA[i];
+        const uint8_t ch = T[p ? p - 1 : n - 1];
+        nm_rank_block &b = rank[i >> 6];
+        const uint64_t bit = 1ULL << (i & 63);
+        if (ch >= SYM_A) {
+            const unsigned c = ch - SYM_A;
+            abs_cnt[c]++;
+            if (c & 1) b.lo |= bit;
+            if (c & 2) b.hi |= bit;
+        } else {
+            sep.push_back(i);
+        }
+        if (p >= nf && p < 2 * nf) { strand[i >> 6].bits |= bit; rc_before++; }
+    }
+    for (uint64_t s : sep) rank[s >> 6].cnt[0] |= NM_SEP_FLAG;
+    if (sep.size() != h.n_sep) { nm_set_error("internal error: separator count mismatch"); return NM_E_FILE_WRITE; }
+
+    h.off_rank = sizeof h;
+    h.off_strand = h.off_rank + rank.size() * sizeof(nm_rank_block);
+    h.off_sep = h.off_strand + strand.size() * sizeof(nm_strand_block);
+    h.file_bytes = h.off_sep + sep.size() * sizeof(uint64_t);
+
+    FILE *fp = fopen(index_path, "wb");        // overwrite, like the reference at its pinned version
+    if (!fp) { nm_set_error("Could not write index file %s: %s", index_path, strerror(errno)); return NM_E_FILE_WRITE; }
+    bool ok = fwrite(&h, sizeof h, 1, fp) == 1 &&
+              fwrite(rank.data(), sizeof(nm_rank_block), rank.size(), fp) == rank.size() &&
+              fwrite(strand.data(), sizeof(nm_strand_block), strand.size(), fp) == strand.size() &&
+              (sep.empty() || fwrite(sep.data(), sizeof(uint64_t), sep.size(), fp) == sep.size());
+    ok = (fclose(fp) == 0) && ok;
+    if (!ok) { nm_set_error("Could not write index file %s", index_path); return NM_E_FILE_WRITE; }
+    return NM_OK;
+}
+
+}  // namespace
+
+extern "C" int nm_index_build(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len) {
+    if (!fasta_path || !index_path) { nm_set_error("null path"); return NM_E_ARGUMENT; }
+    if (seed_len > 16) { nm_set_error("seed length %d is larger than the supported maximum 16", (int)seed_len); return NM_E_ARGUMENT; }
+    try {
+        {   // gzopen succeeds lazily on some platforms; probe with fopen for the reference's error
+            FILE *probe = fopen(fasta_path, "rb");
+            if (!probe) { nm_set_error("Could not open fasta file to create index: %s", fasta_path); return NM_E_FILE_OPEN; }
+            fclose(probe);
+        }
+        FastaText ft;
+        int rc = read_fasta(fasta_path, ft);
+        if (rc != NM_OK) return rc;
+        const uint64_t n = 2 * (uint64_t)ft.f.size() + 1;
+        if (n < (1ULL << 31) - 8) return build_and_write<int32_t>(ft, index_path, sa_ratio, seed_len);
+        return build_and_write<int64_t>(ft, index_path, sa_ratio, seed_len);
+    } catch (const std::bad_alloc &) {
+        nm_set_error("Could not allocate enough memory to create index");
+        return NM_E_ALLOC;
+    } catch (const std::exception &e) {
+        nm_set_error("index build failed: %s", e.what());
+        return NM_E_FILE_WRITE;
+    }
+}

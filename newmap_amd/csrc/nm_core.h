@@ -1,0 +1,307 @@
+// nm_core.h -- per-position search logic of the engine, written once.
+//
+// Included by nm_engine.hip with NM_HD = __device__ __forceinline__ (the product: every function
+// here runs on the GPU only) and by the test-only host simulator tests/hostsim/hostsim.cpp with
+// NM_HD = inline (lets the CPU test-suite exercise this exact logic against the oracle before
+// a GPU is involved; that harness is not part of the product and is never loaded by it).
+//
+// What each function restates (file:line in the reference checkout):
+//   nm_min_unique_one   newmap/search.py:383-548 binary_search, for ONE position, as the closed
+//                       form of SURVEY.md Appendix A.2: least k in [kmin, U_p] whose total count
+//                       is 1.  Because the total is >= 1 and non-increasing in k (:489-535 bisect
+//                       a monotone predicate), the first k at which the suffix-array interval of
+//                       the growing k-mer has size 1 decides the answer: max(k, kmin) if that
+//                       still lies within U_p, else 0.
+//   nm_fixed_k_one      newmap/search.py:551-644 linear_search for ONE position (list order,
+//                       tail truncation :590, permanent drop on ambiguity :593-596, `count == 1`
+//                       stop :639).
+//   nm_count_fwd_one    src/newmap-count.c:91-206 count_kmers_from_sequence for ONE k-mer.
+//   nm_upper_one        newmap/search.py:744-766 + :769-882 for ONE position.
+//   the strand sum of newmap/search.py:647-697 is implicit: the index holds both strands
+//   (nm_format.h), so one interval gives forward + reverse-complement occurrences; `--norc`
+//   splits the interval with the strand blocks instead.
+#ifndef NM_CORE_H
+#define NM_CORE_H
+
+#include <stdint.h>
+#include "nm_format.h"
+
+#ifndef NM_HD
+#error "define NM_HD before including nm_core.h"
+#endif
+
+struct nm_enc_word {            // 64 sequence positions, produced by the encode kernel
+    uint64_t lo, hi;            // bit-planes of the 2-bit base codes (A=0 C=1 G=2 T=3)
+    uint64_t amb;               // 1 = byte not in ACGTacgt, or position >= seq_len
+    uint64_t pad;
+};
+
+struct nm_view {                // the index as the kernels see it
+    const nm_rank_block *rank;
+    const nm_strand_block *strand;
+    const uint64_t *sep;        // sorted BWT positions of separators
+    const uint64_t *seed;       // 4^seed_len entries: interval start (40 bits) | size (24 bits, saturating)
+    const uint64_t *superC;     // [n_super][4]: C[c] + occurrences of c before the superblock
+    uint64_t n;                 // BWT length
+    uint64_t n_sep;
+    uint64_t C[4];              // == superC[0][*]
+    uint32_t seed_len;
+    uint32_t n_super;
+};
+
+struct nm_tally {               // counter build only
+    uint32_t steps, blocks, seeds, strands;
+};
+
+#define NM_SEED_LO_BITS 40
+#define NM_SEED_LO_MASK ((1ULL << NM_SEED_LO_BITS) - 1)
+#define NM_SEED_CNT_SAT 0xFFFFFFu
+
+NM_HD uint32_t nm_base_code(uint32_t byte) {     // 0..3 for ACGTacgt, 4 otherwise
+    uint32_t u = byte & 0xDFu;
+    return u == 0x41u ? 0u : (u == 0x43u ? 1u : (u == 0x47u ? 2u : (u == 0x54u ? 3u : 4u)));
+}
+
+NM_HD uint32_t nm_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+
+// number of separator positions s with a <= s < b (b - a <= 64); only reached for the rare
+// rank blocks flagged NM_SEP_FLAG
+NM_HD uint32_t nm_sep_between(const nm_view &ix, uint64_t a, uint64_t b) {
+    uint64_t lo = 0, hi = ix.n_sep;
+    while (lo < hi) {                       // first separator >= a
+        uint64_t mid = (lo + hi) >> 1;
+        if (ix.sep[mid] < a) lo = mid + 1; else hi = mid;
+    }
+    uint32_t c = 0;
+    while (lo < ix.n_sep && ix.sep[lo] < b) { c++; lo++; }
+    return c;
+}
+
+// LF step: C[c] + rank_c(BWT, i)
+template <bool BIG>
+NM_HD uint64_t nm_lf(const nm_view &ix, uint32_t c, uint64_t i) {
+    const nm_rank_block *b = ix.rank + (i >> 6);
+    const uint32_t c0 = b->cnt[0], c1 = b->cnt[1], c2 = b->cnt[2], c3 = b->cnt[3];
+    const uint64_t plo = b->lo, phi = b->hi;
+    const uint32_t cc = c == 0 ? (c0 & ~NM_SEP_FLAG) : (c == 1 ? c1 : (c == 2 ? c2 : c3));
+    uint64_t m = ((c & 1u) ? plo : ~plo) & ((c & 2u) ? phi : ~phi);
+    const uint32_t off = (uint32_t)(i & 63);
+    m &= (1ULL << off) - 1ULL;
+    uint32_t r = cc + nm_popc64(m);
+    if ((c0 & NM_SEP_FLAG) && c == 0 && off) r -= nm_sep_between(ix, i - off, i);
+    if (BIG) return ix.superC[(i >> NM_SUPER_SHIFT) * 4 + c] + r;
+    return (c == 0 ? ix.C[0] : (c == 1 ? ix.C[1] : (c == 2 ? ix.C[2] : ix.C[3]))) + r;
+}
+
+// suffixes of the RC half among suffix-array positions [0, i)
+NM_HD uint64_t nm_strand_rank(const nm_view &ix, uint64_t i) {
+    const nm_strand_block *b = ix.strand + (i >> 6);
+    return b->before + nm_popc64(b->bits & ((1ULL << (i & 63)) - 1ULL));
+}
+NM_HD bool nm_strand_bit(const nm_view &ix, uint64_t i) {
+    return (ix.strand[i >> 6].bits >> (i & 63)) & 1ULL;
+}
+
+struct nm_window { uint64_t lo, hi, amb; };      // sequence positions [pos, pos+64)
+
+NM_HD nm_window nm_load_window(const nm_enc_word *enc, uint64_t pos) {
+    const nm_enc_word *w = enc + (pos >> 6);
+    const uint32_t s = (uint32_t)(pos & 63);
+    nm_window r;
+    r.lo = w[0].lo; r.hi = w[0].hi; r.amb = w[0].amb;
+    if (s) {
+        r.lo = (r.lo >> s) | (w[1].lo << (64 - s));
+        r.hi = (r.hi >> s) | (w[1].hi << (64 - s));
+        r.amb = (r.amb >> s) | (w[1].amb << (64 - s));
+    }
+    return r;
+}
+
+NM_HD uint32_t nm_window_code(const nm_window &w, uint32_t j) {
+    return (uint32_t)((w.lo >> j) & 1ULL) | ((uint32_t)((w.hi >> j) & 1ULL) << 1);
+}
+
+// seed-table slot of the s-mer at the start of a window: low s bits = lo plane, next s = hi plane
+NM_HD uint64_t nm_seed_slot(const nm_window &w, uint32_t s) {
+    const uint64_t m = (1ULL << s) - 1ULL;
+    return (w.lo & m) | ((w.hi & m) << s);
+}
+NM_HD uint32_t nm_seed_slot_code(uint64_t slot, uint32_t s, uint32_t j) {
+    return (uint32_t)((slot >> j) & 1ULL) | ((uint32_t)((slot >> (s + j)) & 1ULL) << 1);
+}
+
+// are sequence positions [p+from, p+to) all unambiguous?  w/kbase: the window currently held
+NM_HD bool nm_all_valid(const nm_enc_word *enc, uint64_t p, nm_window &w, uint32_t &kbase,
+                        uint32_t from, uint32_t to) {
+    uint32_t k = from;
+    while (k < to) {
+        uint32_t j = k - kbase;
+        if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+        const uint32_t span = (to - k) < (64 - j) ? (to - k) : (64 - j);
+        const uint64_t mask = (span == 64 ? ~0ULL : ((1ULL << span) - 1ULL)) << j;
+        if (w.amb & mask) return false;
+        k += span;
+    }
+    return true;
+}
+
+// One position of range mode.  Returns the element to store (0 = nothing unique in range).
+template <bool BIG, bool RC>
+NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint64_t p,
+                                 uint32_t kmin, uint32_t kmax, bool &amb0, bool &err, nm_tally &t) {
+    nm_window w = nm_load_window(enc, p);
+    uint32_t kbase = 0;
+    amb0 = (w.amb & 1ULL) != 0;
+    err = false;
+    if (amb0) return 0;                                   // search.py:399 mask -> finished, 0
+    uint64_t lo = 0, hi = ix.n;
+    uint32_t k = 0;
+    const uint32_t s = ix.seed_len;
+    if (s && kmin >= s) {
+        if (w.amb & ((1ULL << s) - 1ULL)) return 0;       // U_p < s <= kmin  (search.py:437)
+        const uint64_t e = ix.seed[nm_seed_slot(w, s)];
+        t.seeds++;
+        const uint32_t c = (uint32_t)(e >> NM_SEED_LO_BITS);
+        if (c != NM_SEED_CNT_SAT) { lo = e & NM_SEED_LO_MASK; hi = lo + c; k = s; }
+    }
+    for (;;) {
+        const uint64_t cnt = hi - lo;
+        if (cnt == 0) { err = true; return 0; }           // search.py:699-722
+        if (RC) {
+            if (cnt == 1) break;
+        } else {
+            if (cnt == 1) {
+                t.strands++;
+                if (!nm_strand_bit(ix, lo)) { err = true; return 0; }
+                break;
+            }
+            if (k >= kmin) {
+                const uint64_t f = nm_strand_rank(ix, hi) - nm_strand_rank(ix, lo);
+                t.strands += 2;
+                if (f == 0) { err = true; return 0; }
+                if (f == 1) return k;                     // least k >= kmin with forward count 1
+            }
+        }
+        if (k >= kmax) return 0;
+        uint32_t j = k - kbase;
+        if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+        if ((w.amb >> j) & 1ULL) return 0;                // k == U_p and still not unique
+        const uint32_t c = 3u - nm_window_code(w, j);     // prepend the complement: search rc(k-mer)
+        t.steps++;
+        t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u;
+        lo = nm_lf<BIG>(ix, c, lo);
+        hi = nm_lf<BIG>(ix, c, hi);
+        k++;
+    }
+    const uint32_t ans = k > kmin ? k : kmin;             // k <= kmax here, kmin <= kmax
+    if (!nm_all_valid(enc, p, w, kbase, k, ans)) return 0;   // ans must not exceed U_p
+    return ans;
+}
+
+// One position of list mode.
+template <bool BIG, bool RC>
+NM_HD uint32_t nm_fixed_k_one(const nm_view &ix, const nm_enc_word *enc, uint64_t p, uint64_t seq_len,
+                              const uint32_t *ks, uint32_t nk, bool &amb0, bool &err, nm_tally &t) {
+    nm_window w = nm_load_window(enc, p);
+    uint32_t kbase = 0;
+    amb0 = (w.amb & 1ULL) != 0;
+    err = false;
+    if (amb0) return 0;
+    const uint64_t rem = seq_len - p;
+    uint64_t lo = 0, hi = ix.n;
+    uint32_t k = 0;
+    uint32_t checked = 1;                                 // positions [p, p+checked) known valid
+    const uint32_t s = ix.seed_len;
+    for (uint32_t q = 0; q < nk; q++) {
+        const uint32_t K = ks[q];
+        const uint32_t L = (uint64_t)K < rem ? K : (uint32_t)rem;      // search.py:590 truncation
+        if (L > checked) {
+            if (!nm_all_valid(enc, p, w, kbase, checked, L)) return 0; // search.py:593-596 (permanent)
+            checked = L;
+        }
+        if (L < k) { lo = 0; hi = ix.n; k = 0; }          // shorter than what was searched: restart
+        if (k == 0 && s && L >= s) {
+            if (kbase != 0) { w = nm_load_window(enc, p); kbase = 0; }
+            const uint64_t e = ix.seed[nm_seed_slot(w, s)];
+            t.seeds++;
+            const uint32_t c = (uint32_t)(e >> NM_SEED_LO_BITS);
+            if (c != NM_SEED_CNT_SAT) { lo = e & NM_SEED_LO_MASK; hi = lo + c; k = s; }
+        }
+        while (k < L && hi - lo > 1) {
+            uint32_t j = k - kbase;
+            if (j >= 64 || k < kbase) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+            const uint32_t c = 3u - nm_window_code(w, j);
+            t.steps++;
+            t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u;
+            lo = nm_lf<BIG>(ix, c, lo);
+            hi = nm_lf<BIG>(ix, c, hi);
+            k++;
+        }
+        const uint64_t cnt = hi - lo;
+        if (cnt == 0) { err = true; return 0; }
+        bool uniq;
+        if (RC) {
+            uniq = cnt == 1;
+        } else if (cnt == 1) {
+            t.strands++;
+            if (!nm_strand_bit(ix, lo)) { err = true; return 0; }
+            uniq = true;
+        } else {
+            const uint64_t f = nm_strand_rank(ix, hi) - nm_strand_rank(ix, lo);
+            t.strands += 2;
+            if (f == 0) { err = true; return 0; }
+            uniq = f == 1;
+        }
+        if (uniq) return K;                               // search.py:627-639
+    }
+    return 0;
+}
+
+// forward-strand occurrences of one raw k-mer (any byte; non-ACGT -> 0)
+template <bool BIG>
+NM_HD uint32_t nm_count_fwd_one(const nm_view &ix, const uint8_t *kmer, uint64_t len, nm_tally &t) {
+    uint64_t lo = 0, hi = ix.n;
+    for (uint64_t j = 0; j < len; j++) {
+        const uint32_t code = nm_base_code(kmer[j]);
+        if (code > 3) return 0;
+        const uint32_t c = 3u - code;
+        t.steps++;
+        lo = nm_lf<BIG>(ix, c, lo);
+        hi = nm_lf<BIG>(ix, c, hi);
+        if (lo >= hi) return 0;
+    }
+    if (len == 0) return 0;
+    t.strands += 2;
+    return (uint32_t)(nm_strand_rank(ix, hi) - nm_strand_rank(ix, lo));
+}
+
+// per-position inclusive upper search length (ambiguous positions keep kmax)
+NM_HD uint32_t nm_upper_one(const nm_enc_word *enc, uint64_t p, uint32_t kmax) {
+    nm_window w = nm_load_window(enc, p);
+    if (w.amb & 1ULL) return kmax;
+    uint32_t k = 0, kbase = 0;
+    while (k < kmax) {
+        uint32_t j = k - kbase;
+        if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+        const uint64_t a = w.amb >> j;
+        if (a) { k += (uint32_t)__builtin_ctzll(a); break; }
+        k += 64 - j;
+    }
+    return k < kmax ? k : kmax;
+}
+
+// seed-table entry of slot `slot`: interval of the reverse complement of the s-mer it spells
+template <bool BIG>
+NM_HD uint64_t nm_seed_entry(const nm_view &ix, uint64_t slot, uint32_t s) {
+    uint64_t lo = 0, hi = ix.n;
+    for (uint32_t j = 0; j < s && lo < hi; j++) {
+        const uint32_t c = 3u - nm_seed_slot_code(slot, s, j);
+        lo = nm_lf<BIG>(ix, c, lo);
+        hi = nm_lf<BIG>(ix, c, hi);
+    }
+    uint64_t cnt = hi > lo ? hi - lo : 0;
+    if (cnt >= NM_SEED_CNT_SAT) cnt = NM_SEED_CNT_SAT;
+    return (lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS);
+}
+
+#endif

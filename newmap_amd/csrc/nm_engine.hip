@@ -1,0 +1,584 @@
+// nm_engine.hip -- the MI355X (gfx950 / CDNA4) engine behind the C-ABI of include/newmap_amd.h.
+//
+// Kernels (all integer / bit work, HBM-gather bound, no MFMA):
+//   k_encode        sequence bytes -> 2 bit-planes + ambiguity plane (wave ballots), 32 B / 64 bases
+//   k_seed          device-side construction of the 4^s seed table from the rank blocks
+//   k_min_unique    range mode, one lane per genome position (newmap/search.py:383-548)
+//   k_fixed_k       list mode,  one lane per genome position (newmap/search.py:551-644)
+//   k_count         forward-strand counts of (start, len) k-mers (src/newmap-count.c:91-206)
+//   k_upper         per-position upper search length (newmap/search.py:744-882)
+// The per-position logic lives in nm_core.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/newmap_amd.h"
+#include "nm_format.h"
+#include "nm_internal.h"
+
+#define NM_HD __device__ __forceinline__
+#include "nm_core.h"
+
+#define NM_WAVE 64
+#define NM_BLOCK 256
+
+// ------------------------------------------------------------------------------ kernels ----
+
+__global__ __launch_bounds__(NM_BLOCK) void k_encode(const uint8_t *__restrict__ seq, uint64_t seq_len,
+                                                     nm_enc_word *__restrict__ enc, uint64_t n_words) {
+    // one wave per 64-base word: three ballots give the three planes
+    const uint64_t wave = (blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (wave >= n_words) return;
+    const uint64_t pos = wave * 64 + lane;
+    uint32_t code = 4;
+    if (pos < seq_len) code = nm_base_code(seq[pos]);
+    const uint64_t lo = __ballot((code & 1u) && code < 4);
+    const uint64_t hi = __ballot((code & 2u) && code < 4);
+    const uint64_t amb = __ballot(code > 3);
+    if (lane == 0) {
+        nm_enc_word w;
+        w.lo = lo; w.hi = hi; w.amb = amb; w.pad = 0;
+        enc[wave] = w;
+    }
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_seed(nm_view ix, uint64_t *__restrict__ table, uint64_t n_slots, uint32_t s) {
+    const uint64_t slot = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (slot < n_slots) table[slot] = nm_seed_entry<BIG>(ix, slot, s);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, NM_WAVE);
+    return v;
+}
+
+// shared epilogue: ambiguous count, error report, optional tallies
+template <bool STATS>
+__device__ __forceinline__ void nm_epilogue(bool inb, bool amb0, bool err, uint64_t p, const nm_tally &t,
+                                            uint64_t *__restrict__ status) {
+    const uint64_t amb_mask = __ballot(inb && amb0);
+    const uint64_t err_mask = __ballot(inb && err);
+    const uint32_t lane = threadIdx.x & 63;
+    if (amb_mask && lane == 0) atomicAdd((unsigned long long *)&status[0], (unsigned long long)__popcll(amb_mask));
+    if (err_mask) {
+        if (inb && err) atomicMin((unsigned long long *)&status[2], (unsigned long long)p);
+        if (lane == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
+    }
+    if (STATS) {
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), c = wave_sum(t.seeds),
+                       d = wave_sum(t.strands);
+        const uint32_t e = (uint32_t)__popcll(__ballot(inb && !amb0));
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)d);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)e);
+        }
+    }
+}
+
+__device__ __forceinline__ void nm_store(void *out, int elem_bytes, uint64_t p, uint32_t v) {
+    if (elem_bytes == 1) ((uint8_t *)out)[p] = (uint8_t)v;
+    else if (elem_bytes == 2) ((uint16_t *)out)[p] = (uint16_t)v;
+    else ((uint32_t *)out)[p] = v;
+}
+
+template <bool BIG, bool RC, bool STATS>
+__global__ __launch_bounds__(NM_BLOCK) void k_min_unique(nm_view ix, const nm_enc_word *__restrict__ enc,
+                                                         uint64_t num_kmers, uint32_t kmin, uint32_t kmax,
+                                                         void *__restrict__ out, int elem_bytes,
+                                                         uint64_t *__restrict__ status) {
+    const uint64_t p = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    const bool inb = p < num_kmers;
+    bool amb0 = false, err = false;
+    nm_tally t = {0, 0, 0, 0};
+    uint32_t r = 0;
+    if (inb) {
+        r = nm_min_unique_one<BIG, RC>(ix, enc, p, kmin, kmax, amb0, err, t);
+        nm_store(out, elem_bytes, p, r);
+    }
+    nm_epilogue<STATS>(inb, amb0, err, p, t, status);
+}
+
+template <bool BIG, bool RC, bool STATS>
+__global__ __launch_bounds__(NM_BLOCK) void k_fixed_k(nm_view ix, const nm_enc_word *__restrict__ enc,
+                                                      uint64_t seq_len, uint64_t num_kmers,
+                                                      const uint32_t *__restrict__ ks, uint32_t nk,
+                                                      void *__restrict__ out, int elem_bytes,
+                                                      uint64_t *__restrict__ status) {
+    const uint64_t p = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    const bool inb = p < num_kmers;
+    bool amb0 = false, err = false;
+    nm_tally t = {0, 0, 0, 0};
+    if (inb) {
+        const uint32_t r = nm_fixed_k_one<BIG, RC>(ix, enc, p, seq_len, ks, nk, amb0, err, t);
+        nm_store(out, elem_bytes, p, r);
+    }
+    nm_epilogue<STATS>(inb, amb0, err, p, t, status);
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_count(nm_view ix, const uint8_t *__restrict__ seq,
+                                                    const uint64_t *__restrict__ starts,
+                                                    const uint64_t *__restrict__ lens, uint64_t n,
+                                                    uint32_t *__restrict__ out) {
+    const uint64_t q = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (q >= n) return;
+    nm_tally t = {0, 0, 0, 0};
+    out[q] = nm_count_fwd_one<BIG>(ix, seq + starts[q], lens[q], t);
+}
+
+__global__ __launch_bounds__(NM_BLOCK) void k_upper(const nm_enc_word *__restrict__ enc, uint64_t num_kmers,
+                                                    uint32_t kmax, uint32_t *__restrict__ out) {
+    const uint64_t p = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (p < num_kmers) out[p] = nm_upper_one(enc, p, kmax);
+}
+
+__global__ void k_reset_status(uint64_t *__restrict__ status) {
+    if (threadIdx.x < NM_STATUS_WORDS) status[threadIdx.x] = threadIdx.x == 2 ? ~0ULL : 0ULL;
+}
+
+// ------------------------------------------------------------------------------ host side ---
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            nm_set_error("HIP error %d (%s) at %s:%d: %s", (int)e__, hipGetErrorString(e__),  \
+                         __FILE__, __LINE__, #expr);                                          \
+            return NM_E_DEVICE;                                                               \
+        }                                                                                     \
+    } while (0)
+
+struct nm_buffer {
+    void *p = nullptr;
+    uint64_t bytes = 0;
+};
+
+struct nm_index {
+    int device = 0;
+    nm_file_header h;
+    nm_view view;
+    bool big = false;
+    void *d_rank = nullptr, *d_strand = nullptr, *d_sep = nullptr, *d_seed = nullptr, *d_super = nullptr;
+    uint64_t device_bytes = 0;
+    hipStream_t stream = nullptr;
+    // scratch owned by the handle (grown on demand)
+    nm_buffer enc, seq, out, status, ks, starts, lens;
+    bool count_steps = false;
+};
+
+static int nm_grow(nm_buffer &b, uint64_t bytes) {
+    if (bytes <= b.bytes && b.p) return NM_OK;
+    if (b.p) { HIP_TRY(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    uint64_t want = bytes + bytes / 8 + 4096;
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return NM_OK;
+}
+
+static inline unsigned nm_grid(uint64_t items) { return (unsigned)((items + NM_BLOCK - 1) / NM_BLOCK); }
+
+extern "C" int nm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int nm_build_seed(nm_index *ix, uint32_t s) {
+    ix->view.seed = nullptr;
+    ix->view.seed_len = 0;
+    if (s == 0 || ix->h.n < 2) return NM_OK;
+    const uint64_t n_slots = 1ULL << (2 * s);
+    HIP_TRY(hipMalloc(&ix->d_seed, n_slots * sizeof(uint64_t)));
+    ix->device_bytes += n_slots * sizeof(uint64_t);
+    const unsigned grid = nm_grid(n_slots);     // 4^16 / 256 = 16.7 M blocks max, within limits
+    if (ix->big) hipLaunchKernelGGL(k_seed<true>, dim3(grid), dim3(NM_BLOCK), 0, ix->stream, ix->view, (uint64_t *)ix->d_seed, n_slots, s);
+    else         hipLaunchKernelGGL(k_seed<false>, dim3(grid), dim3(NM_BLOCK), 0, ix->stream, ix->view, (uint64_t *)ix->d_seed, n_slots, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->view.seed = (const uint64_t *)ix->d_seed;
+    ix->view.seed_len = s;
+    return NM_OK;
+}
+
+extern "C" int nm_index_open(const char *index_path, int device, int seed_len_override, nm_index **out) {
+    if (!index_path || !out) { nm_set_error("null argument"); return NM_E_ARGUMENT; }
+    *out = nullptr;
+    if (device < 0) {
+        nm_set_error("device %d: this engine has no CPU path; a MI355X device index (>= 0) is required", device);
+        return NM_E_DEVICE;
+    }
+    FILE *fp = fopen(index_path, "rb");
+    if (!fp) { nm_set_error("Could not load reference index from file %s", index_path); return NM_E_FILE_OPEN; }
+    nm_file_header h;
+    if (fread(&h, sizeof h, 1, fp) != 1 || memcmp(h.magic, NM_MAGIC, 8) != 0 || h.version != NM_FORMAT_VERSION ||
+        h.header_bytes != sizeof h) {
+        fclose(fp);
+        nm_set_error("%s is not a newmap_amd index (format %u): rebuild it with `newmap index`", index_path, NM_FORMAT_VERSION);
+        return NM_E_FILE_FORMAT;
+    }
+    if (h.n_rank_blocks != h.n / 64 + 1 || h.n_strand_blocks != h.n / 64 + 1 || h.n_super != (h.n >> NM_SUPER_SHIFT) + 1 ||
+        h.n_super > NM_MAX_SUPER || h.off_rank != sizeof h) {
+        fclose(fp);
+        nm_set_error("%s: inconsistent index header", index_path);
+        return NM_E_FILE_FORMAT;
+    }
+    int ndev = nm_device_count();
+    if (device >= ndev) {
+        fclose(fp);
+        nm_set_error("device %d requested but %d HIP device(s) are visible", device, ndev);
+        return NM_E_DEVICE;
+    }
+    nm_index *ix = new (std::nothrow) nm_index();
+    if (!ix) { fclose(fp); nm_set_error("out of memory"); return NM_E_ALLOC; }
+    ix->device = device;
+    ix->h = h;
+    ix->big = h.n_super > 1;
+    int rc = NM_OK;
+    auto fail = [&](int code) { fclose(fp); nm_index_close(ix); return code; };
+    if (hipSetDevice(device) != hipSuccess) { nm_set_error("hipSetDevice(%d) failed", device); return fail(NM_E_DEVICE); }
+    if (hipStreamCreate(&ix->stream) != hipSuccess) { nm_set_error("hipStreamCreate failed"); return fail(NM_E_DEVICE); }
+
+    const uint64_t rank_bytes = h.n_rank_blocks * sizeof(nm_rank_block);
+    const uint64_t strand_bytes = h.n_strand_blocks * sizeof(nm_strand_block);
+    const uint64_t sep_bytes = (h.n_sep ? h.n_sep : 1) * sizeof(uint64_t);
+    std::vector<uint64_t> superC(h.n_super * 4);
+    uint64_t C[4];
+    C[0] = h.n_sep;
+    for (int c = 1; c < 4; c++) C[c] = C[c - 1] + h.base_count[c - 1];
+    for (uint64_t j = 0; j < h.n_super; j++)
+        for (int c = 0; c < 4; c++) superC[j * 4 + c] = C[c] + h.super_cnt[j][c];
+
+    // stage through a bounded host buffer: the file is read once, sequentially
+    auto upload = [&](void **dptr, uint64_t off, uint64_t bytes) -> int {
+        if (hipMalloc(dptr, bytes ? bytes : 8) != hipSuccess) { nm_set_error("hipMalloc of %llu bytes failed", (unsigned long long)bytes); return NM_E_ALLOC; }
+        ix->device_bytes += bytes;
+        if (fseeko(fp, (off_t)off, SEEK_SET) != 0) { nm_set_error("seek failed in %s", index_path); return NM_E_FILE_FORMAT; }
+        const uint64_t chunk = 64ULL << 20;
+        std::vector<uint8_t> buf((size_t)(bytes < chunk ? bytes : chunk));
+        for (uint64_t done = 0; done < bytes;) {
+            const uint64_t m = bytes - done < chunk ? bytes - done : chunk;
+            if (fread(buf.data(), 1, (size_t)m, fp) != m) { nm_set_error("%s is truncated", index_path); return NM_E_FILE_FORMAT; }
+            if (hipMemcpy((uint8_t *)*dptr + done, buf.data(), m, hipMemcpyHostToDevice) != hipSuccess) { nm_set_error("hipMemcpy to device failed"); return NM_E_DEVICE; }
+            done += m;
+        }
+        return NM_OK;
+    };
+    if ((rc = upload(&ix->d_rank, h.off_rank, rank_bytes)) != NM_OK) return fail(rc);
+    if ((rc = upload(&ix->d_strand, h.off_strand, strand_bytes)) != NM_OK) return fail(rc);
+    if ((rc = upload(&ix->d_sep, h.off_sep, h.n_sep * sizeof(uint64_t))) != NM_OK) return fail(rc);
+    (void)sep_bytes;
+    if (hipMalloc(&ix->d_super, superC.size() * sizeof(uint64_t)) != hipSuccess ||
+        hipMemcpy(ix->d_super, superC.data(), superC.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
+        nm_set_error("could not upload the superblock table");
+        return fail(NM_E_DEVICE);
+    }
+    fclose(fp);
+    fp = nullptr;
+
+    nm_view &v = ix->view;
+    v.rank = (const nm_rank_block *)ix->d_rank;
+    v.strand = (const nm_strand_block *)ix->d_strand;
+    v.sep = (const uint64_t *)ix->d_sep;
+    v.seed = nullptr;
+    v.superC = (const uint64_t *)ix->d_super;
+    v.n = h.n;
+    v.n_sep = h.n_sep;
+    for (int c = 0; c < 4; c++) v.C[c] = C[c];
+    v.seed_len = 0;
+    v.n_super = (uint32_t)h.n_super;
+
+    uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
+    if (s > 16) s = 16;
+    rc = nm_build_seed(ix, s);
+    if (rc != NM_OK) { nm_index_close(ix); return rc; }
+    rc = nm_grow(ix->status, NM_STATUS_WORDS * sizeof(uint64_t));
+    if (rc != NM_OK) { nm_index_close(ix); return rc; }
+    *out = ix;
+    return NM_OK;
+}
+
+extern "C" void nm_index_close(nm_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_super, ix->enc.p, ix->seq.p,
+                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
+    if (!ix) return 0;
+    switch (what) {
+        case 0: return ix->h.n;
+        case 1: return ix->h.n_fwd;
+        case 2: return ix->h.n_sep;
+        case 3: return ix->h.n_records;
+        case 4: return ix->h.raw_bases;
+        case 5: return ix->view.seed_len;
+        case 6: return ix->device_bytes;
+        case 7: return ix->h.sa_ratio;
+        default: return 0;
+    }
+}
+
+extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
+    if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
+    if (option == NM_OPT_COUNT_STEPS) { ix->count_steps = value != 0; return NM_OK; }
+    nm_set_error("unknown option %d", option);
+    return NM_E_ARGUMENT;
+}
+
+// -------------------------------------------------------------------------- launch helpers --
+
+static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStream_t st) {
+    const uint64_t n_words = seq_len / 64 + 3;
+    int rc = nm_grow(ix->enc, n_words * sizeof(nm_enc_word));
+    if (rc != NM_OK) return rc;
+    hipLaunchKernelGGL(k_encode, dim3(nm_grid(n_words * 64)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
+                       (nm_enc_word *)ix->enc.p, n_words);
+    HIP_TRY(hipGetLastError());
+    return NM_OK;
+}
+
+static int nm_reset_status(uint64_t *d_status, hipStream_t st) {
+    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(NM_WAVE), 0, st, d_status);
+    HIP_TRY(hipGetLastError());
+    return NM_OK;
+}
+
+static int nm_check_segment_args(const nm_index *ix, uint64_t seq_len, uint64_t num_kmers, int elem_bytes) {
+    if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
+    if (num_kmers > seq_len) { nm_set_error("num_kmers (%llu) exceeds the segment length (%llu)", (unsigned long long)num_kmers, (unsigned long long)seq_len); return NM_E_ARGUMENT; }
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4) { nm_set_error("elem_bytes must be 1, 2 or 4"); return NM_E_ARGUMENT; }
+    return NM_OK;
+}
+
+template <bool BIG, bool RC>
+static void launch_min_unique(nm_index *ix, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, void *d_out,
+                              int elem_bytes, uint64_t *d_status, hipStream_t st) {
+    const dim3 grid(nm_grid(num_kmers)), block(NM_BLOCK);
+    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    if (ix->count_steps) hipLaunchKernelGGL((k_min_unique<BIG, RC, true>), grid, block, 0, st, ix->view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
+    else                 hipLaunchKernelGGL((k_min_unique<BIG, RC, false>), grid, block, 0, st, ix->view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
+}
+
+extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
+                                         uint32_t kmin, uint32_t kmax, int use_revcomp, int elem_bytes,
+                                         void *d_out, uint64_t *d_status, void *stream) {
+    int rc = nm_check_segment_args(ix, seq_len, num_kmers, elem_bytes);
+    if (rc != NM_OK) return rc;
+    if (kmin < 1 || kmin > kmax) { nm_set_error("need 1 <= kmin <= kmax (got %u, %u)", kmin, kmax); return NM_E_ARGUMENT; }
+    if ((elem_bytes == 1 && kmax > 0xFF) || (elem_bytes == 2 && kmax > 0xFFFF)) { nm_set_error("kmax %u does not fit in %d-byte elements", kmax, elem_bytes); return NM_E_ARGUMENT; }
+    if (!d_status) { nm_set_error("d_status is required"); return NM_E_ARGUMENT; }
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    if ((rc = nm_reset_status(d_status, st)) != NM_OK) return rc;
+    if (num_kmers == 0) return NM_OK;
+    if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
+    if (ix->big) { if (use_revcomp) launch_min_unique<true, true>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); else launch_min_unique<true, false>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); }
+    else         { if (use_revcomp) launch_min_unique<false, true>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); else launch_min_unique<false, false>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); }
+    HIP_TRY(hipGetLastError());
+    return NM_OK;
+}
+
+template <bool BIG, bool RC>
+static void launch_fixed_k(nm_index *ix, uint64_t seq_len, uint64_t num_kmers, const uint32_t *d_ks, uint32_t nk,
+                           void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st) {
+    const dim3 grid(nm_grid(num_kmers)), block(NM_BLOCK);
+    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    if (ix->count_steps) hipLaunchKernelGGL((k_fixed_k<BIG, RC, true>), grid, block, 0, st, ix->view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
+    else                 hipLaunchKernelGGL((k_fixed_k<BIG, RC, false>), grid, block, 0, st, ix->view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
+}
+
+extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
+                                      const uint32_t *ks, uint32_t nk, int use_revcomp, int elem_bytes,
+                                      void *d_out, uint64_t *d_status, void *stream) {
+    int rc = nm_check_segment_args(ix, seq_len, num_kmers, elem_bytes);
+    if (rc != NM_OK) return rc;
+    if (!ks || nk == 0) { nm_set_error("empty k list"); return NM_E_ARGUMENT; }
+    uint32_t kmax = 0;
+    for (uint32_t i = 0; i < nk; i++) {
+        if (ks[i] < 1) { nm_set_error("k-mer lengths must be >= 1"); return NM_E_ARGUMENT; }
+        if (ks[i] > kmax) kmax = ks[i];
+    }
+    if ((elem_bytes == 1 && kmax > 0xFF) || (elem_bytes == 2 && kmax > 0xFFFF)) { nm_set_error("k %u does not fit in %d-byte elements", kmax, elem_bytes); return NM_E_ARGUMENT; }
+    if (!d_status) { nm_set_error("d_status is required"); return NM_E_ARGUMENT; }
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    if ((rc = nm_reset_status(d_status, st)) != NM_OK) return rc;
+    if (num_kmers == 0) return NM_OK;
+    if ((rc = nm_grow(ix->ks, (uint64_t)nk * sizeof(uint32_t))) != NM_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->ks.p, ks, (uint64_t)nk * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
+    const uint32_t *d_ks = (const uint32_t *)ix->ks.p;
+    if (ix->big) { if (use_revcomp) launch_fixed_k<true, true>(ix, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<true, false>(ix, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
+    else         { if (use_revcomp) launch_fixed_k<false, true>(ix, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<false, false>(ix, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
+    HIP_TRY(hipGetLastError());
+    return NM_OK;
+}
+
+// host-buffer wrappers ---------------------------------------------------------------------
+
+static int nm_finish_segment(nm_index *ix, void *out, uint64_t out_bytes, uint64_t *n_ambiguous, uint64_t *bad_pos) {
+    uint64_t status[NM_STATUS_WORDS];
+    HIP_TRY(hipMemcpyAsync(status, ix->status.p, sizeof status, hipMemcpyDeviceToHost, ix->stream));
+    if (out_bytes) HIP_TRY(hipMemcpyAsync(out, ix->out.p, out_bytes, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    if (n_ambiguous) *n_ambiguous = status[0];
+    if (bad_pos) *bad_pos = status[2];
+    if (status[1]) {
+        nm_set_error("a generated k-mer was not found in the index (first at segment position %llu); "
+                     "possibly a mismatch between the sequence and the index", (unsigned long long)status[2]);
+        return NM_E_KMER_NOT_FOUND;
+    }
+    return NM_OK;
+}
+
+static int nm_stage_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t out_bytes) {
+    int rc;
+    HIP_TRY(hipSetDevice(ix->device));
+    if ((rc = nm_grow(ix->seq, seq_len + 64)) != NM_OK) return rc;
+    if ((rc = nm_grow(ix->out, out_bytes + 64)) != NM_OK) return rc;
+    if (seq_len) HIP_TRY(hipMemcpyAsync(ix->seq.p, seq, seq_len, hipMemcpyHostToDevice, ix->stream));
+    return NM_OK;
+}
+
+extern "C" int nm_min_unique_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
+                                     uint32_t kmin, uint32_t kmax, uint32_t initial_len, int use_revcomp,
+                                     int elem_bytes, void *out, uint64_t *n_ambiguous, uint64_t *bad_pos) {
+    (void)initial_len;   // only shapes the reference's probe schedule (search.py:429-433), never the result
+    int rc = nm_check_segment_args(ix, seq_len, num_kmers, elem_bytes);
+    if (rc != NM_OK) return rc;
+    if ((!seq && seq_len) || (!out && num_kmers)) { nm_set_error("null buffer"); return NM_E_ARGUMENT; }
+    const uint64_t out_bytes = num_kmers * (uint64_t)elem_bytes;
+    if ((rc = nm_stage_segment(ix, seq, seq_len, out_bytes)) != NM_OK) return rc;
+    rc = nm_min_unique_segment_dev(ix, ix->seq.p, seq_len, num_kmers, kmin, kmax, use_revcomp, elem_bytes, ix->out.p,
+                                   (uint64_t *)ix->status.p, ix->stream);
+    if (rc != NM_OK) return rc;
+    return nm_finish_segment(ix, out, out_bytes, n_ambiguous, bad_pos);
+}
+
+extern "C" int nm_fixed_k_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
+                                  const uint32_t *ks, uint32_t nk, int use_revcomp, int elem_bytes, void *out,
+                                  uint64_t *n_ambiguous, uint64_t *bad_pos) {
+    int rc = nm_check_segment_args(ix, seq_len, num_kmers, elem_bytes);
+    if (rc != NM_OK) return rc;
+    if ((!seq && seq_len) || (!out && num_kmers)) { nm_set_error("null buffer"); return NM_E_ARGUMENT; }
+    const uint64_t out_bytes = num_kmers * (uint64_t)elem_bytes;
+    if ((rc = nm_stage_segment(ix, seq, seq_len, out_bytes)) != NM_OK) return rc;
+    rc = nm_fixed_k_segment_dev(ix, ix->seq.p, seq_len, num_kmers, ks, nk, use_revcomp, elem_bytes, ix->out.p,
+                                (uint64_t *)ix->status.p, ix->stream);
+    if (rc != NM_OK) return rc;
+    return nm_finish_segment(ix, out, out_bytes, n_ambiguous, bad_pos);
+}
+
+extern "C" int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
+                                      uint32_t kmax, uint32_t *out) {
+    int rc = nm_check_segment_args(ix, seq_len, num_kmers, 4);
+    if (rc != NM_OK) return rc;
+    if (seq_len - num_kmers >= kmax && kmax) {
+        // newmap/search.py:780-784 asserts the same
+        nm_set_error("Excess sequence buffer length is greater than the maximum search length");
+        return NM_E_ARGUMENT;
+    }
+    const uint64_t out_bytes = num_kmers * 4;
+    if ((rc = nm_stage_segment(ix, seq, seq_len, out_bytes)) != NM_OK) return rc;
+    if (num_kmers == 0) return NM_OK;
+    if ((rc = nm_encode(ix, ix->seq.p, seq_len, ix->stream)) != NM_OK) return rc;
+    hipLaunchKernelGGL(k_upper, dim3(nm_grid(num_kmers)), dim3(NM_BLOCK), 0, ix->stream, (const nm_enc_word *)ix->enc.p,
+                       num_kmers, kmax, (uint32_t *)ix->out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, ix->out.p, out_bytes, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return NM_OK;
+}
+
+extern "C" int nm_count_from_sequence(nm_index *ix, const uint8_t *seq, uint64_t seq_len, const uint64_t *starts,
+                                      const uint64_t *lens, uint64_t n, uint32_t *counts_out) {
+    if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
+    if (n == 0) return NM_OK;
+    if (!seq || !starts || !lens || !counts_out) { nm_set_error("null buffer"); return NM_E_ARGUMENT; }
+    for (uint64_t i = 0; i < n; i++) {
+        // src/newmap-count.c:184-190 (IndexError in the wrapper)
+        if (starts[i] > seq_len || lens[i] > seq_len - starts[i]) {
+            nm_set_error("The sum of the index and length of each k-mer must be less than or equal to the "
+                         "length of the input byte sequence (query %llu)", (unsigned long long)i);
+            return NM_E_ARGUMENT;
+        }
+    }
+    int rc;
+    HIP_TRY(hipSetDevice(ix->device));
+    if ((rc = nm_grow(ix->seq, seq_len + 64)) != NM_OK) return rc;
+    if ((rc = nm_grow(ix->starts, n * 8)) != NM_OK) return rc;
+    if ((rc = nm_grow(ix->lens, n * 8)) != NM_OK) return rc;
+    if ((rc = nm_grow(ix->out, n * 4)) != NM_OK) return rc;
+    hipStream_t st = ix->stream;
+    HIP_TRY(hipMemcpyAsync(ix->seq.p, seq, seq_len, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ix->starts.p, starts, n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ix->lens.p, lens, n * 8, hipMemcpyHostToDevice, st));
+    if (ix->big) hipLaunchKernelGGL(k_count<true>, dim3(nm_grid(n)), dim3(NM_BLOCK), 0, st, ix->view, (const uint8_t *)ix->seq.p, (const uint64_t *)ix->starts.p, (const uint64_t *)ix->lens.p, n, (uint32_t *)ix->out.p);
+    else         hipLaunchKernelGGL(k_count<false>, dim3(nm_grid(n)), dim3(NM_BLOCK), 0, st, ix->view, (const uint8_t *)ix->seq.p, (const uint64_t *)ix->starts.p, (const uint64_t *)ix->lens.p, n, (uint32_t *)ix->out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts_out, ix->out.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NM_OK;
+}
+
+extern "C" int nm_count_kmers(nm_index *ix, const uint8_t *kmers, const uint64_t *offsets, uint64_t n, uint32_t *counts_out) {
+    if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
+    if (n == 0) return NM_OK;
+    if (!kmers || !offsets || !counts_out) { nm_set_error("null buffer"); return NM_E_ARGUMENT; }
+    std::vector<uint64_t> starts(n), lens(n);
+    for (uint64_t i = 0; i < n; i++) {
+        if (offsets[i + 1] <= offsets[i]) {
+            // src/newmap-count.c:64-69
+            nm_set_error("All elements of the kmer list must have non-zero length");
+            return NM_E_ARGUMENT;
+        }
+        starts[i] = offsets[i] - offsets[0];
+        lens[i] = offsets[i + 1] - offsets[i];
+    }
+    return nm_count_from_sequence(ix, kmers + offsets[0], offsets[n] - offsets[0], starts.data(), lens.data(), n, counts_out);
+}
+
+// small device helpers ------------------------------------------------------------------------
+
+extern "C" int nm_dev_alloc(int device, uint64_t bytes, void **out) {
+    if (!out) { nm_set_error("null argument"); return NM_E_ARGUMENT; }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 8));
+    return NM_OK;
+}
+extern "C" int nm_dev_free(int device, void *p) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(p));
+    return NM_OK;
+}
+extern "C" int nm_dev_upload(int device, void *dst, const void *src, uint64_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return NM_OK;
+}
+extern "C" int nm_dev_download(int device, void *dst, const void *src, uint64_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return NM_OK;
+}
+extern "C" int nm_dev_sync(int device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return NM_OK;
+}

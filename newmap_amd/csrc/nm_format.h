@@ -1,0 +1,73 @@
+// nm_format.h -- on-disk / in-HBM layout of the both-strand FM-index (shared by the host
+// builder nm_build.cpp and the device engine nm_engine.hip).
+//
+// Text model (what the reference's index means; pinned by
+// reference tests/test_count_kmers.py:21-25): the FASTA is a set of records; a k-mer occurs only
+// inside one record, case-insensitively.  Every maximal ACGT run r_1..r_k of the records (record
+// boundaries and non-ACGT runs both end a run) goes into
+//
+//      T  =  r_1 $ r_2 $ ... r_k $   rc(r_k) $ ... rc(r_1) $   #
+//            \------ F, n_fwd -----/ \------- RC, n_fwd -------/
+//
+// so that ONE backward search of a pattern in T yields count_fwd(P) + count_fwd(revcomp(P)), the
+// total newmap/search.py:647-697 obtains with two library calls.  '$' and '#' never occur in a
+// pattern; they sort before A.
+//
+// Rank structure: the BWT of T, 64 positions per 32-byte block:
+//      u32 cnt[4]   occurrences of A,C,G,T in BWT[superblock start .. block start)
+//                   (bit 31 of cnt[0] = "this block holds a separator")
+//      u64 lo, hi   bit-planes of the 2-bit codes of the 64 positions (separator stored as A)
+// A superblock is 2^31 positions; absolute counts at superblock starts (plus C[]) live in a
+// tiny table.  Separator positions of the BWT are listed, sorted, in `sep`; blocks flagged above
+// correct rank(A) from that list.
+// Strand structure: 64 suffix-array positions per 16-byte block: u64 count of RC-half suffixes
+// before the block, u64 bits (1 = suffix starts in the RC half).  Used by forward-only counts
+// (count_kmers*, --norc).
+#ifndef NM_FORMAT_H
+#define NM_FORMAT_H
+
+#include <stdint.h>
+
+#define NM_MAGIC "NMAPGFX1"
+#define NM_FORMAT_VERSION 1u
+#define NM_SUPER_SHIFT 31
+#define NM_MAX_SUPER 16            /* up to 2^35 BWT positions */
+#define NM_SEP_FLAG 0x80000000u
+
+struct nm_rank_block {             /* 32 bytes, 64 BWT positions */
+    uint32_t cnt[4];
+    uint64_t lo, hi;
+};
+
+struct nm_strand_block {           /* 16 bytes, 64 suffix-array positions */
+    uint64_t before;
+    uint64_t bits;
+};
+
+struct nm_file_header {            /* 1024 bytes */
+    char     magic[8];
+    uint32_t version;
+    uint32_t header_bytes;
+    uint64_t n;                    /* BWT length = 2*n_fwd + 1 */
+    uint64_t n_fwd;                /* suffixes at text positions [n_fwd, 2*n_fwd) are RC-half */
+    uint64_t n_sep;                /* separators in T (including '#') */
+    uint64_t base_count[4];        /* A,C,G,T in T */
+    uint64_t n_rank_blocks;
+    uint64_t n_strand_blocks;
+    uint64_t n_records;            /* FASTA records with data */
+    uint64_t raw_bases;            /* sum of record lengths as in the FASTA */
+    uint64_t n_runs;               /* k */
+    uint64_t off_rank, off_strand, off_sep, file_bytes;
+    uint8_t  sa_ratio, seed_len, pad8[6];
+    uint64_t n_super;
+    uint64_t super_cnt[NM_MAX_SUPER][4];   /* A,C,G,T before each superblock */
+    uint8_t  reserved[1024 - 8 - 8 - 8 * 3 - 32 - 8 * 5 - 8 * 4 - 8 - 8 - NM_MAX_SUPER * 32];
+};
+
+#ifdef __cplusplus
+static_assert(sizeof(nm_rank_block) == 32, "rank block must be 32 bytes");
+static_assert(sizeof(nm_strand_block) == 16, "strand block must be 16 bytes");
+static_assert(sizeof(nm_file_header) == 1024, "header must be 1024 bytes");
+#endif
+
+#endif

@@ -1,0 +1,86 @@
+"""Test-only host simulation of newmap_amd/csrc/nm_core.h (see hostsim.cpp header)."""
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "_build" / "libhostsim.so"
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    src = _HERE / "hostsim.cpp"
+    core = _HERE.parent.parent / "newmap_amd" / "csrc" / "nm_core.h"
+    stale = (not _SO.exists() or _SO.stat().st_mtime < max(src.stat().st_mtime, core.stat().st_mtime))
+    if stale:
+        _SO.parent.mkdir(exist_ok=True)
+        subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", str(_SO), str(src)],
+                       check=True)
+    L = ctypes.CDLL(str(_SO))
+    vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    L.hs_open.restype = vp
+    L.hs_open.argtypes = [ctypes.c_char_p, i32, i32]
+    L.hs_close.argtypes = [vp]
+    L.hs_info.restype = u64
+    L.hs_info.argtypes = [vp, i32]
+    L.hs_min_unique.restype = i32
+    L.hs_min_unique.argtypes = [vp, vp, u64, u64, u32, u32, i32, i32, vp, vp]
+    L.hs_fixed_k.restype = i32
+    L.hs_fixed_k.argtypes = [vp, vp, u64, u64, vp, u32, i32, i32, vp, vp]
+    L.hs_count.argtypes = [vp, vp, vp, vp, u64, vp]
+    L.hs_upper.argtypes = [vp, u64, u64, u32, vp]
+    _lib = L
+    return L
+
+
+class HostSim:
+    def __init__(self, index_path, seed_len=-1, force_big=False):
+        self.L = lib()
+        self.h = self.L.hs_open(str(index_path).encode(), seed_len, int(force_big))
+        if not self.h:
+            raise OSError(f"hostsim could not read {index_path}")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.hs_close(self.h)
+            self.h = None
+
+    def info(self, what):
+        return int(self.L.hs_info(self.h, what))
+
+    def min_unique(self, seq: bytes, num_kmers, kmin, kmax, use_rc=True, dtype=np.uint8):
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        out = np.zeros(max(num_kmers, 1), dtype=dtype)
+        status = np.zeros(8, dtype=np.uint64)
+        rc = self.L.hs_min_unique(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, int(use_rc),
+                                  out.dtype.itemsize, out.ctypes.data, status.ctypes.data)
+        return out[:num_kmers], status, rc
+
+    def fixed_k(self, seq: bytes, num_kmers, ks, use_rc=True, dtype=np.uint8):
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        out = np.zeros(max(num_kmers, 1), dtype=dtype)
+        status = np.zeros(8, dtype=np.uint64)
+        k = np.asarray(ks, dtype=np.uint32)
+        rc = self.L.hs_fixed_k(self.h, buf.ctypes.data, buf.size, num_kmers, k.ctypes.data, k.size, int(use_rc),
+                               out.dtype.itemsize, out.ctypes.data, status.ctypes.data)
+        return out[:num_kmers], status, rc
+
+    def count(self, seq: bytes, starts, lens):
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        s = np.ascontiguousarray(starts, dtype=np.uint64)
+        l = np.ascontiguousarray(lens, dtype=np.uint64)
+        out = np.zeros(s.size, dtype=np.uint32)
+        self.L.hs_count(self.h, buf.ctypes.data, s.ctypes.data, l.ctypes.data, s.size, out.ctypes.data)
+        return out
+
+    @staticmethod
+    def upper(seq: bytes, num_kmers, kmax):
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        out = np.zeros(max(num_kmers, 1), dtype=np.uint32)
+        lib().hs_upper(buf.ctypes.data, buf.size, num_kmers, kmax, out.ctypes.data)
+        return out[:num_kmers]

@@ -1,0 +1,148 @@
+// tests/hostsim/hostsim.cpp -- TEST-ONLY host simulation of the device functions in
+// newmap_amd/csrc/nm_core.h.  It lets the CPU test-suite (no GPU in the build container) run the
+// exact per-position logic the HIP kernels run, on an index file written by the product's host
+// builder, and compare it with the oracle.  It is compiled by tests/hostsim/__init__.py into
+// tests/hostsim/_build/, is not part of the package `newmap_amd`, is never loaded by it, and is not
+// a fallback: the product has no CPU search path (nm_index_open refuses device < 0).
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#define NM_HD static inline
+#include "../../newmap_amd/csrc/nm_core.h"
+
+struct hs_index {
+    nm_file_header h;
+    std::vector<nm_rank_block> rank;
+    std::vector<nm_strand_block> strand;
+    std::vector<uint64_t> sep, seed, superC;
+    nm_view v;
+    bool big;
+};
+
+static void hs_encode(const uint8_t *seq, uint64_t seq_len, std::vector<nm_enc_word> &enc) {
+    const uint64_t n_words = seq_len / 64 + 3;
+    enc.assign(n_words, nm_enc_word{0, 0, 0, 0});
+    for (uint64_t pos = 0; pos < n_words * 64; pos++) {
+        uint32_t code = pos < seq_len ? nm_base_code(seq[pos]) : 4;
+        nm_enc_word &w = enc[pos >> 6];
+        const uint64_t bit = 1ULL << (pos & 63);
+        if (code > 3) w.amb |= bit;
+        else { if (code & 1) w.lo |= bit; if (code & 2) w.hi |= bit; }
+    }
+}
+
+extern "C" {
+
+hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return nullptr;
+    hs_index *ix = new hs_index();
+    bool ok = fread(&ix->h, sizeof ix->h, 1, fp) == 1 && memcmp(ix->h.magic, NM_MAGIC, 8) == 0;
+    if (ok) {
+        ix->rank.resize(ix->h.n_rank_blocks);
+        ix->strand.resize(ix->h.n_strand_blocks);
+        ix->sep.resize(ix->h.n_sep);
+        ok = fread(ix->rank.data(), sizeof(nm_rank_block), ix->rank.size(), fp) == ix->rank.size() &&
+             fread(ix->strand.data(), sizeof(nm_strand_block), ix->strand.size(), fp) == ix->strand.size() &&
+             fread(ix->sep.data(), 8, ix->sep.size(), fp) == ix->sep.size();
+    }
+    fclose(fp);
+    if (!ok) { delete ix; return nullptr; }
+    const nm_file_header &h = ix->h;
+    uint64_t C[4];
+    C[0] = h.n_sep;
+    for (int c = 1; c < 4; c++) C[c] = C[c - 1] + h.base_count[c - 1];
+    ix->superC.resize(h.n_super * 4);
+    for (uint64_t j = 0; j < h.n_super; j++)
+        for (int c = 0; c < 4; c++) ix->superC[j * 4 + c] = C[c] + h.super_cnt[j][c];
+    ix->big = force_big || h.n_super > 1;
+    nm_view &v = ix->v;
+    v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
+    v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
+    for (int c = 0; c < 4; c++) v.C[c] = C[c];
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super;
+    uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
+    if (s > 12) s = 12;                     // keep the simulated table small
+    if (s && h.n >= 2) {
+        ix->seed.resize(1ULL << (2 * s));
+        for (uint64_t slot = 0; slot < ix->seed.size(); slot++)
+            ix->seed[slot] = ix->big ? nm_seed_entry<true>(v, slot, s) : nm_seed_entry<false>(v, slot, s);
+        v.seed = ix->seed.data();
+        v.seed_len = s;
+    }
+    return ix;
+}
+
+void hs_close(hs_index *ix) { delete ix; }
+uint64_t hs_info(hs_index *ix, int what) {
+    switch (what) { case 0: return ix->h.n; case 1: return ix->h.n_fwd; case 2: return ix->h.n_sep;
+                    case 3: return ix->h.n_records; case 4: return ix->h.raw_bases; case 5: return ix->v.seed_len;
+                    default: return 0; }
+}
+
+// returns 0 ok, 8 k-mer not found (like NM_E_KMER_NOT_FOUND)
+int hs_min_unique(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin,
+                  uint32_t kmax, int use_rc, int elem_bytes, void *out, uint64_t *status) {
+    std::vector<nm_enc_word> enc;
+    hs_encode(seq, seq_len, enc);
+    for (int i = 0; i < 8; i++) status[i] = 0;
+    status[2] = ~0ULL;
+    for (uint64_t p = 0; p < num_kmers; p++) {
+        bool amb0 = false, err = false;
+        nm_tally t = {0, 0, 0, 0};
+        uint32_t r;
+        if (ix->big) r = use_rc ? nm_min_unique_one<true, true>(ix->v, enc.data(), p, kmin, kmax, amb0, err, t)
+                                : nm_min_unique_one<true, false>(ix->v, enc.data(), p, kmin, kmax, amb0, err, t);
+        else         r = use_rc ? nm_min_unique_one<false, true>(ix->v, enc.data(), p, kmin, kmax, amb0, err, t)
+                                : nm_min_unique_one<false, false>(ix->v, enc.data(), p, kmin, kmax, amb0, err, t);
+        if (elem_bytes == 1) ((uint8_t *)out)[p] = (uint8_t)r;
+        else if (elem_bytes == 2) ((uint16_t *)out)[p] = (uint16_t)r;
+        else ((uint32_t *)out)[p] = r;
+        status[0] += amb0;
+        if (err) { status[1] = 1; if (p < status[2]) status[2] = p; }
+        status[3] += t.steps; status[4] += t.blocks; status[5] += t.seeds; status[6] += t.strands;
+        status[7] += !amb0;
+    }
+    return status[1] ? 8 : 0;
+}
+
+int hs_fixed_k(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks,
+               uint32_t nk, int use_rc, int elem_bytes, void *out, uint64_t *status) {
+    std::vector<nm_enc_word> enc;
+    hs_encode(seq, seq_len, enc);
+    for (int i = 0; i < 8; i++) status[i] = 0;
+    status[2] = ~0ULL;
+    for (uint64_t p = 0; p < num_kmers; p++) {
+        bool amb0 = false, err = false;
+        nm_tally t = {0, 0, 0, 0};
+        uint32_t r;
+        if (ix->big) r = use_rc ? nm_fixed_k_one<true, true>(ix->v, enc.data(), p, seq_len, ks, nk, amb0, err, t)
+                                : nm_fixed_k_one<true, false>(ix->v, enc.data(), p, seq_len, ks, nk, amb0, err, t);
+        else         r = use_rc ? nm_fixed_k_one<false, true>(ix->v, enc.data(), p, seq_len, ks, nk, amb0, err, t)
+                                : nm_fixed_k_one<false, false>(ix->v, enc.data(), p, seq_len, ks, nk, amb0, err, t);
+        if (elem_bytes == 1) ((uint8_t *)out)[p] = (uint8_t)r;
+        else if (elem_bytes == 2) ((uint16_t *)out)[p] = (uint16_t)r;
+        else ((uint32_t *)out)[p] = r;
+        status[0] += amb0;
+        if (err) { status[1] = 1; if (p < status[2]) status[2] = p; }
+    }
+    return status[1] ? 8 : 0;
+}
+
+void hs_count(hs_index *ix, const uint8_t *seq, const uint64_t *starts, const uint64_t *lens, uint64_t n, uint32_t *out) {
+    for (uint64_t q = 0; q < n; q++) {
+        nm_tally t = {0, 0, 0, 0};
+        out[q] = ix->big ? nm_count_fwd_one<true>(ix->v, seq + starts[q], lens[q], t)
+                         : nm_count_fwd_one<false>(ix->v, seq + starts[q], lens[q], t);
+    }
+}
+
+void hs_upper(const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmax, uint32_t *out) {
+    std::vector<nm_enc_word> enc;
+    hs_encode(seq, seq_len, enc);
+    for (uint64_t p = 0; p < num_kmers; p++) out[p] = nm_upper_one(enc.data(), p, kmax);
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+"""CPU checks of the product's HOST side and of the device logic's source:
+  * nm_index_build (SA-IS, BWT, rank/strand blocks, file format) on the golden inputs,
+  * the per-position functions of newmap_amd/csrc/nm_core.h, run through the test-only host
+    simulator (tests/hostsim), against the reference-driver fixtures and the oracle.
+The HIP kernels themselves are tested in tests/test_gpu_parity.py (-m gpu)."""
+import io
+
+import numpy as np
+import pytest
+
+from newmap_amd._c_newmap_generate_index import generate_fm_index
+from oracle import ref_driver as rd
+from tests.hostsim import HostSim
+
+
+def _write(tmp_path, text: bytes, name="in.fa"):
+    p = tmp_path / name
+    p.write_bytes(text)
+    return p
+
+
+def _engine_unique(sim, text, lengths, is_binary, batch, use_rc):
+    """Drive the simulated engine exactly as newmap_amd.search drives the HIP engine."""
+    kmin, kmax = min(lengths), max(lengths)
+    dtype, _ = rd.output_dtype(kmax)
+    out = {}
+    lines = io.BytesIO(text).readlines()
+    for seg in rd.sequence_segments(lines, batch + kmax - 1, kmax - 1):
+        n = rd.num_kmers_of(seg, kmax)
+        if is_binary:
+            arr, status, rc = sim.min_unique(seg.data, n, kmin, kmax, use_rc, dtype)
+        else:
+            arr, status, rc = sim.fixed_k(seg.data, n, lengths, use_rc, dtype)
+        assert rc == 0
+        out.setdefault(seg.id, []).append(arr.copy())
+    return {k: np.concatenate(v) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("seed_len,force_big", [(0, False), (3, False), (6, True)])
+def test_core_reproduces_reference_fixtures(tmp_path, golden_search, seed_len, force_big):
+    for c in golden_search:
+        if "quirk" in c["name"]:
+            continue
+        text = c["fasta"].encode("latin-1")
+        fa = _write(tmp_path, text)
+        idx = tmp_path / "x.awfmi"
+        generate_fm_index(str(fa), str(idx), 8, 12)
+        sim = HostSim(idx, seed_len, force_big)
+        got = _engine_unique(sim, text, c["kmer_lengths"], c["is_binary"], c["batch"],
+                             c["use_reverse_complement"])
+        for rid, exp in c["expected"].items():
+            arr = got[rid.encode()]
+            assert arr.dtype == np.dtype(exp["dtype"])
+            assert arr.tolist() == exp["values"], (c["name"], rid, seed_len)
+
+
+def test_core_counts_match_reference_kat(tmp_path, golden_host):
+    from pathlib import Path
+    GOLDEN = Path(__file__).resolve().parent / "golden"
+    idx = tmp_path / "g.awfmi"
+    generate_fm_index(str(GOLDEN / "genome.fa"), str(idx), 8, 12)
+    sim = HostSim(idx, 0)
+    k = golden_host["kat"]["count_kmers"]
+    blob = b"".join(s.encode() for s in k["kmers"])
+    lens = [len(s) for s in k["kmers"]]
+    starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    assert sim.count(blob, starts, lens).tolist() == k["expected"]
+    k = golden_host["kat"]["count_from_sequence"]
+    assert sim.count(k["sequence"].encode(), k["starts"], k["lengths"]).tolist() == k["expected"]
+
+
+def test_core_upper_bound_cases(golden_host):
+    for c in golden_host["upper_bound"]:
+        mask = np.array(c["mask"], dtype=bool)
+        seq = bytes(np.where(mask, ord("N"), ord("A")).astype(np.uint8)) + b"C" * (c["buffer_len"] - mask.size)
+        got = HostSim.upper(seq, mask.size, c["kmax"])
+        assert got.tolist() == c["expected"], c
+
+
+def test_header_and_separators(tmp_path):
+    text = b">a\nACGTNNNNACGT\nNN\n>b\nTTTT\n>empty\n>c\nNNNN\n"
+    fa = _write(tmp_path, text)
+    idx = tmp_path / "h.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 4)
+    sim = HostSim(idx, 2)
+    # runs: ACGT, ACGT, TTTT -> F = 3*(4+1) = 15, n = 31, separators = 2*3+1
+    assert sim.info(0) == 31 and sim.info(1) == 15 and sim.info(2) == 7
+    assert sim.info(3) == 3 and sim.info(4) == 14 + 4 + 4
+    seq = b"ACGTNNNNACGTNN"
+    assert sim.count(seq, [0, 0, 8, 1], [4, 5, 4, 2]).tolist() == [2, 0, 2, 2]
+
+
+def test_overwrite_and_missing_fasta(tmp_path):
+    idx = tmp_path / "o.awfmi"
+    idx.write_bytes(b"junk")
+    fa = _write(tmp_path, b">x\nACGTACGTAA\n")
+    generate_fm_index(str(fa), str(idx), 8, 12)          # overwrites (tests/test_unique_counts.py:25-35)
+    assert idx.read_bytes()[:8] == b"NMAPGFX1"
+    with pytest.raises(FileNotFoundError):               # tests/test_index_generation.py:34-46
+        generate_fm_index(str(tmp_path / "genome_foo.fasta"), str(idx), 8, 12)
+
+
+def test_random_and_repetitive_against_oracle(tmp_path):
+    rng = np.random.default_rng(99)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    r1 = bytearray(bytes(alpha[rng.integers(0, 4, 30000)]))
+    unit = bytes(alpha[rng.integers(0, 4, 7)])
+    r1[5000:9000] = (unit * 600)[:4000]
+    r1[12000:12050] = b"N" * 50
+    r1[20000:20300] = bytes(r1[1000:1300]).lower()
+    r2 = bytes(alpha[rng.integers(0, 4, 12000)]) + bytes(r1[100:2100])
+    text = b">one\n" + bytes(r1) + b"\n>two\n" + r2 + b"\n"
+    fa = _write(tmp_path, text)
+    idx = tmp_path / "r.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    oracle = rd.OracleIndex([bytes(r1), r2])
+    for seed in (0, 5, 8):
+        sim = HostSim(idx, seed)
+        for rec in (bytes(r1), r2):
+            for kmin, kmax, rc in ((20, 200, True), (8, 40, True), (24, 150, False), (20, 300, True)):
+                dtype, _ = rd.output_dtype(kmax)
+                want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, rc)
+                got, status, code = sim.min_unique(rec, len(rec), kmin, kmax, rc, dtype)
+                assert code == 0
+                assert np.array_equal(got, want), (seed, kmin, kmax, rc)
+                assert int(status[0]) == sum(ch not in b"ACGTacgt" for ch in rec)
+    # forward-only counts of arbitrary substrings
+    sim = HostSim(idx, 0)
+    starts = rng.integers(0, len(r2) - 64, 2000)
+    lens = rng.integers(1, 64, 2000)
+    assert np.array_equal(sim.count(r2, starts, lens), oracle.count_from_sequence(r2, starts, lens))
+
+
+def test_kmer_not_found_is_reported(tmp_path):
+    fa = _write(tmp_path, b">x\nACGTACGTTTGACCAGGATTACA\n")
+    idx = tmp_path / "m.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 0)
+    sim = HostSim(idx, 0)
+    got, status, code = sim.min_unique(b"GGGGGGGGGGGGGGGGGGGG", 20, 4, 8)
+    assert code == 8 and int(status[1]) == 1 and int(status[2]) == 0

@@ -8,7 +8,9 @@ import pytest
 
 from oracle import ref_driver as rd
 
-from conftest import GOLDEN
+from pathlib import Path
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
 
 
 @pytest.fixture(scope="module")

@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- genome positions/sec of the min-unique-k search (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (N = 1): BASELINE.json configs[1] -- synthetic 100 Mbp single-record FASTA, uniform ACGT
+(numpy default_rng(20260515)), search range 20:200, reference batch geometry (10 M positions per
+segment + 199 bytes of lookahead, newmap/search.py:229-235).  One STEP = one pass of the hot path
+over every position of the genome.  The index is built once on the host, uploaded once; the
+sequence bytes are resident in HBM before the timed region starts.
+
+N > 1: the genome and the index stay the same; every rank holds a replica of the index in its own
+HBM and searches a contiguous 1/N slice of the positions (independent units, no data-path
+collective), then the per-rank uint8 slices are gathered on rank 0 with one RCCL collective
+(part of the timed step).  Total work is fixed -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+KMIN, KMAX = 20, 200
+BATCH = 10_000_000
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mbp", type=float, default=100.0, help="genome size (default: configs[1], 100 Mbp)")
+    ap.add_argument("--seed-length", type=int, default=12, help="device seed table length (reference default 12)")
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--workdir", default=os.environ.get("NEWMAP_AMD_BENCH_DIR", "/tmp/newmap_amd_bench"))
+    return ap.parse_args()
+
+
+def prepare_workload(args, rank, world, barrier):
+    """rank 0 generates the FASTA and builds the index; everybody then opens the same file"""
+    from newmap_amd import synth
+    from newmap_amd._c_newmap_generate_index import generate_fm_index
+    wd = Path(args.workdir) / f"c2_{args.mbp:g}mbp"
+    fa, idx = wd / "genome.fa", wd / "genome.awfmi"
+    t_gen = t_build = 0.0
+    recs = synth.config_genome("c2", args.mbp)
+    if rank == 0:
+        wd.mkdir(parents=True, exist_ok=True)
+        if not (fa.exists() and idx.exists() and (wd / "ok").exists()):
+            t0 = time.time()
+            synth.write_fasta(fa, recs)
+            t_gen = time.time() - t0
+            t0 = time.time()
+            generate_fm_index(str(fa), str(idx), 8, 12)
+            t_build = time.time() - t0
+            (wd / "ok").write_text("ok")
+            log(f"[bench] wrote {fa} ({t_gen:.1f}s), built index ({t_build:.1f}s, {idx.stat().st_size / 1e6:.0f} MB)")
+    barrier()
+    return recs[0][1], fa, idx, t_build
+
+
+def position_slices(n_positions, world, batch, kmax, seq_len):
+    """contiguous slice per rank, cut into reference-shaped segments (batch positions + kmax-1
+    lookahead; the last segment of the record runs to its end = epilogue)"""
+    per = -(-n_positions // world)
+    out = []
+    for r in range(world):
+        lo, hi = min(r * per, n_positions), min((r + 1) * per, n_positions)
+        segs = []
+        p = lo
+        while p < hi:
+            nk = min(batch, hi - p)
+            end = min(p + nk + kmax - 1, seq_len)
+            segs.append((p, end - p, nk))
+            p += nk
+        out.append((lo, hi, segs))
+    return out
+
+
+def cpu_baseline(args, genome: np.ndarray, gpu_out: np.ndarray):
+    """The oracle's C/OpenMP port of the reference algorithm (forward-strand FM-index, restart per
+    probe, forward + reverse-complement queries, 4^12 seed table) on a bounded sample."""
+    from oracle import ref_driver as rd
+    threads = rd.lib().or_num_threads()
+    t0 = time.time()
+    oracle = rd.OracleIndex([genome.tobytes()])
+    oracle.enable_fm(12)
+    t_index = time.time() - t0
+    rec = genome
+    calib = 20_000
+    t0 = time.time()
+    rd.ref_binary_search_segment_c(oracle, rec[:calib + KMAX - 1].tobytes(), calib, KMIN, KMAX, fm=True)
+    rate = calib / max(time.time() - t0, 1e-6)
+    sample = int(min(max(rate * args.cpu_seconds, calib), len(rec) - KMAX, 10_000_000))
+    t0 = time.time()
+    got, _, stats = rd.ref_binary_search_segment_c(oracle, rec[:sample + KMAX - 1].tobytes(), sample, KMIN, KMAX, fm=True)
+    dt = time.time() - t0
+    same = bool(np.array_equal(got.astype(np.uint8), gpu_out[:sample]))
+    log(f"[bench] cpu baseline: {sample} positions in {dt:.1f}s on {threads} threads "
+        f"(oracle index {t_index:.1f}s); bit-exact vs GPU: {same}")
+    if not same:
+        raise SystemExit("GPU output differs from the CPU oracle on the baseline sample")
+    return {"value": sample / dt, "unit": "positions/s", "cores": threads, "kind": "port",
+            "sample": f"first {sample} positions of the same 100 Mbp workload, 20:200, "
+                      f"{stats['probes'] / sample:.1f} probes and {2 * stats['probe_len'] / sample:.0f} LF steps "
+                      "per position (reference schedule), index build excluded"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch                                   # first: libnewmap_amd.so binds to torch's HIP runtime
+    import torch.distributed as dist
+    from newmap_amd.engine import Index
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    genome, fa, idx_path, t_build = prepare_workload(args, rank, world, barrier)
+    n = int(genome.size)
+    t0 = time.time()
+    ix = Index(idx_path, local_rank, args.seed_length)
+    t_open = time.time() - t0
+    info = ix.info()
+
+    d_seq = torch.from_numpy(genome).to(dev)       # sequence resident in HBM before timing
+    d_out = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_status = torch.zeros(8, dtype=torch.int64, device=dev)
+    slices = position_slices(n, world, args.batch, KMAX, n)
+    lo, hi, segs = slices[rank]
+    per = -(-n // world)
+    gather_buf = torch.empty(per * world, dtype=torch.uint8, device=dev) if world > 1 and rank == 0 else None
+    pad_out = torch.zeros(per, dtype=torch.uint8, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+    seq_ptr, out_ptr, st_ptr = d_seq.data_ptr(), d_out.data_ptr(), d_status.data_ptr()
+
+    def step():
+        for (p, seg_len, nk) in segs:
+            ix.min_unique_segment_dev(seq_ptr + p, seg_len, nk, KMIN, KMAX, True, 1, out_ptr + p, st_ptr, stream)
+        if world > 1:
+            pad_out[:hi - lo].copy_(d_out[lo:hi])
+            dist.gather(pad_out, list(gather_buf.split(per)) if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    ix.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_launch, kern_ms, kern_max = ix.read_timing()
+    ix.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    status = d_status.cpu().numpy()
+    if int(status[1]):
+        raise SystemExit(f"k-mer not found in the index at position {int(status[2])}")
+
+    # counter build of the kernel: LF steps / rank blocks / seed lookups per launch (untimed)
+    ix.set_count_steps(True)
+    tallies = np.zeros(8, dtype=np.int64)
+    for (p, seg_len, nk) in segs:
+        ix.min_unique_segment_dev(seq_ptr + p, seg_len, nk, KMIN, KMAX, True, 1, out_ptr + p, st_ptr, stream)
+        torch.cuda.synchronize()
+        tallies += d_status.cpu().numpy()
+    ix.set_count_steps(False)
+
+    if rank == 0:
+        my_pos = hi - lo
+        steps_pp = tallies[3] / max(tallies[7], 1)
+        # algorithmic bytes (DESIGN.md "Measurement"): 32 B per distinct rank block an LF step reads
+        # (lo and hi in one block count once), 8 B per seed-table entry, 1 sequence byte and one
+        # output element per position
+        alg_bytes = tallies[4] * 32 + tallies[5] * 8 + my_pos * (1 + 1)
+        per_launch_bytes = alg_bytes / max(len(segs), 1)
+        avg_launch_ms = kern_ms / max(n_launch, 1)
+        achieved = per_launch_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        result = {
+            "metric": "genome positions/sec (min-unique-k search, 20:200)",
+            "value": n * args.steps / elapsed,
+            "unit": "positions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"configs[1]: synthetic {args.mbp:g} Mbp single-record FASTA (uniform ACGT, seed 20260515), "
+                                   f"search-range {KMIN}:{KMAX}, both strands",
+                       "positions": n, "batch": args.batch, "segments_per_rank": len(segs),
+                       "seed_length": info["seed_length"], "index_bytes_hbm": info["device_bytes"],
+                       "parallelism": f"positions sharded over {world} GPU(s), index replicated"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_min_unique", "avg_launch_ms": avg_launch_ms, "launches": n_launch,
+                         "algorithmic_bytes_per_launch": per_launch_bytes,
+                         "lf_steps_per_position": float(steps_pp),
+                         "rank_blocks_per_position": float(tallies[4] / max(tallies[7], 1)),
+                         "seed_lookups_per_position": float(tallies[5] / max(tallies[7], 1))},
+            "host": {"index_build_s": t_build, "index_open_s": t_open},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            gpu_out = d_out.cpu().numpy()
+            result["cpu_baseline"] = cpu_baseline(args, genome, gpu_out)
+        print(json.dumps(result), flush=True)
+    barrier()
+    ix.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

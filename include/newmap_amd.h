@@ -110,8 +110,13 @@ int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, ui
                            const uint32_t *ks, uint32_t nk, int use_revcomp, int elem_bytes,
                            void *d_out, uint64_t *d_status, void *stream);
 
-enum { NM_OPT_COUNT_STEPS = 1, NM_OPT_BLOCK_THREADS = 2 };
+enum { NM_OPT_COUNT_STEPS = 1, NM_OPT_TIMING = 3 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
+
+/* NM_OPT_TIMING = 1 brackets every search-kernel launch (k_min_unique / k_fixed_k, not the
+ * encode pass) with HIP events recorded on the launch stream.  nm_timing_read waits for them,
+ * returns their number, summed and longest duration in ms, and resets the record. */
+int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_ms, double *max_ms);
 
 /* small device-memory helpers so a host program needs no other HIP binding */
 int nm_dev_alloc(int device, uint64_t bytes, void **out);

@@ -15,13 +15,14 @@ NM_E_FILE_OPEN, NM_E_ALLOC, NM_E_FILE_EXISTS, NM_E_FILE_WRITE, NM_E_FILE_FORMAT 
 NM_E_ARGUMENT, NM_E_DEVICE, NM_E_KMER_NOT_FOUND, NM_E_TOO_LARGE = 6, 7, 8, 9
 NM_STATUS_WORDS = 8
 NM_OPT_COUNT_STEPS = 1
+NM_OPT_TIMING = 3
 
 EXPORTS = [
     "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_close",
     "nm_index_info", "nm_count_kmers", "nm_count_from_sequence", "nm_min_unique_segment",
     "nm_fixed_k_segment", "nm_upper_bound_segment", "nm_min_unique_segment_dev",
     "nm_fixed_k_segment_dev", "nm_set_option", "nm_dev_alloc", "nm_dev_free", "nm_dev_upload",
-    "nm_dev_download", "nm_dev_sync", "nm_device_count",
+    "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read",
 ]
 
 _lib = None
@@ -92,6 +93,8 @@ def lib():
     L.nm_dev_sync.restype = i32
     L.nm_dev_sync.argtypes = [i32]
     L.nm_device_count.restype = i32
+    L.nm_timing_read.restype = i32
+    L.nm_timing_read.argtypes = [vp, c.POINTER(u64), c.POINTER(c.c_double), c.POINTER(c.c_double)]
     _lib = L
     return L
 

@@ -174,6 +174,26 @@ struct nm_index {
     // scratch owned by the handle (grown on demand)
     nm_buffer enc, seq, out, status, ks, starts, lens;
     bool count_steps = false;
+    // NM_OPT_TIMING: HIP events around every search-kernel launch, on the launch stream
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;      // start/stop pairs, reused
+    size_t ev_used = 0;                   // events consumed since the last read
+};
+
+struct nm_timed {                         // records start on construction, stop on destruction
+    nm_index *ix; hipStream_t st; hipEvent_t stop = nullptr;
+    nm_timed(nm_index *ix_, hipStream_t st_) : ix(ix_), st(st_) {
+        if (!ix->timing) return;
+        if (ix->ev_used + 2 > ix->ev_pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            ix->ev_pool.push_back(a); ix->ev_pool.push_back(b);
+        }
+        (void)hipEventRecord(ix->ev_pool[ix->ev_used], st);
+        stop = ix->ev_pool[ix->ev_used + 1];
+        ix->ev_used += 2;
+    }
+    ~nm_timed() { if (stop) (void)hipEventRecord(stop, st); }
 };
 
 static int nm_grow(nm_buffer &b, uint64_t bytes) {
@@ -315,6 +335,7 @@ extern "C" void nm_index_close(nm_index *ix) {
                     ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -337,8 +358,27 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
 extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
     if (option == NM_OPT_COUNT_STEPS) { ix->count_steps = value != 0; return NM_OK; }
+    if (option == NM_OPT_TIMING) { ix->timing = value != 0; ix->ev_used = 0; return NM_OK; }
     nm_set_error("unknown option %d", option);
     return NM_E_ARGUMENT;
+}
+
+extern "C" int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_ms, double *max_ms) {
+    if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
+    HIP_TRY(hipSetDevice(ix->device));
+    double total = 0.0, mx = 0.0;
+    for (size_t i = 0; i + 1 < ix->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(ix->ev_pool[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ix->ev_pool[i], ix->ev_pool[i + 1]));
+        total += ms;
+        if (ms > mx) mx = ms;
+    }
+    if (n_launches) *n_launches = ix->ev_used / 2;
+    if (total_ms) *total_ms = total;
+    if (max_ms) *max_ms = mx;
+    ix->ev_used = 0;
+    return NM_OK;
 }
 
 // -------------------------------------------------------------------------- launch helpers --
@@ -371,6 +411,7 @@ static void launch_min_unique(nm_index *ix, uint64_t num_kmers, uint32_t kmin, u
                               int elem_bytes, uint64_t *d_status, hipStream_t st) {
     const dim3 grid(nm_grid(num_kmers)), block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    nm_timed timed(ix, st);
     if (ix->count_steps) hipLaunchKernelGGL((k_min_unique<BIG, RC, true>), grid, block, 0, st, ix->view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
     else                 hipLaunchKernelGGL((k_min_unique<BIG, RC, false>), grid, block, 0, st, ix->view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
 }
@@ -399,6 +440,7 @@ static void launch_fixed_k(nm_index *ix, uint64_t seq_len, uint64_t num_kmers, c
                            void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st) {
     const dim3 grid(nm_grid(num_kmers)), block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    nm_timed timed(ix, st);
     if (ix->count_steps) hipLaunchKernelGGL((k_fixed_k<BIG, RC, true>), grid, block, 0, st, ix->view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
     else                 hipLaunchKernelGGL((k_fixed_k<BIG, RC, false>), grid, block, 0, st, ix->view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
 }

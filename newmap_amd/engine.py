@@ -1,0 +1,219 @@
+"""Python handle over the C-ABI (include/newmap_amd.h): one `Index` = one FM-index resident in
+the HBM of one MI355X.  Plumbing only -- every count and every search runs in the HIP kernels
+of csrc/nm_engine.hip."""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from pathlib import Path
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+
+_DTYPES = {1: np.uint8, 2: np.uint16, 4: np.uint32}
+
+
+def default_device() -> int:
+    """LOCAL_RANK when launched by torch.distributed.run, else NEWMAP_AMD_DEVICE, else 0."""
+    for var in ("NEWMAP_AMD_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v not in (None, ""):
+            return int(v)
+    return 0
+
+
+def device_count() -> int:
+    return int(_lib.lib().nm_device_count())
+
+
+def _as_u8(buf) -> np.ndarray:
+    if isinstance(buf, np.ndarray):
+        a = buf if buf.dtype == np.uint8 else buf.view(np.uint8)
+        return np.ascontiguousarray(a)
+    return np.frombuffer(memoryview(buf), dtype=np.uint8)
+
+
+class Index:
+    """Device-resident index.  Replaces the per-call load of src/newmap-count.c:9-17,135-136."""
+
+    def __init__(self, index_path, device: int | None = None, seed_length: int | None = None):
+        self._L = _lib.lib()
+        self.path = Path(index_path)
+        self.device = default_device() if device is None else int(device)
+        h = ctypes.c_void_p()
+        rc = self._L.nm_index_open(os.fsencode(self.path), self.device,
+                                   -1 if seed_length is None else int(seed_length), ctypes.byref(h))
+        _lib.raise_for(rc)
+        self._h = h
+        self._lock = threading.Lock()
+
+    # lifetime -----------------------------------------------------------------------------
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.nm_index_close(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise ValueError("index is closed")
+        return self._h
+
+    def info(self) -> dict:
+        names = ["bwt_length", "forward_text_length", "separators", "records", "raw_bases",
+                 "seed_length", "device_bytes", "sa_ratio"]
+        return {n: int(self._L.nm_index_info(self.handle, i)) for i, n in enumerate(names)}
+
+    def set_count_steps(self, on: bool):
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_COUNT_STEPS, int(bool(on))))
+
+    def set_timing(self, on: bool):
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_TIMING, int(bool(on))))
+
+    def read_timing(self):
+        """(launches, total ms, longest ms) of the search kernels since the last read."""
+        n, tot, mx = ctypes.c_uint64(0), ctypes.c_double(0), ctypes.c_double(0)
+        _lib.raise_for(self._L.nm_timing_read(self.handle, ctypes.byref(n), ctypes.byref(tot), ctypes.byref(mx)))
+        return int(n.value), float(tot.value), float(mx.value)
+
+    # compat seam --------------------------------------------------------------------------
+    def count_kmers(self, kmers: Sequence[bytes]) -> np.ndarray:
+        n = len(kmers)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            np.cumsum([len(k) for k in kmers], out=offs[1:])
+        blob = _as_u8(b"".join(kmers)) if n else np.zeros(1, np.uint8)
+        out = np.zeros(n, dtype=np.uint32)
+        with self._lock:
+            rc = self._L.nm_count_kmers(self.handle, blob.ctypes.data, offs.ctypes.data, n, out.ctypes.data)
+        _lib.raise_for(rc)
+        return out
+
+    def count_from_sequence(self, seq, starts, lens) -> np.ndarray:
+        s = np.ascontiguousarray(starts, dtype=np.uint64)
+        l = np.ascontiguousarray(lens, dtype=np.uint64)
+        if s.shape != l.shape:
+            raise ValueError("Both lists of indices and lengths must be the same length")
+        buf = _as_u8(seq)
+        out = np.zeros(s.size, dtype=np.uint32)
+        with self._lock:
+            rc = self._L.nm_count_from_sequence(self.handle, buf.ctypes.data, buf.size, s.ctypes.data,
+                                                l.ctypes.data, s.size, out.ctypes.data)
+        if rc == _lib.NM_E_ARGUMENT:
+            raise IndexError(_lib.last_error())          # src/newmap-count.c:184-190
+        _lib.raise_for(rc)
+        return out
+
+    # fused hot path -----------------------------------------------------------------------
+    def _not_found(self, seq: np.ndarray, bad_pos: int, length: int) -> str:
+        kmer = bytes(seq[bad_pos:bad_pos + length]).decode("utf-8", "replace")
+        return ("The following generated k-mer was not found in the index:\n"
+                f"{kmer}\nPossibly a mismatch between the sequence and the index.")   # search.py:719-722
+
+    def min_unique_segment(self, seq, num_kmers: int, kmin: int, kmax: int, use_revcomp: bool = True,
+                           dtype=None, initial_search_length: int = 0):
+        """newmap/search.py:383-548 for one segment -> (unique_lengths, n_ambiguous)."""
+        if dtype is None:
+            dtype = np.uint8 if kmax <= 255 else (np.uint16 if kmax <= 65535 else np.uint32)
+        dtype = np.dtype(dtype)
+        buf = _as_u8(seq)
+        out = np.zeros(max(int(num_kmers), 1), dtype=dtype)
+        amb, bad = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        with self._lock:
+            rc = self._L.nm_min_unique_segment(self.handle, buf.ctypes.data, buf.size, int(num_kmers), int(kmin),
+                                               int(kmax), int(initial_search_length), int(bool(use_revcomp)),
+                                               dtype.itemsize, out.ctypes.data, ctypes.byref(amb),
+                                               ctypes.byref(bad))
+        _lib.raise_for(rc, self._not_found(buf, int(bad.value), kmin) if rc == _lib.NM_E_KMER_NOT_FOUND else None)
+        return out[:num_kmers], int(amb.value)
+
+    def fixed_k_segment(self, seq, num_kmers: int, kmer_lengths: Sequence[int], use_revcomp: bool = True,
+                        dtype=None):
+        """newmap/search.py:551-644 for one segment -> (unique_lengths, n_ambiguous)."""
+        ks = np.ascontiguousarray(kmer_lengths, dtype=np.uint32)
+        kmax = int(ks.max())
+        if dtype is None:
+            dtype = np.uint8 if kmax <= 255 else (np.uint16 if kmax <= 65535 else np.uint32)
+        dtype = np.dtype(dtype)
+        buf = _as_u8(seq)
+        out = np.zeros(max(int(num_kmers), 1), dtype=dtype)
+        amb, bad = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        with self._lock:
+            rc = self._L.nm_fixed_k_segment(self.handle, buf.ctypes.data, buf.size, int(num_kmers),
+                                            ks.ctypes.data, ks.size, int(bool(use_revcomp)), dtype.itemsize,
+                                            out.ctypes.data, ctypes.byref(amb), ctypes.byref(bad))
+        _lib.raise_for(rc, self._not_found(buf, int(bad.value), int(ks[0])) if rc == _lib.NM_E_KMER_NOT_FOUND else None)
+        return out[:num_kmers], int(amb.value)
+
+    def upper_bound_segment(self, seq, num_kmers: int, kmax: int) -> np.ndarray:
+        """newmap/search.py:744-766 + :769-882 on the device."""
+        buf = _as_u8(seq)
+        out = np.zeros(max(int(num_kmers), 1), dtype=np.uint32)
+        with self._lock:
+            rc = self._L.nm_upper_bound_segment(self.handle, buf.ctypes.data, buf.size, int(num_kmers), int(kmax),
+                                                out.ctypes.data)
+        if rc == _lib.NM_E_ARGUMENT:
+            raise AssertionError(_lib.last_error())      # search.py:780-784
+        _lib.raise_for(rc)
+        return out[:num_kmers]
+
+    # device-resident variants (bench, multi-GPU driver) ---------------------------------------
+    def min_unique_segment_dev(self, d_seq: int, seq_len: int, num_kmers: int, kmin: int, kmax: int,
+                               use_revcomp: bool, elem_bytes: int, d_out: int, d_status: int, stream: int = 0):
+        rc = self._L.nm_min_unique_segment_dev(self.handle, d_seq, seq_len, num_kmers, kmin, kmax,
+                                               int(bool(use_revcomp)), elem_bytes, d_out, d_status, stream or None)
+        _lib.raise_for(rc)
+
+    def fixed_k_segment_dev(self, d_seq: int, seq_len: int, num_kmers: int, kmer_lengths, use_revcomp: bool,
+                            elem_bytes: int, d_out: int, d_status: int, stream: int = 0):
+        ks = np.ascontiguousarray(kmer_lengths, dtype=np.uint32)
+        rc = self._L.nm_fixed_k_segment_dev(self.handle, d_seq, seq_len, num_kmers, ks.ctypes.data, ks.size,
+                                            int(bool(use_revcomp)), elem_bytes, d_out, d_status, stream or None)
+        _lib.raise_for(rc)
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's FFI is stateless by path (index loaded and freed inside every call).  Keep the
+# same call shape but hold the uploaded index across calls.
+_cache: dict[tuple, Index] = {}
+_cache_lock = threading.Lock()
+
+
+def cached_index(index_path, device: int | None = None) -> Index:
+    p = Path(index_path)
+    try:
+        st = p.stat()
+    except OSError:
+        raise OSError(f"Could not load reference index from file {index_path}") from None   # newmap-count.c:13-16
+    dev = default_device() if device is None else device
+    key = (str(p.resolve()), st.st_mtime_ns, st.st_size, dev)
+    with _cache_lock:
+        ix = _cache.get(key)
+        if ix is None or not ix._h:
+            for k in [k for k in _cache if k[0] == key[0] and k[3] == dev]:
+                _cache.pop(k).close()
+            ix = Index(p, dev)
+            _cache[key] = ix
+        return ix
+
+
+def close_all():
+    with _cache_lock:
+        for ix in _cache.values():
+            ix.close()
+        _cache.clear()

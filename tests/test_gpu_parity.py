@@ -1,0 +1,312 @@
+"""Parity of the HIP engine with the oracle and with the reference's fixtures, through the C-ABI.
+Needs a real MI355X:  python -m pytest tests -m gpu"""
+import ctypes
+import io
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_driver as rd  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from newmap_amd import engine
+    if engine.device_count() < 1:
+        pytest.fail("no HIP device visible: the engine has no CPU fallback")
+    return engine
+
+
+def _build_index(tmp_path, text: bytes, name="x", seed=12):
+    from newmap_amd._c_newmap_generate_index import generate_fm_index
+    fa = tmp_path / f"{name}.fa"
+    fa.write_bytes(text)
+    idx = tmp_path / f"{name}.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, seed)
+    return fa, idx
+
+
+def _random_dna(rng, n):
+    return bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)])
+
+
+# ------------------------------------------------------------------ reference fixtures, end to end
+def test_write_unique_counts_reproduces_reference_fixtures(tmp_path, golden_search, eng):
+    from newmap_amd.search import SearchConfig, write_unique_counts
+    for i, c in enumerate(golden_search):
+        if "quirk" in c["name"]:
+            continue
+        d = tmp_path / f"case{i}"
+        d.mkdir()
+        fa, idx = _build_index(d, c["fasta"].encode("latin-1"))
+        out = d / "out"
+        out.mkdir()
+        write_unique_counts(SearchConfig(
+            fasta_filepaths=[fa], fmindex_filepaths=[idx], kmer_lengths=c["kmer_lengths"],
+            is_binary_search=c["is_binary"], kmer_batch_size=c["batch"], output_directory=out,
+            use_reverse_complement=c["use_reverse_complement"],
+            initial_search_length=c["initial_search_length"]))
+        files = sorted(p.name for p in out.iterdir())
+        assert files == sorted(f"{rid}.unique.{e['dtype']}" for rid, e in c["expected"].items()), c["name"]
+        for rid, e in c["expected"].items():
+            got = np.fromfile(out / f"{rid}.unique.{e['dtype']}", dtype=e["dtype"])
+            assert got.tolist() == e["values"], (c["name"], rid)
+    eng.close_all()
+
+
+def test_reference_kat_through_dropin_modules(tmp_path, golden_host, eng):
+    """reference tests/test_count_kmers.py, translated 1:1 onto the drop-in module."""
+    from newmap_amd._c_newmap_count_kmers import count_kmers, count_kmers_from_sequence
+    from newmap_amd._c_newmap_generate_index import generate_fm_index
+    golden = os.path.join(os.path.dirname(__file__), "golden", "genome.fa")
+    idx = str(tmp_path / "genome.awfmi")
+    generate_fm_index(golden, idx, 8, 12)
+    k = golden_host["kat"]["count_kmers"]
+    assert count_kmers(idx, [s.encode() for s in k["kmers"]], 1) == k["expected"]
+    with pytest.raises(TypeError):
+        count_kmers(idx, ["AAAA"], 1)
+    with pytest.raises(ValueError):
+        count_kmers(idx, [b"AAAA", b"", b"TAT"], 1)
+    k = golden_host["kat"]["count_from_sequence"]
+    assert count_kmers_from_sequence(idx, k["sequence"].encode(), k["starts"], k["lengths"], 1) == k["expected"]
+    with pytest.raises(IndexError):
+        count_kmers_from_sequence(idx, b"ACGT", [2], [3], 1)
+    with pytest.raises(IndexError):
+        count_kmers_from_sequence(idx, b"ACGT", [-1], [3], 1)
+    with pytest.raises(ValueError):
+        count_kmers_from_sequence(idx, b"ACGT", [0, 1], [3], 1)
+    with pytest.raises(TypeError):
+        count_kmers_from_sequence(idx, b"ACGT", [0.5], [3], 1)
+    with pytest.raises(OverflowError):
+        count_kmers(idx, [b"A"], 256)
+    with pytest.raises(OSError):
+        count_kmers(str(tmp_path / "missing.awfmi"), [b"A"], 1)
+    bad = tmp_path / "bad.awfmi"
+    bad.write_bytes(b"not an index" * 100)
+    with pytest.raises(OSError):
+        count_kmers(str(bad), [b"A"], 1)
+    eng.close_all()
+
+
+def test_upper_bound_cases_on_device(tmp_path, golden_host, eng):
+    _, idx = _build_index(tmp_path, b">x\nACGTACGTAC\n")
+    with eng.Index(idx, 0) as ix:
+        for c in golden_host["upper_bound"]:
+            mask = np.array(c["mask"], dtype=bool)
+            seq = bytes(np.where(mask, ord("N"), ord("A")).astype(np.uint8)) + b"C" * (c["buffer_len"] - mask.size)
+            got = ix.upper_bound_segment(seq, mask.size, c["kmax"])
+            assert got.tolist() == c["expected"], c
+        with pytest.raises(AssertionError):
+            ix.upper_bound_segment(b"N" * 4 + b"A" * 50, 4, 50)
+
+
+# ------------------------------------------------------------------ seeded inputs vs the oracle
+@pytest.fixture(scope="module")
+def mixed_genome(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("mixed")
+    rng = np.random.default_rng(4242)
+    r1 = bytearray(_random_dna(rng, 300_000))
+    unit = _random_dna(rng, 13)
+    r1[50_000:80_000] = (unit * 3000)[:30_000]                 # long tandem array
+    r1[120_000:120_400] = b"N" * 400
+    r1[200_000:203_000] = bytes(r1[10_000:13_000]).lower()     # soft-masked duplicate
+    r1[250_000:250_001] = b"R"                                  # lone IUPAC code
+    r2 = _random_dna(rng, 80_000) + bytes(r1[1000:9000]) + \
+        bytes(r1[20_000:24_000]).translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1]
+    text = b">one desc\n" + b"\n".join(bytes(r1[i:i + 70]) for i in range(0, len(r1), 70)) + \
+           b"\n>two\n" + r2 + b"\n"
+    fa, idx = _build_index(tmp, text, "mixed")
+    return {"r1": bytes(r1), "r2": r2, "fa": fa, "idx": idx,
+            "oracle": rd.OracleIndex([bytes(r1), r2])}
+
+
+@pytest.mark.parametrize("kmin,kmax,rc", [(20, 200, True), (24, 150, True), (20, 255, True),
+                                          (8, 60, False), (20, 400, True), (30, 70000, True)])
+def test_min_unique_equals_oracle(mixed_genome, eng, kmin, kmax, rc):
+    g = mixed_genome
+    for seed in (None, 0, 6):
+        with eng.Index(g["idx"], 0, seed) as ix:
+            # very long ranges: keep the oracle's O(k) text comparisons affordable
+            recs = (g["r1"], g["r2"]) if kmax <= 1000 else (g["r1"][49_000:56_000], g["r2"][:5000])
+            for rec in recs:
+                want = rd.closed_form_min_unique(rec, g["oracle"], kmin, kmax, rc)
+                got, n_amb = ix.min_unique_segment(rec, len(rec), kmin, kmax, rc)
+                assert got.dtype == want.dtype
+                assert np.array_equal(got, want), (seed, kmin, kmax, rc)
+                assert n_amb == sum(ch not in b"ACGTacgt" for ch in rec)
+
+
+def test_batch_independence_and_segment_api(mixed_genome, eng):
+    """segments with kmax-1 lookahead, stitched, equal the whole-record answer (Appendix A.2)"""
+    g = mixed_genome
+    rec = g["r1"]
+    kmin, kmax = 20, 200
+    with eng.Index(g["idx"], 0) as ix:
+        whole, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+        for batch in (1000, 65_536, 99_999):
+            parts = []
+            for seg in rd.record_segments(b"one", rec, batch + kmax - 1, kmax - 1):
+                n = rd.num_kmers_of(seg, kmax)
+                arr, _ = ix.min_unique_segment(seg.data, n, kmin, kmax)
+                parts.append(arr)
+            assert np.array_equal(np.concatenate(parts), whole), batch
+
+
+@pytest.mark.parametrize("ks,rc", [([36], True), ([100], True), ([12, 20, 30], True), ([30, 12], True),
+                                   ([24], False), ([300, 20], True)])
+def test_fixed_k_equals_oracle(mixed_genome, eng, ks, rc):
+    g = mixed_genome
+    kmax = max(ks)
+    dtype, _ = rd.output_dtype(kmax)
+    with eng.Index(g["idx"], 0) as ix:
+        for rec in (g["r1"][:150_000], g["r2"]):
+            # the lone 'R' (not upper-case N) is outside the compared prefix of r1: list mode on
+            # other ambiguity codes is a documented divergence
+            for batch in (len(rec), 40_000):
+                got, want = [], []
+                for seg in rd.record_segments(b"r", rec, batch + kmax - 1, kmax - 1):
+                    n = rd.num_kmers_of(seg, kmax)
+                    w, _ = rd.linear_search_segment(g["oracle"], seg, ks, kmax, dtype, rc)
+                    a, _ = ix.fixed_k_segment(seg.data, n, ks, rc)
+                    got.append(a)
+                    want.append(w)
+                assert np.array_equal(np.concatenate(got), np.concatenate(want)), (ks, rc, batch)
+
+
+def test_counts_equal_oracle(mixed_genome, eng):
+    g = mixed_genome
+    rng = np.random.default_rng(5)
+    seq = g["r2"]
+    starts = rng.integers(0, len(seq) - 300, 20_000)
+    lens = rng.integers(1, 300, 20_000)
+    with eng.Index(g["idx"], 0) as ix:
+        got = ix.count_from_sequence(seq, starts, lens)
+        assert np.array_equal(got, g["oracle"].count_from_sequence(seq, starts, lens))
+        kmers = [seq[s:s + l] for s, l in zip(starts[:500], lens[:500])] + [b"NNNN", b"ACGTN", b"acgt"]
+        assert ix.count_kmers(kmers).tolist()[:500] == got[:500].tolist()
+        assert ix.count_kmers(kmers).tolist()[500:502] == [0, 0]
+
+
+def test_zero_count_guard_raises(tmp_path, eng):
+    _, idx = _build_index(tmp_path, b">x\n" + b"ACGTTGCAAGGCTTAACCGGATATCGCGAT" * 4 + b"\n", "small", 4)
+    with eng.Index(idx, 0) as ix:
+        with pytest.raises(RuntimeError, match="not found in the index"):
+            ix.min_unique_segment(b"G" * 64, 64, 4, 8)
+        with pytest.raises(RuntimeError, match="not found in the index"):
+            ix.fixed_k_segment(b"G" * 64, 64, [6])
+
+
+def test_open_errors(tmp_path, eng):
+    with pytest.raises(FileNotFoundError):
+        eng.Index(tmp_path / "nope.awfmi", 0)
+    junk = tmp_path / "junk.awfmi"
+    junk.write_bytes(os.urandom(4096))
+    with pytest.raises(OSError):
+        eng.Index(junk, 0)
+    _, idx = _build_index(tmp_path, b">x\nACGTACGTAC\n")
+    with pytest.raises(RuntimeError):
+        eng.Index(idx, -1)                      # no CPU path
+    with pytest.raises(RuntimeError):
+        eng.Index(idx, 99)
+
+
+def test_empty_and_tiny_inputs(tmp_path, eng):
+    _, idx = _build_index(tmp_path, b">x\nACGTACGTACGGTTAACC\n>y\nNNNN\n>z\nA\n", "tiny", 3)
+    with eng.Index(idx, 0) as ix:
+        arr, amb = ix.min_unique_segment(b"", 0, 4, 8)
+        assert arr.size == 0 and amb == 0
+        arr, amb = ix.min_unique_segment(b"NNNN", 4, 4, 8)
+        assert arr.tolist() == [0, 0, 0, 0] and amb == 4
+        arr, amb = ix.min_unique_segment(b"A", 1, 4, 8)
+        assert arr.tolist() == [0] and amb == 0
+        assert ix.count_kmers([b"A"]).tolist() == [5]
+
+
+# ------------------------------------------------------------------ device-resident API + torch
+def test_device_pointer_api_matches_host_api(mixed_genome, eng):
+    from newmap_amd import _lib
+    L = _lib.lib()
+    g = mixed_genome
+    rec = g["r1"]
+    with eng.Index(g["idx"], 0) as ix:
+        want, amb = ix.min_unique_segment(rec, len(rec), 20, 200)
+        d_seq, d_out, d_st = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        assert L.nm_dev_alloc(0, len(rec), ctypes.byref(d_seq)) == 0
+        assert L.nm_dev_alloc(0, len(rec), ctypes.byref(d_out)) == 0
+        assert L.nm_dev_alloc(0, 64, ctypes.byref(d_st)) == 0
+        buf = np.frombuffer(rec, np.uint8)
+        assert L.nm_dev_upload(0, d_seq, buf.ctypes.data, buf.size) == 0
+        ix.set_count_steps(True)
+        ix.min_unique_segment_dev(d_seq.value, len(rec), len(rec), 20, 200, True, 1, d_out.value, d_st.value)
+        assert L.nm_dev_sync(0) == 0
+        got = np.zeros(len(rec), np.uint8)
+        st = np.zeros(8, np.uint64)
+        assert L.nm_dev_download(0, got.ctypes.data, d_out, got.size) == 0
+        assert L.nm_dev_download(0, st.ctypes.data, d_st, 64) == 0
+        assert np.array_equal(got, want)
+        assert int(st[0]) == amb and int(st[1]) == 0
+        assert int(st[7]) == len(rec) - amb and int(st[3]) > 0 and int(st[4]) >= int(st[3])
+        ix.set_count_steps(False)
+        for p in (d_seq, d_out, d_st):
+            L.nm_dev_free(0, p)
+
+
+def test_torch_tensors_share_the_runtime(mixed_genome):
+    """bench.py and the multi-GPU driver hand torch tensors' data_ptr to the C-ABI: both must sit
+    on one HIP runtime (torch is imported first, see newmap_amd/_lib.py)."""
+    import torch
+    from newmap_amd import engine
+    g = mixed_genome
+    rec = g["r2"]
+    with engine.Index(g["idx"], 0) as ix:
+        want, _ = ix.min_unique_segment(rec, len(rec), 24, 150)
+        seq = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to("cuda:0")
+        out = torch.empty(len(rec), dtype=torch.uint8, device="cuda:0")
+        st = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        ix.min_unique_segment_dev(seq.data_ptr(), len(rec), len(rec), 24, 150, True, 1, out.data_ptr(),
+                                  st.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------ larger sizes: properties
+def test_large_random_genome_properties(tmp_path, eng):
+    """20 Mbp uniform genome (a fifth of BASELINE configs[1]): seed-table independence,
+    batch independence, and minimality re-checked through the count seam."""
+    rng = np.random.default_rng(20260515)
+    rec = _random_dna(rng, 20_000_000)
+    fa, idx = _build_index(tmp_path, b">chr1\n" + rec + b"\n", "big")
+    kmin, kmax = 20, 200
+    with eng.Index(idx, 0, 12) as ix:
+        whole, amb = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+        assert amb == 0
+        parts = [ix.min_unique_segment(s.data, rd.num_kmers_of(s, kmax), kmin, kmax)[0]
+                 for s in rd.record_segments(b"c", rec, 10_000_000 + kmax - 1, kmax - 1)]
+        assert np.array_equal(np.concatenate(parts), whole)
+        # tail: the last kmin-1 positions cannot hold a k-mer of length kmin
+        assert not whole[-(kmin - 1):].any() and whole[:-(kmin - 1)].min() >= kmin
+        # minimality through the compat seam: total count at the reported length is 1,
+        # and (when above kmin) the one-shorter k-mer is not unique
+        comp = bytes.maketrans(b"ACGT", b"TGCA")
+        rcrec = rec.translate(comp)[::-1]
+        pos = rng.integers(0, len(rec) - kmax, 50_000)
+        k = whole[pos].astype(np.int64)
+        assert (k > 0).all()
+        tot = ix.count_from_sequence(rec, pos, k) + ix.count_from_sequence(rcrec, len(rec) - pos - k, k)
+        assert (tot == 1).all()
+        longer = k > kmin
+        tot2 = ix.count_from_sequence(rec, pos[longer], k[longer] - 1) + \
+            ix.count_from_sequence(rcrec, len(rec) - pos[longer] - (k[longer] - 1), k[longer] - 1)
+        assert (tot2 > 1).all()
+    with eng.Index(idx, 0, 0) as ix0:
+        no_seed, _ = ix0.min_unique_segment(rec[:3_000_000 + kmax], 3_000_000, kmin, kmax)
+        assert np.array_equal(no_seed, whole[:3_000_000])
+    # and the oracle itself on a prefix (SA counter, reference schedule in C)
+    oracle = rd.OracleIndex([rec])
+    sample = 200_000
+    want, _, _ = rd.ref_binary_search_segment_c(oracle, rec[:sample + kmax - 1], sample, kmin, kmax, fm=False)
+    assert np.array_equal(want.astype(np.uint8), whole[:sample])

@@ -1,0 +1,163 @@
+"""Multi-GPU `search`: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+A position's result depends only on the bytes [p, p+kmax) of its own record and on the read-only
+index, so positions shard with no data-path collective:
+
+  * the index is replicated -- every rank opens the same index file and uploads it to its own HBM;
+  * the concatenated position space of all selected records is cut into `world` contiguous slices;
+    a slice is cut into work units of at most `kmer_batch_size` positions plus kmax-1 bytes of
+    lookahead taken from the same record (the reference's own segment rule,
+    newmap/search.py:229-235, newmap/fasta.py:109-150);
+  * each rank runs its units on its GPU and keeps the uintN results of its slice;
+  * ONE collective at the end: the per-rank slices (padded to equal length) are gathered on rank 0,
+    which cuts them back into per-record `<id>.unique.<dtype>` files.
+
+The same code runs on CPU tensors with the "gloo" backend (tests/test_parallel_gloo.py), with the
+per-unit compute injected.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Callable, Sequence
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class Unit:
+    record: int          # index into the record list
+    start: int           # first position inside the record
+    count: int           # positions in this unit
+    seg_len: int         # bytes handed to the engine: count + lookahead, clipped at the record end
+
+
+def shard_bounds(total: int, world: int) -> list[tuple[int, int]]:
+    """contiguous, near-equal slices of [0, total)"""
+    per = -(-total // world) if total else 0
+    return [(min(r * per, total), min((r + 1) * per, total)) for r in range(world)]
+
+
+def units_for_slice(record_lengths: Sequence[int], lo: int, hi: int, batch: int, kmax: int) -> list[Unit]:
+    """work units covering global positions [lo, hi) (global = records laid end to end)"""
+    units: list[Unit] = []
+    base = 0
+    for r, n in enumerate(record_lengths):
+        a, b = max(lo, base), min(hi, base + n)
+        p = a
+        while p < b:
+            cnt = min(batch, b - p)
+            start = p - base
+            seg_len = min(start + cnt + kmax - 1, n) - start
+            units.append(Unit(r, start, cnt, seg_len))
+            p += cnt
+        base += n
+    return units
+
+
+def run_slice(records: Sequence[tuple[bytes, bytes]], units: Sequence[Unit],
+              compute: Callable[[bytes, int], np.ndarray], dtype) -> np.ndarray:
+    """results of this rank's units, concatenated in global position order"""
+    parts = []
+    for u in units:
+        data = records[u.record][1]
+        seg = data[u.start:u.start + u.seg_len]
+        arr = np.asarray(compute(seg, u.count), dtype=dtype)
+        if arr.size != u.count:
+            raise RuntimeError("engine returned a result of the wrong length")
+        parts.append(arr)
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=dtype)
+
+
+def gather_to_root(local: np.ndarray, total: int, world: int, rank: int, device=None) -> np.ndarray | None:
+    """ONE collective: equal padded slices -> rank 0.  Returns the full array on rank 0."""
+    if world == 1:
+        return local
+    import torch
+    import torch.distributed as dist
+    per = -(-total // world)
+    dev = device if device is not None else torch.device("cpu")
+    raw = np.ascontiguousarray(local).view(np.uint8)
+    item = local.dtype.itemsize
+    buf = torch.zeros(per * item, dtype=torch.uint8, device=dev)
+    if raw.size:
+        buf[:raw.size].copy_(torch.from_numpy(raw.copy()))
+    if rank == 0:
+        out = [torch.empty(per * item, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.gather(buf, out, dst=0)
+        full = torch.cat(out).cpu().numpy().view(local.dtype)
+        bounds = shard_bounds(total, world)
+        pieces = [full[r * per:r * per + (hi - lo)] for r, (lo, hi) in enumerate(bounds)]
+        return np.concatenate(pieces)
+    dist.gather(buf, None, dst=0)
+    return None
+
+
+def search_records_sharded(records: Sequence[tuple[bytes, bytes]], compute: Callable[[bytes, int], np.ndarray],
+                           kmax: int, batch: int, dtype, world: int, rank: int, device=None):
+    """Returns {record id: array} on rank 0 (None elsewhere)."""
+    lengths = [len(d) for _, d in records]
+    total = int(sum(lengths))
+    lo, hi = shard_bounds(total, world)[rank]
+    units = units_for_slice(lengths, lo, hi, batch, kmax)
+    local = run_slice(records, units, compute, dtype)
+    full = gather_to_root(local, total, world, rank, device)
+    if full is None:
+        return None
+    out, base = {}, 0
+    for (rid, _), n in zip(records, lengths):
+        out[rid] = full[base:base + n]        # duplicate ids: the later record wins, like the
+        base += n                             # reference's truncate-on-new-id (search.py:304-305)
+    return out
+
+
+def write_unique_counts_distributed(config) -> None:
+    """`newmap search` over all ranks of the current torch.distributed job (or a single process).
+    Output files are identical to newmap_amd.search.write_unique_counts."""
+    import os
+    from . import search as S
+    from .engine import cached_index
+    from .fasta import fasta_records
+    from .util import optional_gzip_open
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_backend() == "nccl":
+            device = torch.device("cuda", local_rank)
+
+    kmax, kmin = max(config.kmer_lengths), min(config.kmer_lengths)
+    dtype, suffix = S.output_type(kmax)
+    if len(config.fasta_filepaths) != 1 or len(config.fmindex_filepaths) != 1:
+        raise NotImplementedError("the sharded search takes exactly one FASTA and one index")
+    with optional_gzip_open(config.fasta_filepaths[0], "rb") as fh:
+        records = [(rid, data) for rid, data in fasta_records(fh) if S._wanted(config, rid)]
+    if not records:
+        if config.include_sequence_ids:
+            raise ValueError(f"None of the included sequences were found: {config.include_sequence_ids}")
+        raise ValueError("The excluded sequences were too strict and nothing was processed: "
+                         f"{config.exclude_sequence_ids}")
+    index = cached_index(config.fmindex_filepaths[0], local_rank if config.device is None else config.device)
+
+    def compute(seg: bytes, count: int) -> np.ndarray:
+        if config.is_binary_search:
+            return index.min_unique_segment(seg, count, kmin, kmax, config.use_reverse_complement, dtype)[0]
+        return index.fixed_k_segment(seg, count, config.kmer_lengths, config.use_reverse_complement, dtype)[0]
+
+    result = search_records_sharded(records, compute, kmax, config.kmer_batch_size, dtype, world, rank, device)
+    if result is not None:
+        for rid, arr in result.items():
+            path = Path(config.output_directory) / S.UNIQUE_COUNT_FILENAME_FORMAT.format(rid.decode(), suffix)
+            with open(path, "wb") as fh:
+                arr.tofile(fh)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()

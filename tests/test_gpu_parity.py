@@ -222,7 +222,7 @@ def test_empty_and_tiny_inputs(tmp_path, eng):
         assert arr.tolist() == [0, 0, 0, 0] and amb == 4
         arr, amb = ix.min_unique_segment(b"A", 1, 4, 8)
         assert arr.tolist() == [0] and amb == 0
-        assert ix.count_kmers([b"A"]).tolist() == [5]
+        assert ix.count_kmers([b"A"]).tolist() == [6]
 
 
 # ------------------------------------------------------------------ device-resident API + torch

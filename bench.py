@@ -100,12 +100,15 @@ def cpu_baseline(args, genome: np.ndarray, gpu_out: np.ndarray):
     probe, forward + reverse-complement queries, 4^12 seed table) on a bounded sample."""
     from oracle import ref_driver as rd
     threads = rd.lib().or_num_threads()
+    log(f"[bench] cpu baseline: building the oracle's forward-strand FM-index on {threads} threads ...")
     t0 = time.time()
     oracle = rd.OracleIndex([genome.tobytes()])
+    log(f"[bench] cpu baseline: suffix array done ({time.time() - t0:.1f}s)")
     oracle.enable_fm(12)
     t_index = time.time() - t0
+    log(f"[bench] cpu baseline: FM port + 4^12 seed table done ({t_index:.1f}s)")
     rec = genome
-    calib = 20_000
+    calib = min(1_000_000, len(rec) // 4)
     t0 = time.time()
     rd.ref_binary_search_segment_c(oracle, rec[:calib + KMAX - 1].tobytes(), calib, KMIN, KMAX, fm=True)
     rate = calib / max(time.time() - t0, 1e-6)
@@ -154,6 +157,8 @@ def main():
     ix = Index(idx_path, local_rank, args.seed_length)
     t_open = time.time() - t0
     info = ix.info()
+    if rank == 0:
+        log(f"[bench] index open + upload + seed table: {t_open:.1f}s; {info}")
 
     d_seq = torch.from_numpy(genome).to(dev)       # sequence resident in HBM before timing
     d_out = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -186,6 +191,9 @@ def main():
     elapsed = time.perf_counter() - t0
     n_launch, kern_ms, kern_max = ix.read_timing()
     ix.set_timing(False)
+    if rank == 0:
+        log(f"[bench] {args.steps} steps in {elapsed:.3f}s; {n_launch} search launches, "
+            f"{kern_ms:.2f} ms in the kernel (max {kern_max:.3f} ms)")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -40,6 +40,29 @@ def build(verbose: bool = False) -> Path:
     return LIB_PATH
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so with the
+    same SONAME (libamdhip64.so.7) as /opt/rocm's; whichever is mapped first satisfies
+    libnewmap_amd.so's DT_NEEDED.  If this library came first and torch were imported later, torch
+    would map a SECOND runtime that sees no GPU.  So when torch is installed, map its runtime
+    before ours (without importing torch).  NEWMAP_AMD_HIP_RUNTIME=system opts out."""
+    if os.environ.get("NEWMAP_AMD_HIP_RUNTIME", "auto") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            ctypes.CDLL(str(cand), mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -48,10 +71,7 @@ def lib():
         raise EngineMissingError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C newmap_amd/csrc`).  newmap_amd has no CPU fallback.")
-    # When torch is used in the same process its bundled HIP runtime (same SONAME,
-    # libamdhip64.so.7) must be the one this library binds to, so import it first.
-    if os.environ.get("NEWMAP_AMD_WITH_TORCH", "") == "1" and "torch" not in sys.modules:
-        import torch  # noqa: F401
+    _preload_hip_runtime()
     L = ctypes.CDLL(str(LIB_PATH))
     c = ctypes
     vp, u64, u32, i32, u8 = c.c_void_p, c.c_uint64, c.c_uint32, c.c_int, c.c_uint8

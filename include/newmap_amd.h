@@ -110,7 +110,12 @@ int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, ui
                            const uint32_t *ks, uint32_t nk, int use_revcomp, int elem_bytes,
                            void *d_out, uint64_t *d_status, void *stream);
 
-enum { NM_OPT_COUNT_STEPS = 1, NM_OPT_TIMING = 3 };
+enum {
+    NM_OPT_COUNT_STEPS = 1,
+    NM_OPT_TIMING = 3,
+    NM_OPT_KERNEL = 4,             /* 2 (default): persistent-lane range kernel; 1: one lane per position */
+    NM_OPT_PERSISTENT_BLOCKS = 5   /* grid size of the persistent kernel (default 8 x CUs) */
+};
 int nm_set_option(nm_index *ix, int option, int64_t value);
 
 /* NM_OPT_TIMING = 1 brackets every search-kernel launch (k_min_unique / k_fixed_k, not the

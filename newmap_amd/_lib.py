@@ -16,6 +16,8 @@ NM_E_ARGUMENT, NM_E_DEVICE, NM_E_KMER_NOT_FOUND, NM_E_TOO_LARGE = 6, 7, 8, 9
 NM_STATUS_WORDS = 8
 NM_OPT_COUNT_STEPS = 1
 NM_OPT_TIMING = 3
+NM_OPT_KERNEL = 4
+NM_OPT_PERSISTENT_BLOCKS = 5
 
 EXPORTS = [
     "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_close",

@@ -77,20 +77,33 @@ NM_HD uint32_t nm_sep_between(const nm_view &ix, uint64_t a, uint64_t b) {
     return c;
 }
 
-// LF step: C[c] + rank_c(BWT, i)
-template <bool BIG>
-NM_HD uint64_t nm_lf(const nm_view &ix, uint32_t c, uint64_t i) {
+// one 32-byte rank block held in registers
+struct nm_blk { uint32_t c0, c1, c2, c3; uint64_t lo, hi; };
+
+NM_HD nm_blk nm_load_blk(const nm_view &ix, uint64_t i) {
     const nm_rank_block *b = ix.rank + (i >> 6);
-    const uint32_t c0 = b->cnt[0], c1 = b->cnt[1], c2 = b->cnt[2], c3 = b->cnt[3];
-    const uint64_t plo = b->lo, phi = b->hi;
-    const uint32_t cc = c == 0 ? (c0 & ~NM_SEP_FLAG) : (c == 1 ? c1 : (c == 2 ? c2 : c3));
-    uint64_t m = ((c & 1u) ? plo : ~plo) & ((c & 2u) ? phi : ~phi);
+    nm_blk r;
+    r.c0 = b->cnt[0]; r.c1 = b->cnt[1]; r.c2 = b->cnt[2]; r.c3 = b->cnt[3];
+    r.lo = b->lo; r.hi = b->hi;
+    return r;
+}
+
+// LF step on a loaded block: C[c] + rank_c(BWT, i)
+template <bool BIG>
+NM_HD uint64_t nm_lf_blk(const nm_view &ix, uint32_t c, uint64_t i, const nm_blk &b) {
+    const uint32_t cc = c == 0 ? (b.c0 & ~NM_SEP_FLAG) : (c == 1 ? b.c1 : (c == 2 ? b.c2 : b.c3));
+    uint64_t m = ((c & 1u) ? b.lo : ~b.lo) & ((c & 2u) ? b.hi : ~b.hi);
     const uint32_t off = (uint32_t)(i & 63);
     m &= (1ULL << off) - 1ULL;
     uint32_t r = cc + nm_popc64(m);
-    if ((c0 & NM_SEP_FLAG) && c == 0 && off) r -= nm_sep_between(ix, i - off, i);
+    if ((b.c0 & NM_SEP_FLAG) && c == 0 && off) r -= nm_sep_between(ix, i - off, i);
     if (BIG) return ix.superC[(i >> NM_SUPER_SHIFT) * 4 + c] + r;
     return (c == 0 ? ix.C[0] : (c == 1 ? ix.C[1] : (c == 2 ? ix.C[2] : ix.C[3]))) + r;
+}
+
+template <bool BIG>
+NM_HD uint64_t nm_lf(const nm_view &ix, uint32_t c, uint64_t i) {
+    return nm_lf_blk<BIG>(ix, c, i, nm_load_blk(ix, i));
 }
 
 // suffixes of the RC half among suffix-array positions [0, i)
@@ -104,17 +117,20 @@ NM_HD bool nm_strand_bit(const nm_view &ix, uint64_t i) {
 
 struct nm_window { uint64_t lo, hi, amb; };      // sequence positions [pos, pos+64)
 
-NM_HD nm_window nm_load_window(const nm_enc_word *enc, uint64_t pos) {
-    const nm_enc_word *w = enc + (pos >> 6);
-    const uint32_t s = (uint32_t)(pos & 63);
+NM_HD nm_window nm_window_from(const nm_enc_word &a, const nm_enc_word &b, uint32_t s) {
     nm_window r;
-    r.lo = w[0].lo; r.hi = w[0].hi; r.amb = w[0].amb;
+    r.lo = a.lo; r.hi = a.hi; r.amb = a.amb;
     if (s) {
-        r.lo = (r.lo >> s) | (w[1].lo << (64 - s));
-        r.hi = (r.hi >> s) | (w[1].hi << (64 - s));
-        r.amb = (r.amb >> s) | (w[1].amb << (64 - s));
+        r.lo = (r.lo >> s) | (b.lo << (64 - s));
+        r.hi = (r.hi >> s) | (b.hi << (64 - s));
+        r.amb = (r.amb >> s) | (b.amb << (64 - s));
     }
     return r;
+}
+
+NM_HD nm_window nm_load_window(const nm_enc_word *enc, uint64_t pos) {
+    const nm_enc_word *w = enc + (pos >> 6);
+    return nm_window_from(w[0], w[1], (uint32_t)(pos & 63));
 }
 
 NM_HD uint32_t nm_window_code(const nm_window &w, uint32_t j) {

@@ -108,6 +108,155 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique(nm_view ix, const nm_en
     nm_epilogue<STATS>(inb, amb0, err, p, t, status);
 }
 
+
+// ---- k_min_unique_v2: persistent waves, one lane = one position AT A TIME --------------------
+// Same arithmetic as k_min_unique (nm_min_unique_one), different schedule.  In the simple kernel a
+// wave runs as long as its slowest lane: with ~3 LF steps on average but a long tail, most lanes
+// idle.  Here every wave owns a queue of positions (chunks of NM_CHUNK consecutive positions taken
+// from a global counter); a lane that finishes its position takes the next one in the same loop
+// iteration, so every iteration every lane issues exactly one dependent memory round trip:
+//     SEED lane: its seed-table entry           STEP lane: the two rank blocks of lo and hi
+// The chunk's encoded words (18 x 32 B) are staged in LDS, one coalesced load per chunk,
+// prefetched one chunk ahead; a lane builds its 64-base window from LDS without touching HBM.
+#define NM_CHUNK 1024u
+#define NM_CHUNK_WORDS 18u
+enum { NM_IDLE = 0, NM_SEED = 1, NM_STEP = 2 };
+
+__device__ __forceinline__ uint64_t nm_wave_bcast64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool BIG, bool STATS>
+__global__ __launch_bounds__(NM_BLOCK) void k_min_unique_v2(nm_view ix, const nm_enc_word *__restrict__ enc,
+                                                            uint64_t n_enc_words, uint64_t num_kmers,
+                                                            uint32_t kmin, uint32_t kmax, void *__restrict__ out,
+                                                            int elem_bytes, uint64_t *__restrict__ status,
+                                                            unsigned long long *__restrict__ work) {
+    __shared__ nm_enc_word s_words[NM_BLOCK / NM_WAVE][NM_CHUNK_WORDS];
+    const uint32_t lane = threadIdx.x & 63;
+    nm_enc_word *sw = s_words[threadIdx.x >> 6];
+    const uint32_t s = ix.seed_len;
+    const bool use_seed = s && kmin >= s;
+    const uint64_t seed_mask = (1ULL << s) - 1ULL;
+
+    // wave-uniform queue state
+    uint64_t chunk_base = 0, next_base;
+    uint32_t chunk_len = 0, chunk_next = 0;
+    bool more = true;
+    nm_enc_word pre = {0, 0, 0, 0};
+    auto grab = [&]() {
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(work, (unsigned long long)NM_CHUNK);
+        next_base = nm_wave_bcast64(b);
+        if (next_base < num_kmers && lane < NM_CHUNK_WORDS) {
+            uint64_t w = (next_base >> 6) + lane;
+            if (w >= n_enc_words) w = n_enc_words - 1;          // padding words are all-ambiguous
+            pre = enc[w];
+        }
+    };
+    grab();
+
+    // per-lane search state
+    uint32_t state = NM_IDLE, k = 0, kbase = 0;
+    uint64_t p = 0, lo = 0, hi = 0, slot = 0;
+    nm_window w = {0, 0, 0};
+    uint32_t n_amb = 0;
+    nm_tally t = {0, 0, 0, 0};
+    uint32_t n_done = 0;
+
+    for (uint32_t guard = 0; guard < 0x7FFFFFFFu; guard++) {
+        // ---- advance to the prefetched chunk when the current one is used up
+        if (chunk_next >= chunk_len && more) {
+            chunk_base = next_base;
+            if (chunk_base >= num_kmers) { more = false; chunk_len = 0; chunk_next = 0; }
+            else {
+                const uint64_t left = num_kmers - chunk_base;
+                chunk_len = left < NM_CHUNK ? (uint32_t)left : NM_CHUNK;
+                chunk_next = 0;
+                if (lane < NM_CHUNK_WORDS) sw[lane] = pre;
+                __builtin_amdgcn_wave_barrier();
+                grab();
+            }
+        }
+        // ---- hand the next positions of the chunk to idle lanes
+        const uint64_t idle_mask = __ballot(state == NM_IDLE);
+        const uint32_t rem = chunk_len - chunk_next;
+        if (idle_mask && rem) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+            if (state == NM_IDLE && rank < rem) {
+                const uint32_t q = chunk_next + rank;
+                p = chunk_base + q;
+                w = nm_window_from(sw[q >> 6], sw[(q >> 6) + 1], q & 63);
+                kbase = 0;
+                if (w.amb & 1ULL) { n_amb++; nm_store(out, elem_bytes, p, 0); }
+                else if (use_seed) {
+                    if (w.amb & seed_mask) nm_store(out, elem_bytes, p, 0);      // U_p < s <= kmin
+                    else { slot = nm_seed_slot(w, s); state = NM_SEED; if (STATS) n_done++; }
+                } else { lo = 0; hi = ix.n; k = 0; state = NM_STEP; if (STATS) n_done++; }
+                if (STATS && state == NM_IDLE && !(w.amb & 1ULL)) n_done++;
+            }
+            const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+            chunk_next += n_idle < rem ? n_idle : rem;
+        }
+        if (!__ballot(state != NM_IDLE)) {
+            if (!more && chunk_next >= chunk_len) break;
+            continue;
+        }
+        // ---- one memory round trip per lane
+        nm_blk ba = {0, 0, 0, 0, 0, 0}, bb = {0, 0, 0, 0, 0, 0};
+        uint64_t e = 0;
+        if (state == NM_STEP) { ba = nm_load_blk(ix, lo); bb = nm_load_blk(ix, hi); }
+        else if (state == NM_SEED) e = ix.seed[slot];
+        // ---- consume it
+        if (state == NM_SEED) {
+            const uint32_t c = (uint32_t)(e >> NM_SEED_LO_BITS);
+            if (c != NM_SEED_CNT_SAT) { lo = e & NM_SEED_LO_MASK; hi = lo + c; k = s; }
+            else { lo = 0; hi = ix.n; k = 0; }
+            state = NM_STEP;
+            if (STATS) t.seeds++;
+        } else if (state == NM_STEP) {
+            const uint32_t c = 3u - nm_window_code(w, k - kbase);
+            if (STATS) { t.steps++; t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u; }
+            lo = nm_lf_blk<BIG>(ix, c, lo, ba);
+            hi = nm_lf_blk<BIG>(ix, c, hi, bb);
+            k++;
+        }
+        // ---- decide: finished, or which base comes next
+        if (state == NM_STEP) {
+            const uint64_t cnt = hi - lo;
+            uint32_t result = 0;
+            bool done = true;
+            if (cnt == 0) {                                         // search.py:699-722
+                atomicMin((unsigned long long *)&status[2], (unsigned long long)p);
+                atomicOr((unsigned long long *)&status[1], 1ULL);
+            } else if (cnt == 1) {
+                const uint32_t ans = k > kmin ? k : kmin;
+                result = nm_all_valid(enc, p, w, kbase, k, ans) ? ans : 0u;
+            } else if (k < kmax) {
+                uint32_t j = k - kbase;
+                if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+                done = ((w.amb >> j) & 1ULL) != 0;                  // k == U_p and still not unique
+            }
+            if (done) { nm_store(out, elem_bytes, p, result); state = NM_IDLE; }
+        }
+    }
+    // ---- wave totals
+    const uint32_t amb_sum = wave_sum(n_amb);
+    if (lane == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
+    if (STATS) {
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), c = wave_sum(t.seeds), d = wave_sum(n_done);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)d);
+        }
+    }
+}
+
 template <bool BIG, bool RC, bool STATS>
 __global__ __launch_bounds__(NM_BLOCK) void k_fixed_k(nm_view ix, const nm_enc_word *__restrict__ enc,
                                                       uint64_t seq_len, uint64_t num_kmers,
@@ -142,8 +291,9 @@ __global__ __launch_bounds__(NM_BLOCK) void k_upper(const nm_enc_word *__restric
     if (p < num_kmers) out[p] = nm_upper_one(enc, p, kmax);
 }
 
-__global__ void k_reset_status(uint64_t *__restrict__ status) {
+__global__ void k_reset_status(uint64_t *__restrict__ status, unsigned long long *__restrict__ work) {
     if (threadIdx.x < NM_STATUS_WORDS) status[threadIdx.x] = threadIdx.x == 2 ? ~0ULL : 0ULL;
+    if (threadIdx.x == 0 && work) *work = 0ULL;
 }
 
 // ------------------------------------------------------------------------------ host side ---
@@ -172,7 +322,10 @@ struct nm_index {
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
-    nm_buffer enc, seq, out, status, ks, starts, lens;
+    nm_buffer enc, seq, out, status, ks, starts, lens, work;
+    uint64_t enc_words = 0;               // words written by the last nm_encode
+    int kernel_version = 2;               // 2 = persistent-lane kernel (range mode, both strands), 1 = simple
+    unsigned persistent_blocks = 2048;    // set from the device properties at open
     bool count_steps = false;
     // NM_OPT_TIMING: HIP events around every search-kernel launch, on the launch stream
     bool timing = false;
@@ -322,7 +475,13 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     rc = nm_build_seed(ix, s);
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     rc = nm_grow(ix->status, NM_STATUS_WORDS * sizeof(uint64_t));
+    if (rc == NM_OK) rc = nm_grow(ix->work, sizeof(unsigned long long));
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ix->persistent_blocks = (unsigned)prop.multiProcessorCount * 8u;    // 8 x 256 threads = 32 waves / CU
+    }
     *out = ix;
     return NM_OK;
 }
@@ -332,7 +491,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_super, ix->enc.p, ix->seq.p,
-                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p};
+                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
@@ -359,6 +518,16 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
     if (option == NM_OPT_COUNT_STEPS) { ix->count_steps = value != 0; return NM_OK; }
     if (option == NM_OPT_TIMING) { ix->timing = value != 0; ix->ev_used = 0; return NM_OK; }
+    if (option == NM_OPT_KERNEL) {
+        if (value != 1 && value != 2) { nm_set_error("kernel version must be 1 or 2"); return NM_E_ARGUMENT; }
+        ix->kernel_version = (int)value;
+        return NM_OK;
+    }
+    if (option == NM_OPT_PERSISTENT_BLOCKS) {
+        if (value < 1 || value > 65536) { nm_set_error("persistent block count out of range"); return NM_E_ARGUMENT; }
+        ix->persistent_blocks = (unsigned)value;
+        return NM_OK;
+    }
     nm_set_error("unknown option %d", option);
     return NM_E_ARGUMENT;
 }
@@ -387,14 +556,15 @@ static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStrea
     const uint64_t n_words = seq_len / 64 + 3;
     int rc = nm_grow(ix->enc, n_words * sizeof(nm_enc_word));
     if (rc != NM_OK) return rc;
+    ix->enc_words = n_words;
     hipLaunchKernelGGL(k_encode, dim3(nm_grid(n_words * 64)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
                        (nm_enc_word *)ix->enc.p, n_words);
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }
 
-static int nm_reset_status(uint64_t *d_status, hipStream_t st) {
-    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(NM_WAVE), 0, st, d_status);
+static int nm_reset_status(nm_index *ix, uint64_t *d_status, hipStream_t st) {
+    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(NM_WAVE), 0, st, d_status, (unsigned long long *)ix->work.p);
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }
@@ -409,9 +579,21 @@ static int nm_check_segment_args(const nm_index *ix, uint64_t seq_len, uint64_t 
 template <bool BIG, bool RC>
 static void launch_min_unique(nm_index *ix, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, void *d_out,
                               int elem_bytes, uint64_t *d_status, hipStream_t st) {
-    const dim3 grid(nm_grid(num_kmers)), block(NM_BLOCK);
+    const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
     nm_timed timed(ix, st);
+    if (RC && ix->kernel_version == 2) {
+        // persistent grid: enough waves to fill the chip, never more than there are chunks
+        const uint64_t chunks = (num_kmers + NM_CHUNK - 1) / NM_CHUNK;
+        uint64_t blocks = (chunks + NM_BLOCK / NM_WAVE - 1) / (NM_BLOCK / NM_WAVE);
+        if (blocks > ix->persistent_blocks) blocks = ix->persistent_blocks;
+        const dim3 pgrid((unsigned)blocks);
+        unsigned long long *work = (unsigned long long *)ix->work.p;
+        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_v2<BIG, true>), pgrid, block, 0, st, ix->view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
+        else                 hipLaunchKernelGGL((k_min_unique_v2<BIG, false>), pgrid, block, 0, st, ix->view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
+        return;
+    }
+    const dim3 grid(nm_grid(num_kmers));
     if (ix->count_steps) hipLaunchKernelGGL((k_min_unique<BIG, RC, true>), grid, block, 0, st, ix->view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
     else                 hipLaunchKernelGGL((k_min_unique<BIG, RC, false>), grid, block, 0, st, ix->view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
 }
@@ -426,7 +608,7 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
     if (!d_status) { nm_set_error("d_status is required"); return NM_E_ARGUMENT; }
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
-    if ((rc = nm_reset_status(d_status, st)) != NM_OK) return rc;
+    if ((rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
     if (num_kmers == 0) return NM_OK;
     if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
     if (ix->big) { if (use_revcomp) launch_min_unique<true, true>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); else launch_min_unique<true, false>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); }
@@ -460,7 +642,7 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     if (!d_status) { nm_set_error("d_status is required"); return NM_E_ARGUMENT; }
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
-    if ((rc = nm_reset_status(d_status, st)) != NM_OK) return rc;
+    if ((rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
     if (num_kmers == 0) return NM_OK;
     if ((rc = nm_grow(ix->ks, (uint64_t)nk * sizeof(uint32_t))) != NM_OK) return rc;
     HIP_TRY(hipMemcpyAsync(ix->ks.p, ks, (uint64_t)nk * sizeof(uint32_t), hipMemcpyHostToDevice, st));

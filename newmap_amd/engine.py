@@ -82,6 +82,13 @@ class Index:
     def set_count_steps(self, on: bool):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_COUNT_STEPS, int(bool(on))))
 
+    def set_kernel(self, version: int):
+        """2 = persistent-lane kernel (default), 1 = one lane per position (A/B measurements)"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_KERNEL, int(version)))
+
+    def set_persistent_blocks(self, blocks: int):
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_PERSISTENT_BLOCKS, int(blocks)))
+
     def set_timing(self, on: bool):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_TIMING, int(bool(on))))
 

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_v2(nm_view ix, const nm
     nm_tally t = {0, 0, 0, 0};
     uint32_t n_done = 0;
 
-    for (uint32_t guard = 0; guard < 0x7FFFFFFFu; guard++) {
+    for (uint32_t guard = 0; guard < (1u << 24); guard++) {      // every wave reaches an exit
         // ---- advance to the prefetched chunk when the current one is used up
         if (chunk_next >= chunk_len && more) {
             chunk_base = next_base;

@@ -49,6 +49,8 @@ class Index:
         _lib.raise_for(rc)
         self._h = h
         self._lock = threading.Lock()
+        if os.environ.get("NEWMAP_AMD_KERNEL"):            # A/B measurements: 1 = simple, 2 = persistent
+            self.set_kernel(int(os.environ["NEWMAP_AMD_KERNEL"]))
 
     # lifetime -----------------------------------------------------------------------------
     def close(self):

@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mbp", type=float, default=100.0, help="genome size (default: configs[1], 100 Mbp)")
-    ap.add_argument("--seed-length", type=int, default=12, help="device seed table length (reference default 12)")
+    ap.add_argument("--seed-length", default="auto",
+                    help="device seed table length: auto (default, ceil(log4 n)+1), file (the index's, 12), or 0..16")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -154,7 +155,7 @@ def main():
     genome, fa, idx_path, t_build = prepare_workload(args, rank, world, barrier)
     n = int(genome.size)
     t0 = time.time()
-    ix = Index(idx_path, local_rank, args.seed_length)
+    ix = Index(idx_path, local_rank, args.seed_length if args.seed_length in ("auto", "file") else int(args.seed_length))
     t_open = time.time() - t0
     info = ix.info()
     if rank == 0:

@@ -56,8 +56,12 @@ const char *nm_version(void);
  * device seed table built at nm_index_open time. */
 int nm_index_build(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len);
 
-/* Read an index file and upload it to HBM of `device` (>= 0).  seed_len_override < 0 keeps the
- * length recorded in the file; 0 disables the seed table.  Replaces createIndex()
+/* Read an index file and upload it to HBM of `device` (>= 0).  seed_len_override: -1 keeps the
+ * length recorded in the file (the reference's --seed-length, default 12), -2 = automatic
+ * (ceil(log4 n) + 1 bases, at most 16 and at most a quarter of the free HBM: with 288 GB the table
+ * can be long enough that most positions resolve in ONE lookup), 0 disables the seed table,
+ * 1..16 forces a length.  Searches whose shortest length is below the table's get a second small
+ * table of that length on first use.  Replaces createIndex()
  * (src/newmap-count.c:9-17) -- but returns an error instead of continuing with a bad handle. */
 int nm_index_open(const char *index_path, int device, int seed_len_override, nm_index **out);
 void nm_index_close(nm_index *ix);

@@ -49,8 +49,9 @@ __global__ __launch_bounds__(NM_BLOCK) void k_encode(const uint8_t *__restrict__
 }
 
 template <bool BIG>
-__global__ __launch_bounds__(NM_BLOCK) void k_seed(nm_view ix, uint64_t *__restrict__ table, uint64_t n_slots, uint32_t s) {
-    const uint64_t slot = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+__global__ __launch_bounds__(NM_BLOCK) void k_seed(nm_view ix, uint64_t *__restrict__ table, uint64_t first_slot,
+                                                   uint64_t n_slots, uint32_t s) {
+    const uint64_t slot = first_slot + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     if (slot < n_slots) table[slot] = nm_seed_entry<BIG>(ix, slot, s);
 }
 
@@ -319,12 +320,14 @@ struct nm_index {
     nm_view view;
     bool big = false;
     void *d_rank = nullptr, *d_strand = nullptr, *d_sep = nullptr, *d_seed = nullptr, *d_super = nullptr;
+    void *d_seed2 = nullptr;              // small secondary seed table (nm_view_for)
+    uint32_t seed2_len = 0;
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
     nm_buffer enc, seq, out, status, ks, starts, lens, work;
     uint64_t enc_words = 0;               // words written by the last nm_encode
-    int kernel_version = 2;               // 2 = persistent-lane kernel (range mode, both strands), 1 = simple
+    int kernel_version = 1;               // 1 = one lane per position (default, faster as measured), 2 = persistent lanes
     unsigned persistent_blocks = 2048;    // set from the device properties at open
     bool count_steps = false;
     // NM_OPT_TIMING: HIP events around every search-kernel launch, on the launch stream
@@ -366,20 +369,66 @@ extern "C" int nm_device_count(void) {
     return n;
 }
 
+// build the 4^s table on the device; launches are sliced so that grid * block stays below 2^32
+static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table) {
+    const uint64_t n_slots = 1ULL << (2 * s);
+    HIP_TRY(hipMalloc(d_table, n_slots * sizeof(uint64_t)));
+    ix->device_bytes += n_slots * sizeof(uint64_t);
+    nm_view v = ix->view;
+    v.seed = nullptr;
+    v.seed_len = 0;
+    const uint64_t slice = 1ULL << 30;
+    for (uint64_t first = 0; first < n_slots; first += slice) {
+        const uint64_t m = n_slots - first < slice ? n_slots - first : slice;
+        if (ix->big) hipLaunchKernelGGL(k_seed<true>, dim3(nm_grid(m)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)*d_table, first, n_slots, s);
+        else         hipLaunchKernelGGL(k_seed<false>, dim3(nm_grid(m)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)*d_table, first, n_slots, s);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return NM_OK;
+}
+
+// seed length that makes most positions resolve in the table: one more base than log4(n)
+static uint32_t nm_auto_seed_len(const nm_index *ix) {
+    uint32_t s = 1;
+    while (s < 16 && (1ULL << (2 * s)) < ix->h.n) s++;     // s = ceil(log4 n)
+    s = s + 1 > 16 ? 16 : s + 1;
+    if (s < 4) s = 4;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        while (s > 4 && (8ULL << (2 * s)) > free_b / 4) s--;   // never more than a quarter of free HBM
+    return s;
+}
+
 static int nm_build_seed(nm_index *ix, uint32_t s) {
     ix->view.seed = nullptr;
     ix->view.seed_len = 0;
     if (s == 0 || ix->h.n < 2) return NM_OK;
-    const uint64_t n_slots = 1ULL << (2 * s);
-    HIP_TRY(hipMalloc(&ix->d_seed, n_slots * sizeof(uint64_t)));
-    ix->device_bytes += n_slots * sizeof(uint64_t);
-    const unsigned grid = nm_grid(n_slots);     // 4^16 / 256 = 16.7 M blocks max, within limits
-    if (ix->big) hipLaunchKernelGGL(k_seed<true>, dim3(grid), dim3(NM_BLOCK), 0, ix->stream, ix->view, (uint64_t *)ix->d_seed, n_slots, s);
-    else         hipLaunchKernelGGL(k_seed<false>, dim3(grid), dim3(NM_BLOCK), 0, ix->stream, ix->view, (uint64_t *)ix->d_seed, n_slots, s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ix->stream));
+    int rc = nm_build_seed_table(ix, s, &ix->d_seed);
+    if (rc != NM_OK) return rc;
     ix->view.seed = (const uint64_t *)ix->d_seed;
     ix->view.seed_len = s;
+    return NM_OK;
+}
+
+// Range / list searches whose shortest length is below the main table's s cannot use it; they get
+// a second, small table of exactly that length (built on first use, kept in the handle).
+static int nm_view_for(nm_index *ix, uint32_t shortest, nm_view *v) {
+    *v = ix->view;
+    if (ix->view.seed_len == 0 || shortest >= ix->view.seed_len) return NM_OK;
+    v->seed = nullptr;
+    v->seed_len = 0;
+    const uint32_t s2 = shortest > 12 ? 12 : shortest;
+    if (s2 < 4) return NM_OK;
+    if (ix->seed2_len != s2) {
+        if (ix->d_seed2) { HIP_TRY(hipFree(ix->d_seed2)); ix->d_seed2 = nullptr; ix->device_bytes -= 8ULL << (2 * ix->seed2_len); }
+        ix->seed2_len = 0;
+        int rc = nm_build_seed_table(ix, s2, &ix->d_seed2);
+        if (rc != NM_OK) return rc;
+        ix->seed2_len = s2;
+    }
+    v->seed = (const uint64_t *)ix->d_seed2;
+    v->seed_len = s2;
     return NM_OK;
 }
 
@@ -470,7 +519,8 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.seed_len = 0;
     v.n_super = (uint32_t)h.n_super;
 
-    uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
+    uint32_t s = seed_len_override == -1 ? h.seed_len
+               : (seed_len_override < -1 ? nm_auto_seed_len(ix) : (uint32_t)seed_len_override);
     if (s > 16) s = 16;
     rc = nm_build_seed(ix, s);
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
@@ -490,7 +540,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_super, ix->enc.p, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_super, ix->enc.p, ix->seq.p,
                     ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -577,7 +627,7 @@ static int nm_check_segment_args(const nm_index *ix, uint64_t seq_len, uint64_t 
 }
 
 template <bool BIG, bool RC>
-static void launch_min_unique(nm_index *ix, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, void *d_out,
+static void launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, void *d_out,
                               int elem_bytes, uint64_t *d_status, hipStream_t st) {
     const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
@@ -589,13 +639,13 @@ static void launch_min_unique(nm_index *ix, uint64_t num_kmers, uint32_t kmin, u
         if (blocks > ix->persistent_blocks) blocks = ix->persistent_blocks;
         const dim3 pgrid((unsigned)blocks);
         unsigned long long *work = (unsigned long long *)ix->work.p;
-        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_v2<BIG, true>), pgrid, block, 0, st, ix->view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
-        else                 hipLaunchKernelGGL((k_min_unique_v2<BIG, false>), pgrid, block, 0, st, ix->view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
+        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_v2<BIG, true>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
+        else                 hipLaunchKernelGGL((k_min_unique_v2<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
         return;
     }
     const dim3 grid(nm_grid(num_kmers));
-    if (ix->count_steps) hipLaunchKernelGGL((k_min_unique<BIG, RC, true>), grid, block, 0, st, ix->view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
-    else                 hipLaunchKernelGGL((k_min_unique<BIG, RC, false>), grid, block, 0, st, ix->view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
+    if (ix->count_steps) hipLaunchKernelGGL((k_min_unique<BIG, RC, true>), grid, block, 0, st, view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
+    else                 hipLaunchKernelGGL((k_min_unique<BIG, RC, false>), grid, block, 0, st, view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
 }
 
 extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
@@ -611,20 +661,22 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
     if ((rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
     if (num_kmers == 0) return NM_OK;
     if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
-    if (ix->big) { if (use_revcomp) launch_min_unique<true, true>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); else launch_min_unique<true, false>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); }
-    else         { if (use_revcomp) launch_min_unique<false, true>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); else launch_min_unique<false, false>(ix, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); }
+    nm_view view;
+    if ((rc = nm_view_for(ix, kmin, &view)) != NM_OK) return rc;
+    if (ix->big) { if (use_revcomp) launch_min_unique<true, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); else launch_min_unique<true, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); }
+    else         { if (use_revcomp) launch_min_unique<false, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); else launch_min_unique<false, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); }
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }
 
 template <bool BIG, bool RC>
-static void launch_fixed_k(nm_index *ix, uint64_t seq_len, uint64_t num_kmers, const uint32_t *d_ks, uint32_t nk,
+static void launch_fixed_k(nm_index *ix, const nm_view &view, uint64_t seq_len, uint64_t num_kmers, const uint32_t *d_ks, uint32_t nk,
                            void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st) {
     const dim3 grid(nm_grid(num_kmers)), block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
     nm_timed timed(ix, st);
-    if (ix->count_steps) hipLaunchKernelGGL((k_fixed_k<BIG, RC, true>), grid, block, 0, st, ix->view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
-    else                 hipLaunchKernelGGL((k_fixed_k<BIG, RC, false>), grid, block, 0, st, ix->view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
+    if (ix->count_steps) hipLaunchKernelGGL((k_fixed_k<BIG, RC, true>), grid, block, 0, st, view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
+    else                 hipLaunchKernelGGL((k_fixed_k<BIG, RC, false>), grid, block, 0, st, view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
 }
 
 extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
@@ -648,8 +700,12 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     HIP_TRY(hipMemcpyAsync(ix->ks.p, ks, (uint64_t)nk * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
     const uint32_t *d_ks = (const uint32_t *)ix->ks.p;
-    if (ix->big) { if (use_revcomp) launch_fixed_k<true, true>(ix, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<true, false>(ix, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
-    else         { if (use_revcomp) launch_fixed_k<false, true>(ix, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<false, false>(ix, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
+    uint32_t kshort = ks[0];
+    for (uint32_t i = 1; i < nk; i++) if (ks[i] < kshort) kshort = ks[i];
+    nm_view view;
+    if ((rc = nm_view_for(ix, kshort, &view)) != NM_OK) return rc;
+    if (ix->big) { if (use_revcomp) launch_fixed_k<true, true>(ix, view, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<true, false>(ix, view, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
+    else         { if (use_revcomp) launch_fixed_k<false, true>(ix, view, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<false, false>(ix, view, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }

@@ -39,13 +39,17 @@ def _as_u8(buf) -> np.ndarray:
 class Index:
     """Device-resident index.  Replaces the per-call load of src/newmap-count.c:9-17,135-136."""
 
-    def __init__(self, index_path, device: int | None = None, seed_length: int | None = None):
+    def __init__(self, index_path, device: int | None = None, seed_length: int | str | None = None):
+        """seed_length: None / "auto" = sized for the device (ceil(log4 n)+1, <= 16), "file" = the
+        --seed-length recorded by `newmap index`, 0 = no seed table, 1..16 = that length."""
         self._L = _lib.lib()
         self.path = Path(index_path)
         self.device = default_device() if device is None else int(device)
+        if seed_length is None:
+            seed_length = os.environ.get("NEWMAP_AMD_SEED_LENGTH", "auto")
+        code = -2 if seed_length == "auto" else (-1 if seed_length == "file" else int(seed_length))
         h = ctypes.c_void_p()
-        rc = self._L.nm_index_open(os.fsencode(self.path), self.device,
-                                   -1 if seed_length is None else int(seed_length), ctypes.byref(h))
+        rc = self._L.nm_index_open(os.fsencode(self.path), self.device, code, ctypes.byref(h))
         _lib.raise_for(rc)
         self._h = h
         self._lock = threading.Lock()

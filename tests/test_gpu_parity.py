@@ -310,3 +310,82 @@ def test_large_random_genome_properties(tmp_path, eng):
     sample = 200_000
     want, _, _ = rd.ref_binary_search_segment_c(oracle, rec[:sample + kmax - 1], sample, kmin, kmax, fm=False)
     assert np.array_equal(want.astype(np.uint8), whole[:sample])
+
+
+# ------------------------------------------------------------------ BASELINE configs, scaled down
+def _records_fasta(recs):
+    out = []
+    for name, seq in recs:
+        out.append(b">" + name.encode() + b"\n" + seq.tobytes() + b"\n")
+    return b"".join(out)
+
+
+def test_config3_human_shaped_24_records(tmp_path, eng):
+    """BASELINE configs[2] at 1/1000 scale: 24 records, search-range 24:150, written through
+    write_unique_counts with a batch that splits the larger records."""
+    from newmap_amd import synth
+    from newmap_amd.search import SearchConfig, write_unique_counts
+    recs = synth.config_genome("c3", 3.0)
+    fa, idx = _build_index(tmp_path, _records_fasta(recs), "c3")
+    out = tmp_path / "out"
+    out.mkdir()
+    write_unique_counts(SearchConfig(fasta_filepaths=[fa], fmindex_filepaths=[idx],
+                                     kmer_lengths=list(range(24, 151)), is_binary_search=True,
+                                     kmer_batch_size=100_000, output_directory=out))
+    oracle = rd.OracleIndex([s.tobytes() for _, s in recs])
+    for name, seq in recs:
+        got = np.fromfile(out / f"{name}.unique.uint8", dtype=np.uint8)
+        want = rd.closed_form_min_unique(seq.tobytes(), oracle, 24, 150)
+        assert np.array_equal(got, want), name
+    eng.close_all()
+
+
+def test_config5_tandem_repeats_20_255(tmp_path, eng):
+    """BASELINE configs[4] at 1/500 scale: 50 % tandem repeats, 20:255 (worst-case walk depth)."""
+    from newmap_amd import synth
+    recs = synth.config_genome("c5", 2.0)
+    fa, idx = _build_index(tmp_path, _records_fasta(recs), "c5")
+    rec = recs[0][1].tobytes()
+    oracle = rd.OracleIndex([rec])
+    want = rd.closed_form_min_unique(rec, oracle, 20, 255)
+    with eng.Index(idx, 0) as ix:
+        got, amb = ix.min_unique_segment(rec, len(rec), 20, 255)
+        assert amb == 0 and np.array_equal(got, want)
+        ix.set_kernel(1)
+        got1, _ = ix.min_unique_segment(rec, len(rec), 20, 255)
+        assert np.array_equal(got1, want)
+    assert 0.2 < np.count_nonzero(want == 0) / want.size < 0.8      # repeats really are not unique
+
+
+@pytest.mark.parametrize("k", [36, 100])
+def test_config4_fixed_k(tmp_path, eng, k):
+    """BASELINE configs[3] shape (fixed-k list mode, k = 36 and 100) on a scaled human-shaped genome
+    with N gaps; compared with the oracle's restatement of linear_search incl. the tail rule."""
+    from newmap_amd import synth
+    recs = synth.config_genome("c3", 1.0)[:6]
+    recs = [(n, s.copy()) for n, s in recs]
+    recs[0][1][5000:6000] = ord("N")
+    recs[2][1][:300] = ord("N")
+    fa, idx = _build_index(tmp_path, _records_fasta(recs), "c4")
+    oracle = rd.OracleIndex([s.tobytes() for _, s in recs])
+    with eng.Index(idx, 0) as ix:
+        for name, seq in recs:
+            data = seq.tobytes()
+            seg = rd.Segment(name.encode(), data, True)
+            want, _ = rd.linear_search_segment(oracle, seg, [k], k, np.uint8)
+            got, _ = ix.fixed_k_segment(data, len(data), [k])
+            assert np.array_equal(got, want), (name, k)
+
+
+def test_both_range_kernels_agree(mixed_genome, eng):
+    """the persistent-lane kernel (default) and the one-lane-per-position kernel are two schedules
+    of the same arithmetic"""
+    g = mixed_genome
+    with eng.Index(g["idx"], 0) as ix:
+        for rec in (g["r1"], g["r2"]):
+            for kmin, kmax in ((20, 200), (8, 30), (20, 1000)):
+                ix.set_kernel(2)
+                a, amb_a = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                ix.set_kernel(1)
+                b, amb_b = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                assert np.array_equal(a, b) and amb_a == amb_b

@@ -118,7 +118,8 @@ enum {
     NM_OPT_COUNT_STEPS = 1,
     NM_OPT_TIMING = 3,
     NM_OPT_KERNEL = 4,             /* 2 (default): persistent-lane range kernel; 1: one lane per position */
-    NM_OPT_PERSISTENT_BLOCKS = 5   /* grid size of the persistent kernel (default 8 x CUs) */
+    NM_OPT_PERSISTENT_BLOCKS = 5,  /* grid size of the persistent kernel (default 8 x CUs) */
+    NM_OPT_FORCE_BIG = 6           /* tests: use the kernels for indexes beyond 2^31 positions */
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 

@@ -18,6 +18,7 @@ NM_OPT_COUNT_STEPS = 1
 NM_OPT_TIMING = 3
 NM_OPT_KERNEL = 4
 NM_OPT_PERSISTENT_BLOCKS = 5
+NM_OPT_FORCE_BIG = 6
 
 EXPORTS = [
     "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_close",

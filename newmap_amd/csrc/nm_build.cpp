@@ -26,6 +26,7 @@
 #include "nm_format.h"
 #include "nm_internal.h"
 #include "nm_sais.hpp"
+#include "nm_pdsa.hpp"
 
 static thread_local char g_err[1024] = "";
 
@@ -136,8 +137,18 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
     }
     T[n - 1] = SYM_END;
 
-    std::vector<I> SA(n);
-    nm::sais<uint8_t, I>(T.data(), SA.data(), (I)n, (I)6);
+    // suffix array: parallel prefix doubling when there are cores to use, SA-IS otherwise
+    // (NEWMAP_AMD_SA=sais|pd forces one; both give the same array, tests/test_index_and_core_cpu.py)
+    const bool verbose = nm::pd_verbose();
+    double tv = nm::pd_now();
+    nm::PdBuf<I> SA(n);
+    {
+        const char *want = getenv("NEWMAP_AMD_SA");
+        const bool use_pd = want ? strcmp(want, "pd") == 0 : (nm::pd_threads() > 1 && n > (1u << 16));
+        if (use_pd) nm::pd_suffix_array<I>(T.data(), n, SA.data());
+        else nm::sais<uint8_t, I>(T.data(), SA.data(), (I)n, (I)6);
+        if (verbose) { fprintf(stderr, "[build] suffix array (%s, %d threads): %.2fs\n", use_pd ? "prefix doubling" : "SA-IS", nm::pd_threads(), nm::pd_now() - tv); tv = nm::pd_now(); }
+    }
 
     nm_file_header h;
     memset(&h, 0, sizeof h);
@@ -158,39 +169,89 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
     h.n_super = (n >> NM_SUPER_SHIFT) + 1;
     if (h.n_super > NM_MAX_SUPER) { nm_set_error("text of %llu symbols is too large", (unsigned long long)n); return NM_E_TOO_LARGE; }
 
-    std::vector<nm_rank_block> rank(h.n_rank_blocks);
+    // ---- BWT symbol (low bits) and "suffix starts in the RC half" (bit 7) per suffix-array position
+    const int nt = nm::pd_threads();
+    const uint64_t nblk = h.n_rank_blocks;
+    nm::PdBuf<uint8_t> bw(n);
+    std::vector<uint64_t> part((size_t)(nt + 1) * 5, 0);          // per block range: A,C,G,T,rc-half
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const uint64_t i0 = std::min<uint64_t>(nblk * (uint64_t)t / nt * 64, n);
+        const uint64_t i1 = std::min<uint64_t>(nblk * (uint64_t)(t + 1) / nt * 64, n);
+        uint64_t cnt[5] = {0, 0, 0, 0, 0};
+        for (uint64_t i = i0; i < i1; i++) {
+            const uint64_t p = (uint64_t)SA[i];
+            const uint8_t ch = T[p ? p - 1 : n - 1];
+            const bool rc_half = p >= nf && p < 2 * nf;
+            bw[i] = (uint8_t)(ch | (rc_half ? 0x80 : 0));
+            if (ch >= SYM_A) cnt[ch - SYM_A]++;
+            cnt[4] += rc_half;
+        }
+        for (int c = 0; c < 5; c++) part[(size_t)(t + 1) * 5 + c] = cnt[c];
+    }
+    SA.release();
+    for (int t = 0; t < nt; t++)
+        for (int c = 0; c < 5; c++) part[(size_t)(t + 1) * 5 + c] += part[(size_t)t * 5 + c];
+
+    // ---- blocks: absolute counts first, made superblock-relative afterwards
+    std::vector<nm_rank_block> rank(nblk);
     std::vector<nm_strand_block> strand(h.n_strand_blocks);
+    nm::PdBuf<uint64_t> absv(nblk * 4);
+    std::vector<std::vector<uint64_t>> tsep((size_t)nt);
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const uint64_t b0 = nblk * (uint64_t)t / nt, b1 = nblk * (uint64_t)(t + 1) / nt;
+        uint64_t run[4], rc_before = part[(size_t)t * 5 + 4];
+        for (int c = 0; c < 4; c++) run[c] = part[(size_t)t * 5 + c];
+        for (uint64_t b = b0; b < b1; b++) {
+            for (int c = 0; c < 4; c++) absv[(size_t)b * 4 + c] = run[c];
+            uint64_t lo = 0, hi = 0, bits = 0;
+            uint32_t flag = 0;
+            const uint64_t base = b * 64, e = std::min<uint64_t>(base + 64, n);
+            for (uint64_t i = base; i < e; i++) {
+                const uint8_t v = bw[i], ch = v & 0x7F;
+                const uint64_t bit = 1ULL << (i & 63);
+                if (ch >= SYM_A) {
+                    const unsigned c = ch - SYM_A;
+                    run[c]++;
+                    if (c & 1) lo |= bit;
+                    if (c & 2) hi |= bit;
+                } else {
+                    tsep[t].push_back(i);
+                    flag = NM_SEP_FLAG;
+                }
+                if (v & 0x80) bits |= bit;
+            }
+            rank[b].cnt[0] = flag; rank[b].cnt[1] = rank[b].cnt[2] = rank[b].cnt[3] = 0;
+            rank[b].lo = lo; rank[b].hi = hi;
+            strand[b].before = rc_before;
+            strand[b].bits = bits;
+            rc_before += (uint64_t)__builtin_popcountll(bits);
+        }
+    }
+    const uint64_t blocks_per_super = 1ULL << (NM_SUPER_SHIFT - 6);
+    for (uint64_t sb = 0; sb < h.n_super; sb++)
+        for (int c = 0; c < 4; c++) h.super_cnt[sb][c] = absv[(size_t)(sb * blocks_per_super) * 4 + c];
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int64_t b = 0; b < (int64_t)nblk; b++) {
+        const uint64_t sb = (uint64_t)b / blocks_per_super;
+        for (int c = 0; c < 4; c++)
+            rank[b].cnt[c] |= (uint32_t)(absv[(size_t)b * 4 + c] - h.super_cnt[sb][c]);
+    }
+    if (verbose) { fprintf(stderr, "[build] BWT + blocks: %.2fs\n", nm::pd_now() - tv); tv = nm::pd_now(); }
     std::vector<uint64_t> sep;
     sep.reserve(h.n_sep);
-    memset(rank.data(), 0, rank.size() * sizeof(nm_rank_block));
-    memset(strand.data(), 0, strand.size() * sizeof(nm_strand_block));
-
-    uint64_t abs_cnt[4] = {0, 0, 0, 0}, sup_cnt[4] = {0, 0, 0, 0}, rc_before = 0;
-    for (uint64_t i = 0; i <= n; i++) {
-        if ((i & 63) == 0) {
-            if ((i & ((1ULL << NM_SUPER_SHIFT) - 1)) == 0) {
-                for (int c = 0; c < 4; c++) { sup_cnt[c] = abs_cnt[c]; h.super_cnt[i >> NM_SUPER_SHIFT][c] = abs_cnt[c]; }
-            }
-            nm_rank_block &b = rank[i >> 6];
-            for (int c = 0; c < 4; c++) b.cnt[c] = (uint32_t)(abs_cnt[c] - sup_cnt[c]);
-            strand[i >> 6].before = rc_before;
-        }
-        if (i == n) break;
-        const uint64_t p = (uint64_t)SA[i];
-        const uint8_t ch = T[p ? p - 1 : n - 1];
-        nm_rank_block &b = rank[i >> 6];
-        const uint64_t bit = 1ULL << (i & 63);
-        if (ch >= SYM_A) {
-            const unsigned c = ch - SYM_A;
-            abs_cnt[c]++;
-            if (c & 1) b.lo |= bit;
-            if (c & 2) b.hi |= bit;
-        } else {
-            sep.push_back(i);
-        }
-        if (p >= nf && p < 2 * nf) { strand[i >> 6].bits |= bit; rc_before++; }
-    }
-    for (uint64_t s : sep) rank[s >> 6].cnt[0] |= NM_SEP_FLAG;
+    for (auto &v : tsep) sep.insert(sep.end(), v.begin(), v.end());
     if (sep.size() != h.n_sep) { nm_set_error("internal error: separator count mismatch"); return NM_E_FILE_WRITE; }
 
     h.off_rank = sizeof h;

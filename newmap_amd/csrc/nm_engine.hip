@@ -568,6 +568,10 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
     if (option == NM_OPT_COUNT_STEPS) { ix->count_steps = value != 0; return NM_OK; }
     if (option == NM_OPT_TIMING) { ix->timing = value != 0; ix->ev_used = 0; return NM_OK; }
+    if (option == NM_OPT_FORCE_BIG) {      // tests: run the >2^31-position code path on a small index
+        ix->big = value != 0 || ix->h.n_super > 1;
+        return NM_OK;
+    }
     if (option == NM_OPT_KERNEL) {
         if (value != 1 && value != 2) { nm_set_error("kernel version must be 1 or 2"); return NM_E_ARGUMENT; }
         ix->kernel_version = (int)value;

@@ -95,6 +95,10 @@ class Index:
     def set_persistent_blocks(self, blocks: int):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_PERSISTENT_BLOCKS, int(blocks)))
 
+    def set_force_big(self, on: bool):
+        """tests: exercise the code path of indexes beyond 2^31 positions on a small index"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_FORCE_BIG, int(bool(on))))
+
     def set_timing(self, on: bool):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_TIMING, int(bool(on))))
 

@@ -389,3 +389,22 @@ def test_both_range_kernels_agree(mixed_genome, eng):
                 ix.set_kernel(1)
                 b, amb_b = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                 assert np.array_equal(a, b) and amb_a == amb_b
+
+
+def test_big_index_code_path(mixed_genome, eng):
+    """kernels templated for > 2^31 BWT positions (64-bit superblock table) on a small index"""
+    g = mixed_genome
+    with eng.Index(g["idx"], 0) as ix:
+        rec = g["r1"]
+        a, amb = ix.min_unique_segment(rec, len(rec), 20, 200)
+        f, _ = ix.fixed_k_segment(rec[:100_000], 100_000, [36])
+        c = ix.count_from_sequence(rec, [0, 77, 50_000], [30, 12, 400])
+        n, _ = ix.min_unique_segment(rec, len(rec), 20, 200, use_revcomp=False)
+        ix.set_force_big(True)
+        for kernel in (1, 2):
+            ix.set_kernel(kernel)
+            b, amb_b = ix.min_unique_segment(rec, len(rec), 20, 200)
+            assert np.array_equal(a, b) and amb == amb_b
+        assert np.array_equal(f, ix.fixed_k_segment(rec[:100_000], 100_000, [36])[0])
+        assert np.array_equal(c, ix.count_from_sequence(rec, [0, 77, 50_000], [30, 12, 400]))
+        assert np.array_equal(n, ix.min_unique_segment(rec, len(rec), 20, 200, use_revcomp=False)[0])

@@ -12,6 +12,9 @@ from newmap_amd._c_newmap_generate_index import generate_fm_index
 from oracle import ref_driver as rd
 from tests.hostsim import HostSim
 
+from pathlib import Path as _P
+ROOT_DIR = _P(__file__).resolve().parent.parent
+
 
 def _write(tmp_path, text: bytes, name="in.fa"):
     p = tmp_path / name
@@ -138,3 +141,33 @@ def test_kmer_not_found_is_reported(tmp_path):
     sim = HostSim(idx, 0)
     got, status, code = sim.min_unique(b"GGGGGGGGGGGGGGGGGGGG", 20, 4, 8)
     assert code == 8 and int(status[1]) == 1 and int(status[2]) == 0
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "8"])
+def test_parallel_suffix_sort_equals_sais(tmp_path, threads):
+    """the two suffix sorters of the host builder (serial SA-IS, parallel prefix doubling) must write
+    byte-identical index files, whatever the thread count"""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(321)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    parts = [bytes(alpha[rng.integers(0, 4, 120_000)])]
+    unit = bytes(alpha[rng.integers(0, 4, 5)])
+    parts.append(unit * 9000)                               # 45 kb tandem array
+    parts.append(b"A" * 30_000)                             # homopolymer: deepest doubling
+    parts.append(b"N" * 100 + parts[0][1000:21_000])        # long exact duplicate
+    parts.append(bytes(alpha[rng.integers(0, 4, 50_000)]))
+    text = b">a\n" + b"".join(parts[:3]) + b"\n>b\n" + b"".join(parts[3:]) + b"\n>c\nACGT\n"
+    fa = tmp_path / "p.fa"
+    fa.write_bytes(text)
+    out = {}
+    for algo in ("sais", "pd"):
+        idx = tmp_path / f"{algo}.awfmi"
+        env = dict(os.environ, NEWMAP_AMD_SA=algo, OMP_NUM_THREADS=threads if algo == "pd" else "1")
+        code = ("import sys; sys.path.insert(0, %r); "
+                "from newmap_amd._c_newmap_generate_index import generate_fm_index; "
+                "generate_fm_index(%r, %r, 8, 12)") % (str(ROOT_DIR), str(fa), str(idx))
+        subprocess.run([sys.executable, "-c", code], check=True, env=env)
+        out[algo] = idx.read_bytes()
+    assert out["sais"] == out["pd"]

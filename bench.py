@@ -32,8 +32,15 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-KMIN, KMAX = 20, 200
 BATCH = 10_000_000
+# BASELINE.json configs: name -> (search range, description); configs[1] = c2 is the bench workload,
+# the others are parity / capability cases that the same harness can run on request
+CONFIGS = {
+    "c2": ((20, 200), "configs[1]: synthetic {mbp:g} Mbp single-record FASTA (uniform ACGT, seed 20260515)"),
+    "c3": ((24, 150), "configs[2]: synthetic {mbp:g} Mbp FASTA as 24 human-shaped records (uniform ACGT, seeds 20260516+i)"),
+    "c5": ((20, 255), "configs[4]: synthetic {mbp:g} Mbp, 50 % tandem repeats (seed 20260517)"),
+}
+DEFAULT_MBP = {"c2": 100.0, "c3": 3088.3, "c5": 1000.0}
 
 
 def log(*a):
@@ -45,24 +52,31 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mbp", type=float, default=100.0, help="genome size (default: configs[1], 100 Mbp)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json workload (default c2 = configs[1])")
+    ap.add_argument("--mbp", type=float, default=None, help="genome size in Mbp (default: the config's own size)")
     ap.add_argument("--seed-length", default="auto",
                     help="device seed table length: auto (default, ceil(log4 n)+1), file (the index's, 12), or 0..16")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--workdir", default=os.environ.get("NEWMAP_AMD_BENCH_DIR", "/tmp/newmap_amd_bench"))
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.mbp is None:
+        args.mbp = DEFAULT_MBP[args.config]
+    return args
 
 
 def prepare_workload(args, rank, world, barrier):
     """rank 0 generates the FASTA and builds the index; everybody then opens the same file"""
     from newmap_amd import synth
     from newmap_amd._c_newmap_generate_index import generate_fm_index
-    wd = Path(args.workdir) / f"c2_{args.mbp:g}mbp"
+    wd = Path(args.workdir) / f"{args.config}_{args.mbp:g}mbp"
     fa, idx = wd / "genome.fa", wd / "genome.awfmi"
     t_gen = t_build = 0.0
-    recs = synth.config_genome("c2", args.mbp)
+    t0 = time.time()
+    recs = synth.config_genome(args.config, None if args.mbp == DEFAULT_MBP[args.config] and args.config != "c2" else args.mbp)
+    if rank == 0:
+        log(f"[bench] generated {len(recs)} record(s), {sum(r.size for _, r in recs)} bases ({time.time() - t0:.1f}s)")
     if rank == 0:
         wd.mkdir(parents=True, exist_ok=True)
         if not (fa.exists() and idx.exists() and (wd / "ok").exists()):
@@ -75,28 +89,35 @@ def prepare_workload(args, rank, world, barrier):
             (wd / "ok").write_text("ok")
             log(f"[bench] wrote {fa} ({t_gen:.1f}s), built index ({t_build:.1f}s, {idx.stat().st_size / 1e6:.0f} MB)")
     barrier()
-    return recs[0][1], fa, idx, t_build
+    return recs, fa, idx, t_build
 
 
-def position_slices(n_positions, world, batch, kmax, seq_len):
-    """contiguous slice per rank, cut into reference-shaped segments (batch positions + kmax-1
-    lookahead; the last segment of the record runs to its end = epilogue)"""
-    per = -(-n_positions // world)
-    out = []
-    for r in range(world):
-        lo, hi = min(r * per, n_positions), min((r + 1) * per, n_positions)
-        segs = []
-        p = lo
-        while p < hi:
-            nk = min(batch, hi - p)
-            end = min(p + nk + kmax - 1, seq_len)
-            segs.append((p, end - p, nk))
-            p += nk
-        out.append((lo, hi, segs))
-    return out
+def verify_sample(ix, recs, rec_off, d_out, KMIN, KMAX, samples=20000):
+    """No oracle fits a multi-Gbp genome: re-derive a sample of the outputs through the count seam --
+    at the reported length the both-strand count is 1, one base shorter (if allowed) it is not."""
+    rng = np.random.default_rng(7)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    checked = 0
+    for (name, r), o in zip(recs[:3], rec_off[:-1]):
+        m = min(r.size, 50_000_000)
+        rec = r[:m].tobytes()
+        out = d_out[int(o):int(o) + m].cpu().numpy()
+        pos = rng.integers(0, max(m - KMAX, 1), samples)
+        k = out[pos].astype(np.int64)
+        ok = k > 0
+        pos, k = pos[ok], k[ok]
+        rc = rec.translate(comp)[::-1]
+        tot = ix.count_from_sequence(rec, pos, k) + ix.count_from_sequence(rc, m - pos - k, k)
+        assert (tot == 1).all(), f"{name}: reported length is not unique"
+        longer = k > KMIN
+        tot2 = ix.count_from_sequence(rec, pos[longer], k[longer] - 1) + \
+            ix.count_from_sequence(rc, m - pos[longer] - (k[longer] - 1), k[longer] - 1)
+        assert (tot2 > 1).all(), f"{name}: a shorter unique length exists"
+        checked += int(pos.size)
+    return {"sampled_positions": checked, "property": "count(k)==1 and count(k-1)>1 via nm_count_from_sequence"}
 
 
-def cpu_baseline(args, genome: np.ndarray, gpu_out: np.ndarray):
+def cpu_baseline(args, genome: np.ndarray, gpu_out: np.ndarray, KMIN: int, KMAX: int):
     """The oracle's C/OpenMP port of the reference algorithm (forward-strand FM-index, restart per
     probe, forward + reverse-complement queries, 4^12 seed table) on a bounded sample."""
     from oracle import ref_driver as rd
@@ -123,7 +144,7 @@ def cpu_baseline(args, genome: np.ndarray, gpu_out: np.ndarray):
     if not same:
         raise SystemExit("GPU output differs from the CPU oracle on the baseline sample")
     return {"value": sample / dt, "unit": "positions/s", "cores": threads, "kind": "port",
-            "sample": f"first {sample} positions of the same 100 Mbp workload, 20:200, "
+            "sample": f"first {sample} positions of the same workload, {KMIN}:{KMAX}, "
                       f"{stats['probes'] / sample:.1f} probes and {2 * stats['probe_len'] / sample:.0f} LF steps "
                       "per position (reference schedule), index build excluded"}
 
@@ -152,8 +173,12 @@ def main():
         if world > 1:
             dist.barrier()
 
-    genome, fa, idx_path, t_build = prepare_workload(args, rank, world, barrier)
-    n = int(genome.size)
+    from newmap_amd import parallel
+    (KMIN, KMAX), desc = CONFIGS[args.config]
+    recs, fa, idx_path, t_build = prepare_workload(args, rank, world, barrier)
+    lengths = [int(r.size) for _, r in recs]
+    rec_off = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
+    n = int(rec_off[-1])
     t0 = time.time()
     ix = Index(idx_path, local_rank, args.seed_length if args.seed_length in ("auto", "file") else int(args.seed_length))
     t_open = time.time() - t0
@@ -161,11 +186,17 @@ def main():
     if rank == 0:
         log(f"[bench] index open + upload + seed table: {t_open:.1f}s; {info}")
 
-    d_seq = torch.from_numpy(genome).to(dev)       # sequence resident in HBM before timing
+    # sequence bytes resident in HBM before timing (records laid end to end)
+    d_seq = torch.empty(n, dtype=torch.uint8, device=dev)
+    for (_, r), o in zip(recs, rec_off[:-1]):
+        d_seq[int(o):int(o) + r.size].copy_(torch.from_numpy(r))
     d_out = torch.zeros(n, dtype=torch.uint8, device=dev)
     d_status = torch.zeros(8, dtype=torch.int64, device=dev)
-    slices = position_slices(n, world, args.batch, KMAX, n)
-    lo, hi, segs = slices[rank]
+    # the same plan as newmap_amd.parallel: contiguous slice of the global position space per rank,
+    # cut into reference-shaped units (<= batch positions + kmax-1 bytes of lookahead from the record)
+    lo, hi = parallel.shard_bounds(n, world)[rank]
+    units = parallel.units_for_slice(lengths, lo, hi, args.batch, KMAX)
+    segs = [(int(rec_off[u.record]) + u.start, u.seg_len, u.count) for u in units]
     per = -(-n // world)
     gather_buf = torch.empty(per * world, dtype=torch.uint8, device=dev) if world > 1 and rank == 0 else None
     pad_out = torch.zeros(per, dtype=torch.uint8, device=dev) if world > 1 else None
@@ -223,15 +254,15 @@ def main():
         avg_launch_ms = kern_ms / max(n_launch, 1)
         achieved = per_launch_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         result = {
-            "metric": "genome positions/sec (min-unique-k search, 20:200)",
+            "metric": f"genome positions/sec (min-unique-k search, {KMIN}:{KMAX})",
             "value": n * args.steps / elapsed,
             "unit": "positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"configs[1]: synthetic {args.mbp:g} Mbp single-record FASTA (uniform ACGT, seed 20260515), "
-                                   f"search-range {KMIN}:{KMAX}, both strands",
+            "config": {"workload": desc.format(mbp=n / 1e6) + f", search-range {KMIN}:{KMAX}, both strands",
+                       "records": len(recs),
                        "positions": n, "batch": args.batch, "segments_per_rank": len(segs),
                        "seed_length": info["seed_length"], "index_bytes_hbm": info["device_bytes"],
                        "parallelism": f"positions sharded over {world} GPU(s), index replicated"},
@@ -244,9 +275,11 @@ def main():
                          "seed_lookups_per_position": float(tallies[5] / max(tallies[7], 1))},
             "host": {"index_build_s": t_build, "index_open_s": t_open},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            gpu_out = d_out.cpu().numpy()
-            result["cpu_baseline"] = cpu_baseline(args, genome, gpu_out)
+        if world == 1 and not args.no_cpu_baseline and lengths[0] < 2_000_000_000 and len(recs) == 1:
+            gpu_out = d_out[:lengths[0]].cpu().numpy()
+            result["cpu_baseline"] = cpu_baseline(args, recs[0][1], gpu_out, KMIN, KMAX)
+        if rank == 0 and args.config != "c2":
+            result["verify"] = verify_sample(ix, recs, rec_off, d_out, KMIN, KMAX)
         print(json.dumps(result), flush=True)
     barrier()
     ix.close()

@@ -117,7 +117,8 @@ int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, ui
 enum {
     NM_OPT_COUNT_STEPS = 1,
     NM_OPT_TIMING = 3,
-    NM_OPT_KERNEL = 4,             /* 2 (default): persistent-lane range kernel; 1: one lane per position */
+    NM_OPT_KERNEL = 4,             /* range-mode kernel: 1 one lane per position, 2 persistent lanes,
+                                      3 several positions per lane (scalar window loads, batched seeds) */
     NM_OPT_PERSISTENT_BLOCKS = 5,  /* grid size of the persistent kernel (default 8 x CUs) */
     NM_OPT_FORCE_BIG = 6           /* tests: use the kernels for indexes beyond 2^31 positions */
 };

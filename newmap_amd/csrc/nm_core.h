@@ -161,25 +161,13 @@ NM_HD bool nm_all_valid(const nm_enc_word *enc, uint64_t p, nm_window &w, uint32
     return true;
 }
 
-// One position of range mode.  Returns the element to store (0 = nothing unique in range).
+// Range mode, second half: from an interval [lo, hi) that spells the first k bases of the k-mer at
+// p (k = 0: the whole suffix array), extend base by base until the interval has one element.
+// `w` holds sequence positions [p + kbase, p + kbase + 64).  Returns the element to store.
 template <bool BIG, bool RC>
-NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint64_t p,
-                                 uint32_t kmin, uint32_t kmax, bool &amb0, bool &err, nm_tally &t) {
-    nm_window w = nm_load_window(enc, p);
-    uint32_t kbase = 0;
-    amb0 = (w.amb & 1ULL) != 0;
-    err = false;
-    if (amb0) return 0;                                   // search.py:399 mask -> finished, 0
-    uint64_t lo = 0, hi = ix.n;
-    uint32_t k = 0;
-    const uint32_t s = ix.seed_len;
-    if (s && kmin >= s) {
-        if (w.amb & ((1ULL << s) - 1ULL)) return 0;       // U_p < s <= kmin  (search.py:437)
-        const uint64_t e = ix.seed[nm_seed_slot(w, s)];
-        t.seeds++;
-        const uint32_t c = (uint32_t)(e >> NM_SEED_LO_BITS);
-        if (c != NM_SEED_CNT_SAT) { lo = e & NM_SEED_LO_MASK; hi = lo + c; k = s; }
-    }
+NM_HD uint32_t nm_min_unique_walk(const nm_view &ix, const nm_enc_word *enc, uint64_t p, nm_window w,
+                                  uint32_t kbase, uint64_t lo, uint64_t hi, uint32_t k, uint32_t kmin,
+                                  uint32_t kmax, bool &err, nm_tally &t) {
     for (;;) {
         const uint64_t cnt = hi - lo;
         if (cnt == 0) { err = true; return 0; }           // search.py:699-722
@@ -212,6 +200,43 @@ NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint
     const uint32_t ans = k > kmin ? k : kmin;             // k <= kmax here, kmin <= kmax
     if (!nm_all_valid(enc, p, w, kbase, k, ans)) return 0;   // ans must not exceed U_p
     return ans;
+}
+
+// Range mode, first half: what the window alone decides.  Returns true when the position is
+// settled without touching the index (result 0): its own byte is ambiguous (amb0), or an ambiguous
+// byte sits inside the first s <= kmin bases (U_p < kmin, search.py:437).
+NM_HD bool nm_min_unique_settled(const nm_window &w, uint32_t s, bool use_seed, bool &amb0) {
+    amb0 = (w.amb & 1ULL) != 0;
+    if (amb0) return true;                                // search.py:399 mask -> finished, 0
+    return use_seed && (w.amb & ((1ULL << s) - 1ULL)) != 0;
+}
+
+// decode a seed entry into the interval of the first s bases; false = saturated entry (walk from 0)
+NM_HD bool nm_seed_decode(uint64_t e, uint64_t &lo, uint64_t &hi) {
+    const uint32_t c = (uint32_t)(e >> NM_SEED_LO_BITS);
+    if (c == NM_SEED_CNT_SAT) return false;
+    lo = e & NM_SEED_LO_MASK;
+    hi = lo + c;
+    return true;
+}
+
+// One position of range mode.  Returns the element to store (0 = nothing unique in range).
+template <bool BIG, bool RC>
+NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint64_t p,
+                                 uint32_t kmin, uint32_t kmax, bool &amb0, bool &err, nm_tally &t) {
+    const nm_window w = nm_load_window(enc, p);
+    err = false;
+    const uint32_t s = ix.seed_len;
+    const bool use_seed = s && kmin >= s;
+    if (nm_min_unique_settled(w, s, use_seed, amb0)) return 0;
+    uint64_t lo = 0, hi = ix.n;
+    uint32_t k = 0;
+    if (use_seed) {
+        t.seeds++;
+        if (nm_seed_decode(ix.seed[nm_seed_slot(w, s)], lo, hi)) k = s;
+        else { lo = 0; hi = ix.n; }
+    }
+    return nm_min_unique_walk<BIG, RC>(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);
 }
 
 // One position of list mode.

@@ -110,6 +110,92 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique(nm_view ix, const nm_en
 }
 
 
+// ---- k_min_unique_mp: NM_MP positions per lane --------------------------------------------------
+// Same arithmetic as k_min_unique.  Two changes in how the work is laid out on a wave:
+//   * a wave owns 64*NM_MP consecutive positions, so the encoded words its windows are cut from are
+//     wave-uniform: NM_MP+1 scalar 32-byte loads replace 4 vector loads per lane and position;
+//   * a lane first issues the seed-table lookups of all its NM_MP positions (independent HBM
+//     gathers in flight together) and only then consumes them, walking further where needed.
+#define NM_MP 4
+
+template <bool BIG, bool RC, bool STATS>
+__global__ __launch_bounds__(NM_BLOCK) void k_min_unique_mp(nm_view ix, const nm_enc_word *__restrict__ enc,
+                                                            uint64_t n_enc_words, uint64_t num_kmers,
+                                                            uint32_t kmin, uint32_t kmax, void *__restrict__ out,
+                                                            int elem_bytes, uint64_t *__restrict__ status) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * (64ull * NM_MP);
+    if (wave_base >= num_kmers) return;                                  // whole wave out of range
+    const uint32_t s = ix.seed_len;
+    const bool use_seed = s && kmin >= s;
+
+    // wave-uniform words (scalar loads); indexes beyond the array are clamped to the all-ambiguous pad
+    nm_enc_word W[NM_MP + 1];
+    const uint64_t w0 = wave_base >> 6;
+#pragma unroll
+    for (int j = 0; j <= NM_MP; j++) {
+        uint64_t wi = w0 + j;
+        if (wi >= n_enc_words) wi = n_enc_words - 1;
+        W[j] = enc[wi];
+    }
+    nm_window win[NM_MP];
+    uint64_t e[NM_MP];
+    bool amb0[NM_MP], settled[NM_MP];
+    uint32_t n_amb = 0, n_searched = 0;
+    nm_tally t = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NM_MP; j++) {
+        const uint64_t p = wave_base + 64ull * j + lane;
+        win[j] = nm_window_from(W[j], W[j + 1], lane);
+        settled[j] = nm_min_unique_settled(win[j], s, use_seed, amb0[j]);
+        if (p >= num_kmers) { settled[j] = true; amb0[j] = false; }
+        e[j] = 0;
+        if (!settled[j] && use_seed) e[j] = ix.seed[nm_seed_slot(win[j], s)];   // NM_MP gathers in flight
+    }
+    bool any_err = false;
+    uint64_t err_pos = ~0ULL;
+#pragma unroll
+    for (int j = 0; j < NM_MP; j++) {
+        const uint64_t p = wave_base + 64ull * j + lane;
+        if (p >= num_kmers) continue;
+        uint32_t r = 0;
+        if (amb0[j]) n_amb++;
+        if (!settled[j]) {
+            uint64_t lo = 0, hi = ix.n;
+            uint32_t k = 0;
+            if (use_seed) {
+                if (STATS) t.seeds++;
+                if (nm_seed_decode(e[j], lo, hi)) k = s;
+                else { lo = 0; hi = ix.n; }
+            }
+            bool err = false;
+            r = nm_min_unique_walk<BIG, RC>(ix, enc, p, win[j], 0, lo, hi, k, kmin, kmax, err, t);
+            if (err) { any_err = true; if (p < err_pos) err_pos = p; }
+        }
+        if (STATS && !amb0[j]) n_searched++;
+        nm_store(out, elem_bytes, p, r);
+    }
+    // wave totals
+    const uint32_t amb_sum = wave_sum(n_amb);
+    if (lane == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
+    if (__ballot(any_err)) {
+        if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
+        if (lane == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
+    }
+    if (STATS) {
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), c = wave_sum(t.seeds),
+                       d = wave_sum(t.strands), f = wave_sum(n_searched);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)d);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)f);
+        }
+    }
+}
+
 // ---- k_min_unique_v2: persistent waves, one lane = one position AT A TIME --------------------
 // Same arithmetic as k_min_unique (nm_min_unique_one), different schedule.  In the simple kernel a
 // wave runs as long as its slowest lane: with ~3 LF steps on average but a long tail, most lanes
@@ -573,7 +659,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_KERNEL) {
-        if (value != 1 && value != 2) { nm_set_error("kernel version must be 1 or 2"); return NM_E_ARGUMENT; }
+        if (value < 1 || value > 3) { nm_set_error("kernel version must be 1, 2 or 3"); return NM_E_ARGUMENT; }
         ix->kernel_version = (int)value;
         return NM_OK;
     }
@@ -645,6 +731,13 @@ static void launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_km
         unsigned long long *work = (unsigned long long *)ix->work.p;
         if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_v2<BIG, true>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
         else                 hipLaunchKernelGGL((k_min_unique_v2<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
+        return;
+    }
+    if (ix->kernel_version == 3) {
+        const uint64_t per_block = (uint64_t)NM_BLOCK * NM_MP;
+        const dim3 mgrid((unsigned)((num_kmers + per_block - 1) / per_block));
+        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_mp<BIG, RC, true>), mgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
+        else                 hipLaunchKernelGGL((k_min_unique_mp<BIG, RC, false>), mgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
         return;
     }
     const dim3 grid(nm_grid(num_kmers));

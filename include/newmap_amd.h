@@ -120,7 +120,8 @@ enum {
     NM_OPT_KERNEL = 4,             /* range-mode kernel: 1 one lane per position, 2 persistent lanes,
                                       3 several positions per lane (scalar window loads, batched seeds) */
     NM_OPT_PERSISTENT_BLOCKS = 5,  /* grid size of the persistent kernel (default 8 x CUs) */
-    NM_OPT_FORCE_BIG = 6           /* tests: use the kernels for indexes beyond 2^31 positions */
+    NM_OPT_FORCE_BIG = 6,          /* tests: use the kernels for indexes beyond 2^31 positions */
+    NM_OPT_SEED_POLICY = 7         /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 

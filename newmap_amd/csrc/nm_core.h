@@ -47,6 +47,8 @@ struct nm_view {                // the index as the kernels see it
     uint64_t C[4];              // == superC[0][*]
     uint32_t seed_len;
     uint32_t n_super;
+    uint32_t seed_policy;       // experiment knob: cache policy of the seed-table load (0 = default)
+    uint32_t pad_;
 };
 
 struct nm_tally {               // counter build only
@@ -211,6 +213,11 @@ NM_HD bool nm_min_unique_settled(const nm_window &w, uint32_t s, bool use_seed, 
     return use_seed && (w.amb & ((1ULL << s) - 1ULL)) != 0;
 }
 
+// the seed-table gather; NM_SEED_LOAD may be overridden by the device build to try cache policies
+#ifndef NM_SEED_LOAD
+#define NM_SEED_LOAD(ix, slot) ((ix).seed[(slot)])
+#endif
+
 // decode a seed entry into the interval of the first s bases; false = saturated entry (walk from 0)
 NM_HD bool nm_seed_decode(uint64_t e, uint64_t &lo, uint64_t &hi) {
     const uint32_t c = (uint32_t)(e >> NM_SEED_LO_BITS);
@@ -233,7 +240,7 @@ NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint
     uint32_t k = 0;
     if (use_seed) {
         t.seeds++;
-        if (nm_seed_decode(ix.seed[nm_seed_slot(w, s)], lo, hi)) k = s;
+        if (nm_seed_decode(NM_SEED_LOAD(ix, nm_seed_slot(w, s)), lo, hi)) k = s;
         else { lo = 0; hi = ix.n; }
     }
     return nm_min_unique_walk<BIG, RC>(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);

@@ -22,7 +22,18 @@
 #include "nm_internal.h"
 
 #define NM_HD __device__ __forceinline__
+struct nm_view;
+static __device__ __forceinline__ uint64_t nm_seed_load_policy(const nm_view &ix, uint64_t slot);
+#define NM_SEED_LOAD(ix, slot) nm_seed_load_policy((ix), (slot))
 #include "nm_core.h"
+
+// seed-table gather under a selectable cache policy (NM_OPT_SEED_POLICY; measurement knob)
+static __device__ __forceinline__ uint64_t nm_seed_load_policy(const nm_view &ix, uint64_t slot) {
+    const uint64_t *p = ix.seed + slot;
+    if (ix.seed_policy == 1) return __builtin_nontemporal_load(p);
+    if (ix.seed_policy == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
 
 #define NM_WAVE 64
 #define NM_BLOCK 256
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_mp(nm_view ix, const nm
         settled[j] = nm_min_unique_settled(win[j], s, use_seed, amb0[j]);
         if (p >= num_kmers) { settled[j] = true; amb0[j] = false; }
         e[j] = 0;
-        if (!settled[j] && use_seed) e[j] = ix.seed[nm_seed_slot(win[j], s)];   // NM_MP gathers in flight
+        if (!settled[j] && use_seed) e[j] = NM_SEED_LOAD(ix, nm_seed_slot(win[j], s));   // NM_MP gathers in flight
     }
     bool any_err = false;
     uint64_t err_pos = ~0ULL;
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_v2(nm_view ix, const nm
         nm_blk ba = {0, 0, 0, 0, 0, 0}, bb = {0, 0, 0, 0, 0, 0};
         uint64_t e = 0;
         if (state == NM_STEP) { ba = nm_load_blk(ix, lo); bb = nm_load_blk(ix, hi); }
-        else if (state == NM_SEED) e = ix.seed[slot];
+        else if (state == NM_SEED) e = NM_SEED_LOAD(ix, slot);
         // ---- consume it
         if (state == NM_SEED) {
             const uint32_t c = (uint32_t)(e >> NM_SEED_LO_BITS);
@@ -604,6 +615,8 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
     v.seed_len = 0;
     v.n_super = (uint32_t)h.n_super;
+    v.seed_policy = 0;
+    v.pad_ = 0;
 
     uint32_t s = seed_len_override == -1 ? h.seed_len
                : (seed_len_override < -1 ? nm_auto_seed_len(ix) : (uint32_t)seed_len_override);
@@ -654,6 +667,11 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
     if (option == NM_OPT_COUNT_STEPS) { ix->count_steps = value != 0; return NM_OK; }
     if (option == NM_OPT_TIMING) { ix->timing = value != 0; ix->ev_used = 0; return NM_OK; }
+    if (option == NM_OPT_SEED_POLICY) {
+        if (value < 0 || value > 2) { nm_set_error("seed policy must be 0, 1 or 2"); return NM_E_ARGUMENT; }
+        ix->view.seed_policy = (uint32_t)value;
+        return NM_OK;
+    }
     if (option == NM_OPT_FORCE_BIG) {      // tests: run the >2^31-position code path on a small index
         ix->big = value != 0 || ix->h.n_super > 1;
         return NM_OK;

@@ -53,8 +53,11 @@ class Index:
         _lib.raise_for(rc)
         self._h = h
         self._lock = threading.Lock()
-        if os.environ.get("NEWMAP_AMD_KERNEL"):            # A/B measurements: 1 = simple, 2 = persistent
+        if os.environ.get("NEWMAP_AMD_KERNEL"):            # A/B measurements, see set_kernel
             self.set_kernel(int(os.environ["NEWMAP_AMD_KERNEL"]))
+        if os.environ.get("NEWMAP_AMD_SEED_POLICY"):
+            _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SEED_POLICY,
+                                                 int(os.environ["NEWMAP_AMD_SEED_POLICY"])))
 
     # lifetime -----------------------------------------------------------------------------
     def close(self):
@@ -89,7 +92,7 @@ class Index:
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_COUNT_STEPS, int(bool(on))))
 
     def set_kernel(self, version: int):
-        """2 = persistent-lane kernel (default), 1 = one lane per position (A/B measurements)"""
+        """1 = one lane per position, 2 = persistent lanes, 3 = several positions per lane"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_KERNEL, int(version)))
 
     def set_persistent_blocks(self, blocks: int):

@@ -62,7 +62,7 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
     v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
     v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
-    v.seed_len = 0; v.n_super = (uint32_t)h.n_super;
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pad_ = 0;
     uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
     if (s > 12) s = 12;                     // keep the simulated table small
     if (s && h.n >= 2) {

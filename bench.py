@@ -264,11 +264,14 @@ def main():
             "config": {"workload": desc.format(mbp=n / 1e6) + f", search-range {KMIN}:{KMAX}, both strands",
                        "records": len(recs),
                        "positions": n, "batch": args.batch, "segments_per_rank": len(segs),
-                       "seed_length": info["seed_length"], "index_bytes_hbm": info["device_bytes"],
+                       "seed_length": info["seed_length"], "pair_core_length": info["pair_core_length"],
+                       "index_bytes_hbm": info["device_bytes"],
                        "parallelism": f"positions sharded over {world} GPU(s), index replicated"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_min_unique", "avg_launch_ms": avg_launch_ms, "launches": n_launch,
+                         "kernel": {1: "k_min_unique", 2: "k_min_unique_v2", 3: "k_min_unique_mp",
+                                    4: "k_min_unique_pair"}.get(ix.info()["last_range_kernel"], "?"),
+                         "avg_launch_ms": avg_launch_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "lf_steps_per_position": float(steps_pp),
                          "rank_blocks_per_position": float(tallies[4] / max(tallies[7], 1)),

@@ -67,7 +67,8 @@ int nm_index_open(const char *index_path, int device, int seed_len_override, nm_
 void nm_index_close(nm_index *ix);
 
 /* index facts: 0 n (BWT length), 1 forward text length, 2 separators, 3 records, 4 raw bases,
- * 5 seed length in use, 6 device bytes held, 7 sa_ratio recorded */
+ * 5 seed length in use, 6 device bytes held, 7 sa_ratio recorded, 8 range kernel used by the last
+ * launch (see NM_OPT_KERNEL), 9 core length of the pair table (0 = none) */
 uint64_t nm_index_info(const nm_index *ix, int what);
 
 /* ------------------------------------------------------------------------- compat seam ------
@@ -117,8 +118,9 @@ int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, ui
 enum {
     NM_OPT_COUNT_STEPS = 1,
     NM_OPT_TIMING = 3,
-    NM_OPT_KERNEL = 4,             /* range-mode kernel: 1 one lane per position, 2 persistent lanes,
-                                      3 several positions per lane (scalar window loads, batched seeds) */
+    NM_OPT_KERNEL = 4,             /* range-mode kernel: 0 automatic (default), 1 one lane per position,
+                                      2 persistent lanes, 3 several positions per lane, 4 position
+                                      pairs on the pair table (one 128-byte line per two positions) */
     NM_OPT_PERSISTENT_BLOCKS = 5,  /* grid size of the persistent kernel (default 8 x CUs) */
     NM_OPT_FORCE_BIG = 6,          /* tests: use the kernels for indexes beyond 2^31 positions */
     NM_OPT_SEED_POLICY = 7         /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */

@@ -48,7 +48,8 @@ struct nm_view {                // the index as the kernels see it
     uint32_t seed_len;
     uint32_t n_super;
     uint32_t seed_policy;       // experiment knob: cache policy of the seed-table load (0 = default)
-    uint32_t pad_;
+    uint32_t pair_m;            // core length of the pair table (0 = none)
+    const uint64_t *pair;       // 4^pair_m blocks of 8 entries: [a] interval of a.Y, [4+b] interval of Y.b
 };
 
 struct nm_tally {               // counter build only
@@ -336,6 +337,29 @@ NM_HD uint32_t nm_upper_one(const nm_enc_word *enc, uint64_t p, uint32_t kmax) {
         k += 64 - j;
     }
     return k < kmax ? k : kmax;
+}
+
+// pair-table entry: core Y = the m-mer spelled by `slot` (same bit layout as a seed slot);
+// e < 4: the (m+1)-mer e.Y, e >= 4: the (m+1)-mer Y.(e-4)
+template <bool BIG>
+NM_HD uint64_t nm_pair_entry(const nm_view &ix, uint64_t slot, uint32_t m, uint32_t e) {
+    uint64_t lo = 0, hi = ix.n;
+    if (e < 4) {
+        lo = nm_lf<BIG>(ix, 3u - e, lo);
+        hi = nm_lf<BIG>(ix, 3u - e, hi);
+    }
+    for (uint32_t j = 0; j < m && lo < hi; j++) {
+        const uint32_t c = 3u - nm_seed_slot_code(slot, m, j);
+        lo = nm_lf<BIG>(ix, c, lo);
+        hi = nm_lf<BIG>(ix, c, hi);
+    }
+    if (e >= 4 && lo < hi) {
+        lo = nm_lf<BIG>(ix, 3u - (e - 4), lo);
+        hi = nm_lf<BIG>(ix, 3u - (e - 4), hi);
+    }
+    uint64_t cnt = hi > lo ? hi - lo : 0;
+    if (cnt >= NM_SEED_CNT_SAT) cnt = NM_SEED_CNT_SAT;
+    return (lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS);
 }
 
 // seed-table entry of slot `slot`: interval of the reverse complement of the s-mer it spells

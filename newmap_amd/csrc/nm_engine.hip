@@ -207,6 +207,99 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_mp(nm_view ix, const nm
     }
 }
 
+// ---- k_min_unique_pair: one 128-byte line serves TWO positions ---------------------------------
+// Measured (profiles/round1): with a long seed table the range kernel is bound by HBM line fetches --
+// every L2 miss is a 128-byte read (TCC_EA0_RDREQ_128B), one per position for its 8-byte seed entry,
+// ~5.8 TB/s of real traffic whatever the kernel's structure.  The only lever left is fewer lines per
+// position.  Neighbouring positions p and p+1 share the m-mer core Y = S[p+1 .. p+1+m): their
+// (m+1)-mers are S[p].Y and Y.S[p+1+m].  The pair table stores, per core, the intervals of all four
+// a.Y and all four Y.b in one 64-byte block, so a lane that owns positions (2i, 2i+1) touches ONE line
+// for both seeds.
+template <bool BIG, bool STATS>
+__global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const nm_enc_word *__restrict__ enc,
+                                                              uint64_t n_enc_words, uint64_t num_kmers,
+                                                              uint32_t kmin, uint32_t kmax, void *__restrict__ out,
+                                                              int elem_bytes, uint64_t *__restrict__ status) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * 128ull;
+    if (wave_base >= num_kmers) return;
+    const uint32_t m = ix.pair_m, s = m + 1;
+    const uint64_t core_mask = (1ULL << m) - 1ULL;
+
+    nm_enc_word W[3];                                     // wave-uniform -> scalar loads
+    const uint64_t w0 = wave_base >> 6;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        uint64_t wi = w0 + j;
+        if (wi >= n_enc_words) wi = n_enc_words - 1;
+        W[j] = enc[wi];
+    }
+    const uint32_t q = 2 * lane;                          // offset of the even position in the wave's 128
+    const nm_enc_word &Wa = q < 64 ? W[0] : W[1];
+    const nm_enc_word &Wb = q < 64 ? W[1] : W[2];
+    const uint64_t p0 = wave_base + q, p1 = p0 + 1;
+    const nm_window win0 = nm_window_from(Wa, Wb, q & 63);
+    const nm_window win1 = nm_window_from(Wa, Wb, (q & 63) + 1);   // (q & 63) <= 62
+    const bool in0 = p0 < num_kmers, in1 = p1 < num_kmers;
+    const bool amb0 = (win0.amb & 1ULL) != 0, amb1 = (win0.amb & 2ULL) != 0;
+    const bool core_ok = ((win0.amb >> 1) & core_mask) == 0;
+    const bool go0 = in0 && !amb0 && core_ok;                                   // bases 0..m unambiguous
+    const bool go1 = in1 && core_ok && !((win0.amb >> s) & 1ULL);               // bases 1..m+1 unambiguous
+    const uint64_t slot = ((win0.lo >> 1) & core_mask) | (((win0.hi >> 1) & core_mask) << m);
+    const uint64_t *blk = ix.pair + slot * 8;
+    uint64_t e0 = 0, e1 = 0;
+    if (go0) e0 = blk[nm_window_code(win0, 0)];                                  // both in one 64-byte block
+    if (go1) e1 = blk[4 + nm_window_code(win0, s)];
+    nm_tally t = {0, 0, 0, 0};
+    bool any_err = false;
+    uint64_t err_pos = ~0ULL;
+    uint32_t r0 = 0, r1 = 0;
+    if (go0) {
+        uint64_t lo = 0, hi = ix.n;
+        uint32_t k = 0;
+        if (nm_seed_decode(e0, lo, hi)) k = s; else { lo = 0; hi = ix.n; }
+        bool err = false;
+        r0 = nm_min_unique_walk<BIG, true>(ix, enc, p0, win0, 0, lo, hi, k, kmin, kmax, err, t);
+        if (err) { any_err = true; err_pos = p0; }
+    }
+    if (go1) {
+        uint64_t lo = 0, hi = ix.n;
+        uint32_t k = 0;
+        if (nm_seed_decode(e1, lo, hi)) k = s; else { lo = 0; hi = ix.n; }
+        bool err = false;
+        r1 = nm_min_unique_walk<BIG, true>(ix, enc, p1, win1, 0, lo, hi, k, kmin, kmax, err, t);
+        if (err) { any_err = true; if (p1 < err_pos) err_pos = p1; }
+    }
+    if (in0) nm_store(out, elem_bytes, p0, r0);
+    if (in1) nm_store(out, elem_bytes, p1, r1);
+
+    const uint32_t amb_sum = wave_sum((uint32_t)(in0 && amb0) + (uint32_t)(in1 && amb1));
+    if (lane == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
+    if (__ballot(any_err)) {
+        if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
+        if (lane == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
+    }
+    if (STATS) {
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks),
+                       c = wave_sum((uint32_t)go0 + (uint32_t)go1),                 // 8-byte entries read
+                       f = wave_sum((uint32_t)(in0 && !amb0) + (uint32_t)(in1 && !amb1));
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)f);
+        }
+    }
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_pair(nm_view ix, uint64_t *__restrict__ table, uint64_t first,
+                                                   uint64_t n_entries, uint32_t m) {
+    const uint64_t i = first + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (i < n_entries) table[i] = nm_pair_entry<BIG>(ix, i >> 3, m, (uint32_t)(i & 7));
+}
+
 // ---- k_min_unique_v2: persistent waves, one lane = one position AT A TIME --------------------
 // Same arithmetic as k_min_unique (nm_min_unique_one), different schedule.  In the simple kernel a
 // wave runs as long as its slowest lane: with ~3 LF steps on average but a long tail, most lanes
@@ -419,14 +512,16 @@ struct nm_index {
     void *d_rank = nullptr, *d_strand = nullptr, *d_sep = nullptr, *d_seed = nullptr, *d_super = nullptr;
     void *d_seed2 = nullptr;              // small secondary seed table (nm_view_for)
     uint32_t seed2_len = 0;
+    void *d_pair = nullptr;               // pair table (k_min_unique_pair)
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
     nm_buffer enc, seq, out, status, ks, starts, lens, work;
     uint64_t enc_words = 0;               // words written by the last nm_encode
-    int kernel_version = 1;               // 1 = one lane per position (default, faster as measured), 2 = persistent lanes
+    int kernel_version = 0;               // 0 = automatic (pair kernel when its table exists, else 1); 1..4 force a kernel
     unsigned persistent_blocks = 2048;    // set from the device properties at open
     bool count_steps = false;
+    int last_kernel = 0;                  // which range kernel the last launch used (nm_index_info 8)
     // NM_OPT_TIMING: HIP events around every search-kernel launch, on the launch stream
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;      // start/stop pairs, reused
@@ -495,6 +590,30 @@ static uint32_t nm_auto_seed_len(const nm_index *ix) {
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
         while (s > 4 && (8ULL << (2 * s)) > free_b / 4) s--;   // never more than a quarter of free HBM
     return s;
+}
+
+// pair table for cores of m bases: 4^m blocks x 8 entries x 8 bytes
+static int nm_build_pair(nm_index *ix, uint32_t m) {
+    ix->view.pair = nullptr;
+    ix->view.pair_m = 0;
+    if (m < 3 || ix->h.n < 2) return NM_OK;
+    const uint64_t n_entries = 8ULL << (2 * m);
+    HIP_TRY(hipMalloc(&ix->d_pair, n_entries * sizeof(uint64_t)));
+    ix->device_bytes += n_entries * sizeof(uint64_t);
+    nm_view v = ix->view;
+    v.seed = nullptr;
+    v.seed_len = 0;
+    const uint64_t slice = 1ULL << 30;
+    for (uint64_t first = 0; first < n_entries; first += slice) {
+        const uint64_t cnt = n_entries - first < slice ? n_entries - first : slice;
+        if (ix->big) hipLaunchKernelGGL(k_pair<true>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_pair, first, n_entries, m);
+        else         hipLaunchKernelGGL(k_pair<false>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_pair, first, n_entries, m);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->view.pair = (const uint64_t *)ix->d_pair;
+    ix->view.pair_m = m;
+    return NM_OK;
 }
 
 static int nm_build_seed(nm_index *ix, uint32_t s) {
@@ -616,13 +735,24 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.seed_len = 0;
     v.n_super = (uint32_t)h.n_super;
     v.seed_policy = 0;
-    v.pad_ = 0;
+    v.pair_m = 0;
+    v.pair = nullptr;
 
     uint32_t s = seed_len_override == -1 ? h.seed_len
                : (seed_len_override < -1 ? nm_auto_seed_len(ix) : (uint32_t)seed_len_override);
     if (s > 16) s = 16;
     rc = nm_build_seed(ix, s);
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
+    if (seed_len_override < -1 && s >= 5) {
+        // automatic sizing also builds the pair table (cores of s-1 bases, same resolution as the
+        // seed table, twice its bytes) unless it would not fit a quarter of the free HBM
+        uint32_t m = s - 1 > 15 ? 15 : s - 1;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (m > 4 && (64ULL << (2 * m)) > free_b / 4) m--;
+        rc = nm_build_pair(ix, m);
+        if (rc != NM_OK) { nm_index_close(ix); return rc; }
+    }
     rc = nm_grow(ix->status, NM_STATUS_WORDS * sizeof(uint64_t));
     if (rc == NM_OK) rc = nm_grow(ix->work, sizeof(unsigned long long));
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
@@ -639,7 +769,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_super, ix->enc.p, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_super, ix->enc.p, ix->seq.p,
                     ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -659,6 +789,8 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 5: return ix->view.seed_len;
         case 6: return ix->device_bytes;
         case 7: return ix->h.sa_ratio;
+        case 8: return (uint64_t)ix->last_kernel;
+        case 9: return ix->view.pair_m;
         default: return 0;
     }
 }
@@ -677,7 +809,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_KERNEL) {
-        if (value < 1 || value > 3) { nm_set_error("kernel version must be 1, 2 or 3"); return NM_E_ARGUMENT; }
+        if (value < 0 || value > 4) { nm_set_error("kernel version must be 0..4"); return NM_E_ARGUMENT; }
         ix->kernel_version = (int)value;
         return NM_OK;
     }
@@ -741,6 +873,7 @@ static void launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_km
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
     nm_timed timed(ix, st);
     if (RC && ix->kernel_version == 2) {
+        ix->last_kernel = 2;
         // persistent grid: enough waves to fill the chip, never more than there are chunks
         const uint64_t chunks = (num_kmers + NM_CHUNK - 1) / NM_CHUNK;
         uint64_t blocks = (chunks + NM_BLOCK / NM_WAVE - 1) / (NM_BLOCK / NM_WAVE);
@@ -751,7 +884,16 @@ static void launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_km
         else                 hipLaunchKernelGGL((k_min_unique_v2<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
         return;
     }
+    if (RC && (ix->kernel_version == 4 || ix->kernel_version == 0) && view.pair && kmin >= view.pair_m + 1) {
+        const uint64_t per_block = (uint64_t)NM_BLOCK * 2;
+        const dim3 pgrid((unsigned)((num_kmers + per_block - 1) / per_block));
+        ix->last_kernel = 4;
+        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_pair<BIG, true>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
+        else                 hipLaunchKernelGGL((k_min_unique_pair<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
+        return;
+    }
     if (ix->kernel_version == 3) {
+        ix->last_kernel = 3;
         const uint64_t per_block = (uint64_t)NM_BLOCK * NM_MP;
         const dim3 mgrid((unsigned)((num_kmers + per_block - 1) / per_block));
         if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_mp<BIG, RC, true>), mgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
@@ -759,6 +901,7 @@ static void launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_km
         return;
     }
     const dim3 grid(nm_grid(num_kmers));
+    ix->last_kernel = 1;
     if (ix->count_steps) hipLaunchKernelGGL((k_min_unique<BIG, RC, true>), grid, block, 0, st, view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
     else                 hipLaunchKernelGGL((k_min_unique<BIG, RC, false>), grid, block, 0, st, view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
 }

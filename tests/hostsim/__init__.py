@@ -26,6 +26,8 @@ def lib():
     L.hs_open.restype = vp
     L.hs_open.argtypes = [ctypes.c_char_p, i32, i32]
     L.hs_close.argtypes = [vp]
+    L.hs_check_pair.restype = u64
+    L.hs_check_pair.argtypes = [vp, u32]
     L.hs_info.restype = u64
     L.hs_info.argtypes = [vp, i32]
     L.hs_min_unique.restype = i32
@@ -49,6 +51,9 @@ class HostSim:
         if getattr(self, "h", None):
             self.L.hs_close(self.h)
             self.h = None
+
+    def check_pair(self, m):
+        return int(self.L.hs_check_pair(self.h, m))
 
     def info(self, what):
         return int(self.L.hs_info(self.h, what))

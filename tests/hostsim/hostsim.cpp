@@ -62,7 +62,7 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
     v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
     v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
-    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pad_ = 0;
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pair_m = 0; v.pair = nullptr;
     uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
     if (s > 12) s = 12;                     // keep the simulated table small
     if (s && h.n >= 2) {
@@ -76,6 +76,27 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
 }
 
 void hs_close(hs_index *ix) { delete ix; }
+
+// pair-table entries must equal the plain seed entries of the (m+1)-mers they stand for
+uint64_t hs_check_pair(hs_index *ix, uint32_t m) {
+    const uint32_t s = m + 1;
+    const uint64_t mask = (1ULL << m) - 1;
+    uint64_t bad = 0;
+    for (uint64_t slot = 0; slot < (1ULL << (2 * m)); slot++) {
+        const uint64_t ylo = slot & mask, yhi = slot >> m;
+        for (uint32_t e = 0; e < 8; e++) {
+            uint64_t sl;
+            if (e < 4) sl = (uint64_t)(e & 1) | (ylo << 1) | ((uint64_t)(e >> 1) << s) | (yhi << (s + 1));
+            else { const uint32_t b = e - 4; sl = ylo | ((uint64_t)(b & 1) << m) | (yhi << s) | ((uint64_t)(b >> 1) << (s + m)); }
+            const uint64_t want = ix->big ? nm_seed_entry<true>(ix->v, sl, s) : nm_seed_entry<false>(ix->v, sl, s);
+            const uint64_t got = ix->big ? nm_pair_entry<true>(ix->v, slot, m, e) : nm_pair_entry<false>(ix->v, slot, m, e);
+            // an empty interval may sit anywhere: compare sizes, and starts only when non-empty
+            const uint64_t wc = want >> NM_SEED_LO_BITS, gc = got >> NM_SEED_LO_BITS;
+            if (wc != gc || (wc && want != got)) bad++;
+        }
+    }
+    return bad;
+}
 uint64_t hs_info(hs_index *ix, int what) {
     switch (what) { case 0: return ix->h.n; case 1: return ix->h.n_fwd; case 2: return ix->h.n_sep;
                     case 3: return ix->h.n_records; case 4: return ix->h.raw_bases; case 5: return ix->v.seed_len;

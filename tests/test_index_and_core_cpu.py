@@ -171,3 +171,19 @@ def test_parallel_suffix_sort_equals_sais(tmp_path, threads):
         subprocess.run([sys.executable, "-c", code], check=True, env=env)
         out[algo] = idx.read_bytes()
     assert out["sais"] == out["pd"]
+
+
+def test_pair_table_entries_equal_seed_entries(tmp_path):
+    """the pair table (k_min_unique_pair) stores, per m-mer core, the intervals of a.Y and Y.b: they must
+    be the plain seed entries of those (m+1)-mers"""
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    text = b">x\n" + bytes(alpha[rng.integers(0, 4, 6000)]) + b"NN" + b"ACGT" * 50 + b"\n>y\nAAAAAAAAAAAACCCCCCCCGGGGT\n"
+    fa = tmp_path / "p.fa"
+    fa.write_bytes(text)
+    idx = tmp_path / "p.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    for big in (False, True):
+        sim = HostSim(idx, 0, big)
+        for m in (3, 5):
+            assert sim.check_pair(m) == 0

@@ -745,11 +745,11 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     if (seed_len_override < -1 && s >= 5) {
         // automatic sizing also builds the pair table (cores of s-1 bases, same resolution as the
-        // seed table, twice its bytes) unless it would not fit a quarter of the free HBM
+        // seed table, twice its bytes) unless it would take more than 40 % of the free HBM
         uint32_t m = s - 1 > 15 ? 15 : s - 1;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (m > 4 && (64ULL << (2 * m)) > free_b / 4) m--;
+            while (m > 4 && (64ULL << (2 * m)) > free_b * 2 / 5) m--;   // at most 40 % of what is still free
         rc = nm_build_pair(ix, m);
         if (rc != NM_OK) { nm_index_close(ix); return rc; }
     }

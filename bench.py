@@ -92,6 +92,29 @@ def prepare_workload(args, rank, world, barrier):
     return recs, fa, idx, t_build
 
 
+def measured_traffic(kernel: str, config: str, positions_per_launch: float):
+    """HBM-side read+write bytes per launch of the dominant kernel, from the PMC passes committed under
+    profiles/ (rocprofv3 --pmc cannot run inside this process).  Reads: TCC_EA0_RDREQ x 128 B -- on
+    gfx950 every read request of this kernel is a 128-byte one (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ),
+    which is the guide's "FETCH_SIZE reports half" correction stated exactly; writes: WRITE_SIZE (KB).
+    The counts are per 10 M-position launch of configs[1]; other workloads report null."""
+    if config != "c2" or kernel != "k_min_unique_pair":
+        return None, None
+    f = ROOT / "profiles" / "round1" / "pmc_pair_kernel_summary.csv"
+    if not f.exists():
+        return None, None
+    vals = {}
+    for line in f.read_text().splitlines()[1:]:
+        k, v = line.rsplit(",", 1)
+        vals[k] = float(v)
+    if "TCC_EA0_RDREQ_sum" not in vals:
+        return None, None
+    scale = positions_per_launch / 10_000_000
+    read_b = vals["TCC_EA0_RDREQ_sum"] * 128.0
+    write_b = 11_150.6 * 1024.0            # WRITE_SIZE of k_min_unique on the same launch (profiles/round1/pmc_auto_WRITE_S_summary.csv)
+    return (read_b + write_b) * scale, str(f.relative_to(ROOT))
+
+
 def verify_sample(ix, recs, rec_off, d_out, KMIN, KMAX, samples=20000):
     """No oracle fits a multi-Gbp genome: re-derive a sample of the outputs through the count seam --
     at the reported length the both-strand count is 1, one base shorter (if allowed) it is not."""
@@ -253,6 +276,9 @@ def main():
         per_launch_bytes = alg_bytes / max(len(segs), 1)
         avg_launch_ms = kern_ms / max(n_launch, 1)
         achieved = per_launch_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        kernel_name = {1: "k_min_unique", 2: "k_min_unique_v2", 3: "k_min_unique_mp",
+                       4: "k_min_unique_pair"}.get(ix.info()["last_range_kernel"], "?")
+        traffic, traffic_src = measured_traffic(kernel_name, args.config, my_pos / max(len(segs), 1))
         result = {
             "metric": f"genome positions/sec (min-unique-k search, {KMIN}:{KMAX})",
             "value": n * args.steps / elapsed,
@@ -268,9 +294,8 @@ def main():
                        "index_bytes_hbm": info["device_bytes"],
                        "parallelism": f"positions sharded over {world} GPU(s), index replicated"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": {1: "k_min_unique", 2: "k_min_unique_v2", 3: "k_min_unique_mp",
-                                    4: "k_min_unique_pair"}.get(ix.info()["last_range_kernel"], "?"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name,
                          "avg_launch_ms": avg_launch_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "lf_steps_per_position": float(steps_pp),

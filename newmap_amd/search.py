@@ -245,4 +245,11 @@ def write_unique_counts(config: SearchConfig):
 
 
 def main(args):
-    write_unique_counts(SearchConfig.from_args(args))
+    import os
+    config = SearchConfig.from_args(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # launched one rank per GPU (python -m torch.distributed.run ... -m newmap_amd.main search ...)
+        from .parallel import write_unique_counts_distributed
+        write_unique_counts_distributed(config)
+    else:
+        write_unique_counts(config)

@@ -68,7 +68,7 @@ void nm_index_close(nm_index *ix);
 
 /* index facts: 0 n (BWT length), 1 forward text length, 2 separators, 3 records, 4 raw bases,
  * 5 seed length in use, 6 device bytes held, 7 sa_ratio recorded, 8 range kernel used by the last
- * launch (see NM_OPT_KERNEL), 9 core length of the pair table (0 = none) */
+ * launch (see NM_OPT_KERNEL), 9 core length of the pair table (0 = none), 10 device index */
 uint64_t nm_index_info(const nm_index *ix, int what);
 
 /* ------------------------------------------------------------------------- compat seam ------
@@ -131,6 +131,25 @@ int nm_set_option(nm_index *ix, int option, int64_t value);
  * encode pass) with HIP events recorded on the launch stream.  nm_timing_read waits for them,
  * returns their number, summed and longest duration in ms, and resets the record. */
 int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_ms, double *max_ms);
+
+/* --------------------------------------------------------------- native search driver --------
+ * The whole of newmap/search.py:197-380 `write_unique_counts` for one FASTA and one index in one
+ * call: streaming FASTA reader (plain or .gz; record and segment rules of newmap/fasta.py:20-190),
+ * pinned double buffers, H2D / fused kernels / D2H on one stream overlapped with parsing and with the
+ * file appends, one `<out_dir>/<id>.unique.uint8|16|32` per record id.  `ks`: the range kmin..kmax is
+ * given by its two ends when range_mode != 0, else the list of lengths in order.  include / exclude:
+ * record ids to keep / to skip (at most one of the two lists non-empty).  `cb` (may be NULL) is
+ * called once per output file, in file order, after the search; `total` receives the sums. */
+typedef struct nm_search_summary {
+    uint64_t records, positions, ambiguous, unique, no_unique;
+    uint32_t max_len, min_len;      /* search.py:242-243: start at kmin / kmax, updated by found lengths */
+} nm_search_summary;
+typedef void (*nm_record_callback)(const char *record_id, const nm_search_summary *s, void *user);
+int nm_search_fasta(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks,
+                    uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
+                    const char *const *include_ids, uint32_t n_include,
+                    const char *const *exclude_ids, uint32_t n_exclude,
+                    nm_record_callback cb, void *user, nm_search_summary *total);
 
 /* small device-memory helpers so a host program needs no other HIP binding */
 int nm_dev_alloc(int device, uint64_t bytes, void **out);

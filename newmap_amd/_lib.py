@@ -26,10 +26,19 @@ EXPORTS = [
     "nm_index_info", "nm_count_kmers", "nm_count_from_sequence", "nm_min_unique_segment",
     "nm_fixed_k_segment", "nm_upper_bound_segment", "nm_min_unique_segment_dev",
     "nm_fixed_k_segment_dev", "nm_set_option", "nm_dev_alloc", "nm_dev_free", "nm_dev_upload",
-    "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read",
+    "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read", "nm_search_fasta",
 ]
 
 _lib = None
+
+
+class SearchSummary(ctypes.Structure):
+    _fields_ = [("records", ctypes.c_uint64), ("positions", ctypes.c_uint64), ("ambiguous", ctypes.c_uint64),
+                ("unique", ctypes.c_uint64), ("no_unique", ctypes.c_uint64), ("max_len", ctypes.c_uint32),
+                ("min_len", ctypes.c_uint32)]
+
+
+RECORD_CALLBACK = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.POINTER(SearchSummary), ctypes.c_void_p)
 
 
 class EngineMissingError(ImportError):
@@ -117,6 +126,10 @@ def lib():
     L.nm_dev_sync.restype = i32
     L.nm_dev_sync.argtypes = [i32]
     L.nm_device_count.restype = i32
+    L.nm_search_fasta.restype = i32
+    L.nm_search_fasta.argtypes = [vp, c.c_char_p, c.c_char_p, vp, u32, i32, i32, u64,
+                                  c.POINTER(c.c_char_p), u32, c.POINTER(c.c_char_p), u32,
+                                  RECORD_CALLBACK, vp, c.POINTER(SearchSummary)]
     L.nm_timing_read.restype = i32
     L.nm_timing_read.argtypes = [vp, c.POINTER(u64), c.POINTER(c.c_double), c.POINTER(c.c_double)]
     _lib = L

@@ -791,6 +791,7 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 7: return ix->h.sa_ratio;
         case 8: return (uint64_t)ix->last_kernel;
         case 9: return ix->view.pair_m;
+        case 10: return (uint64_t)ix->device;
         default: return 0;
     }
 }

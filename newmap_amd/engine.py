@@ -192,6 +192,34 @@ class Index:
         _lib.raise_for(rc)
         return out[:num_kmers]
 
+    # native driver ------------------------------------------------------------------------------
+    def search_fasta(self, fasta_path, out_dir, kmer_lengths, is_range: bool, use_revcomp: bool = True,
+                     batch: int = 10_000_000, include=(), exclude=(), on_record=None):
+        """nm_search_fasta: FASTA in -> `<id>.unique.<dtype>` files out, natively.  `on_record(id: bytes,
+        summary: dict)` is called once per output file.  Returns the totals as a dict."""
+        ks = np.ascontiguousarray([min(kmer_lengths), max(kmer_lengths)] if is_range else list(kmer_lengths),
+                                  dtype=np.uint32)
+        fields = [f[0] for f in _lib.SearchSummary._fields_]
+
+        def _cb(rec_id, summary, _user):
+            if on_record is not None:
+                on_record(rec_id, {f: int(getattr(summary.contents, f)) for f in fields})
+
+        cb = _lib.RECORD_CALLBACK(_cb)
+        inc = (ctypes.c_char_p * max(len(include), 1))(*[bytes(x) for x in include])
+        exc = (ctypes.c_char_p * max(len(exclude), 1))(*[bytes(x) for x in exclude])
+        total = _lib.SearchSummary()
+        with self._lock:
+            rc = self._L.nm_search_fasta(self.handle, os.fsencode(fasta_path), os.fsencode(out_dir), ks.ctypes.data,
+                                         ks.size, int(bool(is_range)), int(bool(use_revcomp)), int(batch),
+                                         inc, len(include), exc, len(exclude), cb, None, ctypes.byref(total))
+        if rc == _lib.NM_E_ARGUMENT:
+            msg = _lib.last_error()
+            if "nothing was processed" in msg or "included sequences" in msg:
+                return {f: 0 for f in fields}             # the caller raises the reference's ValueError
+        _lib.raise_for(rc)
+        return {f: int(getattr(total, f)) for f in fields}
+
     # device-resident variants (bench, multi-GPU driver) ---------------------------------------
     def min_unique_segment_dev(self, d_seq: int, seq_len: int, num_kmers: int, kmin: int, kmax: int,
                                use_revcomp: bool, elem_bytes: int, d_out: int, d_status: int, stream: int = 0):

@@ -187,10 +187,18 @@ def _wanted(config: SearchConfig, sequence_id: bytes) -> bool:
 
 
 def write_unique_counts(config: SearchConfig):
-    """newmap/search.py:197-380: one `<id>.unique.<dtype>` file per FASTA record."""
-    max_kmer_length = max(config.kmer_lengths)
-    min_kmer_length = min(config.kmer_lengths)
-    data_type, suffix = output_type(max_kmer_length)
+    """newmap/search.py:197-380: one `<id>.unique.<dtype>` file per FASTA record.
+
+    Runs the native driver (csrc/nm_driver.hip: streaming FASTA reader, pinned double buffers, copies and
+    kernels overlapped with parsing and file appends); NEWMAP_AMD_PYTHON_DRIVER=1 selects the
+    segment-by-segment Python loop below, which produces the same files."""
+    import os
+    if os.environ.get("NEWMAP_AMD_PYTHON_DRIVER", "") != "1":
+        return _write_unique_counts_native(config)
+    return _write_unique_counts_python(config)
+
+
+def _check_range(config: SearchConfig, min_kmer_length: int, max_kmer_length: int):
     if config.is_binary_search:
         # NB: the reference evaluates log2(kmax - kmin) here and so rejects a:a ranges with
         # "math domain error" (newmap/search.py:215-217); same exception, clearer message.
@@ -200,6 +208,46 @@ def write_unique_counts(config: SearchConfig):
             ceil(log2(max_kmer_length - min_kmer_length) + 1), min_kmer_length, max_kmer_length))
     if len(config.fasta_filepaths) != 1:
         _first_segment([None] * len(config.fasta_filepaths))
+
+
+def _nothing_processed(config: SearchConfig):
+    if config.include_sequence_ids:                                   # newmap/search.py:368-380
+        raise ValueError(f"None of the included sequences were found: {config.include_sequence_ids}")
+    if config.exclude_sequence_ids:
+        raise ValueError("The excluded sequences were too strict and nothing was processed: "
+                         f"{config.exclude_sequence_ids}")
+
+
+def _write_unique_counts_native(config: SearchConfig):
+    max_kmer_length, min_kmer_length = max(config.kmer_lengths), min(config.kmer_lengths)
+    _check_range(config, min_kmer_length, max_kmer_length)
+    index = _single_index(config)
+    running = _Summary(min_kmer_length, max_kmer_length)
+
+    def on_record(rec_id: bytes, s: dict):
+        config.log(f"Writing unique lengths for sequence ID: {rec_id.decode()}")
+        running.unique += s["unique"]
+        running.ambiguous += s["ambiguous"]
+        running.none += s["no_unique"]
+        if s["unique"]:
+            running.max_len = max(running.max_len, s["max_len"])
+            running.min_len = min(running.min_len, s["min_len"])
+        running.report(config, rec_id)
+
+    total = index.search_fasta(config.fasta_filepaths[0], config.output_directory, config.kmer_lengths,
+                               config.is_binary_search, config.use_reverse_complement, config.kmer_batch_size,
+                               config.include_sequence_ids, config.exclude_sequence_ids,
+                               on_record if config.verbose else None)
+    if total["records"] == 0:
+        _nothing_processed(config)
+
+
+def _write_unique_counts_python(config: SearchConfig):
+    """the same driver, one segment at a time from Python (reference-shaped loop)"""
+    max_kmer_length = max(config.kmer_lengths)
+    min_kmer_length = min(config.kmer_lengths)
+    data_type, suffix = output_type(max_kmer_length)
+    _check_range(config, min_kmer_length, max_kmer_length)
     index = _single_index(config)
 
     lookahead = max_kmer_length - 1                                   # :229
@@ -237,11 +285,7 @@ def write_unique_counts(config: SearchConfig):
         if current_id is not None:
             summary.report(config, current_id)
     if not processed_any:                                             # :368-380
-        if config.include_sequence_ids:
-            raise ValueError(f"None of the included sequences were found: {config.include_sequence_ids}")
-        if config.exclude_sequence_ids:
-            raise ValueError("The excluded sequences were too strict and nothing was processed: "
-                             f"{config.exclude_sequence_ids}")
+        _nothing_processed(config)
 
 
 def main(args):

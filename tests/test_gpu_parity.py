@@ -408,3 +408,55 @@ def test_big_index_code_path(mixed_genome, eng):
         assert np.array_equal(f, ix.fixed_k_segment(rec[:100_000], 100_000, [36])[0])
         assert np.array_equal(c, ix.count_from_sequence(rec, [0, 77, 50_000], [30, 12, 400]))
         assert np.array_equal(n, ix.min_unique_segment(rec, len(rec), 20, 200, use_revcomp=False)[0])
+
+
+def test_native_driver_equals_python_driver(tmp_path, golden_search, eng, monkeypatch):
+    """csrc/nm_driver.hip (streaming FASTA reader + pipelined launches) writes the same files as the
+    segment-by-segment Python loop and as the reference fixtures; also .gz input, include / exclude,
+    consecutive records with one id, headerless data."""
+    import gzip
+    from newmap_amd.search import SearchConfig, write_unique_counts
+
+    def run(fa, idx, out, python_driver, **kw):
+        out.mkdir()
+        monkeypatch.setenv("NEWMAP_AMD_PYTHON_DRIVER", "1" if python_driver else "0")
+        write_unique_counts(SearchConfig(fasta_filepaths=[fa], fmindex_filepaths=[idx], output_directory=out, **kw))
+        return {p.name: p.read_bytes() for p in sorted(out.iterdir())}
+
+    for i, c in enumerate(golden_search):
+        if "quirk" in c["name"]:
+            continue
+        d = tmp_path / f"n{i}"
+        d.mkdir()
+        fa, idx = _build_index(d, c["fasta"].encode("latin-1"))
+        kw = dict(kmer_lengths=c["kmer_lengths"], is_binary_search=c["is_binary"], kmer_batch_size=c["batch"],
+                  use_reverse_complement=c["use_reverse_complement"])
+        a = run(fa, idx, d / "native", False, **kw)
+        b = run(fa, idx, d / "python", True, **kw)
+        assert a == b, c["name"]
+        for rid, e in c["expected"].items():
+            assert np.frombuffer(a[f"{rid}.unique.{e['dtype']}"], dtype=e["dtype"]).tolist() == e["values"]
+    # odd FASTA shapes
+    rng = np.random.default_rng(77)
+    body = _random_dna(rng, 5000)
+    text = (b"ACGTACGTTTGACCA" + body[:200] + b"\n>r1 first\n" + body[200:1500] + b"\n" + body[1500:1700] + b"  \n"
+            b">r1 again\n" + body[1700:2500] + b"\n;r2\r\n" + body[2500:3300] + b"\r\n>empty\n>r3\n" + body[3300:] + b"\nNNNN")
+    d = tmp_path / "odd"
+    d.mkdir()
+    fa, idx = _build_index(d, text)
+    gz = d / "x.fa.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(text)
+    kw = dict(kmer_lengths=list(range(12, 61)), is_binary_search=True, kmer_batch_size=300)
+    a = run(fa, idx, d / "native", False, **kw)
+    b = run(fa, idx, d / "python", True, **kw)
+    g = run(gz, idx, d / "gz", False, **kw)
+    assert a == b == g and set(a) == {".unique.uint8", "r1.unique.uint8", "r2.unique.uint8", "r3.unique.uint8"}
+    assert len(a["r1.unique.uint8"]) == 1300 + 200 + 800          # consecutive records with one id append
+    inc = run(fa, idx, d / "inc", False, include_sequence_ids=[b"r2", b"r3"], **kw)
+    assert set(inc) == {"r2.unique.uint8", "r3.unique.uint8"} and inc["r2.unique.uint8"] == a["r2.unique.uint8"]
+    exc = run(fa, idx, d / "exc", False, exclude_sequence_ids=[b"r1", b""], **kw)
+    assert exc == inc
+    with pytest.raises(ValueError, match="None of the included sequences"):
+        run(fa, idx, d / "none", False, include_sequence_ids=[b"zzz"], **kw)
+    eng.close_all()

@@ -339,7 +339,8 @@ extern "C" int nm_search_fasta(nm_index *ix, const char *fasta_path, const char 
     for (auto &s : d.slots)
         if ((rc = alloc_slot(d, s)) != NM_OK) break;
     if (rc == NM_OK) rc = run(d, fasta_path);
-    for (auto &s : d.slots) {
+    for (int i = 0; i < 2; i++) {                         // oldest segment first: appends stay in order
+        Slot &s = d.slots[d.next_slot ^ i];
         if (rc == NM_OK) rc = drain_slot(d, s);
         else if (s.busy) (void)hipEventSynchronize(s.done);
     }

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * 128ull;
-    if (wave_base >= num_kmers) return;
+    // (no early exit for waves past the end: every wave of the block reaches the barriers below)
     const uint32_t m = ix.pair_m, s = m + 1;
     const uint64_t core_mask = (1ULL << m) - 1ULL;
 
@@ -254,25 +254,54 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
     nm_tally t = {0, 0, 0, 0};
     bool any_err = false;
     uint64_t err_pos = ~0ULL;
-    uint32_t r0 = 0, r1 = 0;
-    if (go0) {
-        uint64_t lo = 0, hi = ix.n;
-        uint32_t k = 0;
-        if (nm_seed_decode(e0, lo, hi)) k = s; else { lo = 0; hi = ix.n; }
+    // ---- stage 1: what the table line alone decides.  Most positions end here (interval of one
+    // element); the rest are queued in LDS so that only as many waves as there is work stay resident
+    __shared__ uint64_t q_p[NM_BLOCK * 2], q_lo[NM_BLOCK * 2];
+    __shared__ uint32_t q_cnt[NM_BLOCK * 2];
+    __shared__ uint32_t q_n;
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+    auto stage1 = [&](bool go, bool in_range, uint64_t p, const nm_window &win, uint64_t e) {
+        if (!in_range) return;
+        uint32_t r = 0;
+        if (go) {
+            uint64_t lo = 0, hi = ix.n;
+            const bool have = nm_seed_decode(e, lo, hi);
+            const uint64_t cnt = hi - lo;
+            if (have && cnt == 1) {                       // unique already: max(s, kmin) if within U_p
+                nm_window w = win;
+                uint32_t kbase = 0;
+                const uint32_t ans = s > kmin ? s : kmin;
+                r = nm_all_valid(enc, p, w, kbase, s, ans) ? ans : 0u;
+            } else if (have && cnt == 0) {                // search.py:699-722
+                any_err = true;
+                if (p < err_pos) err_pos = p;
+            } else {                                      // needs a walk: queue it
+                const uint32_t slot_i = atomicAdd(&q_n, 1u);
+                q_p[slot_i] = p;
+                q_lo[slot_i] = have ? lo : 0;
+                q_cnt[slot_i] = have ? (uint32_t)cnt : 0u; // 0 = saturated entry, walk from scratch
+                return;                                   // stored by stage 2
+            }
+        }
+        nm_store(out, elem_bytes, p, r);
+    };
+    stage1(go0, in0, p0, win0, e0);
+    stage1(go1, in1, p1, win1, e1);
+    __syncthreads();
+    // ---- stage 2: dense walks; waves beyond the queue length leave and free their slots
+    const uint32_t n_walk = q_n;
+    for (uint32_t i = threadIdx.x; i < n_walk; i += NM_BLOCK) {
+        const uint64_t p = q_p[i];
+        uint64_t lo = q_lo[i], hi = lo + q_cnt[i];
+        uint32_t k = s;
+        if (q_cnt[i] == 0) { lo = 0; hi = ix.n; k = 0; }
         bool err = false;
-        r0 = nm_min_unique_walk<BIG, true>(ix, enc, p0, win0, 0, lo, hi, k, kmin, kmax, err, t);
-        if (err) { any_err = true; err_pos = p0; }
+        const nm_window w = nm_load_window(enc, p);
+        const uint32_t r = nm_min_unique_walk<BIG, true>(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);
+        if (err) { any_err = true; if (p < err_pos) err_pos = p; }
+        nm_store(out, elem_bytes, p, r);
     }
-    if (go1) {
-        uint64_t lo = 0, hi = ix.n;
-        uint32_t k = 0;
-        if (nm_seed_decode(e1, lo, hi)) k = s; else { lo = 0; hi = ix.n; }
-        bool err = false;
-        r1 = nm_min_unique_walk<BIG, true>(ix, enc, p1, win1, 0, lo, hi, k, kmin, kmax, err, t);
-        if (err) { any_err = true; if (p1 < err_pos) err_pos = p1; }
-    }
-    if (in0) nm_store(out, elem_bytes, p0, r0);
-    if (in1) nm_store(out, elem_bytes, p1, r1);
 
     const uint32_t amb_sum = wave_sum((uint32_t)(in0 && amb0) + (uint32_t)(in1 && amb1));
     if (lane == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);

@@ -151,6 +151,13 @@ int nm_search_fasta(nm_index *ix, const char *fasta_path, const char *out_dir, c
                     const char *const *exclude_ids, uint32_t n_exclude,
                     nm_record_callback cb, void *user, nm_search_summary *total);
 
+/* --------------------------------------------------------------- track on the device ----------
+ * newmap/track.py:22-121 for ONE unique-length file: marks, windowed prefix sums, run-length BED
+ * lines and formatted WIG lines, appended to bed_path / wig_path (either may be NULL).  `chr_name` is
+ * the text before ".unique" in the file name (track.py:155-158). */
+int nm_track_file(int device, const char *unique_path, const char *chr_name, int elem_bytes, uint32_t k,
+                  const char *bed_path, const char *wig_path, uint64_t *n_positions, uint64_t *n_runs);
+
 /* small device-memory helpers so a host program needs no other HIP binding */
 int nm_dev_alloc(int device, uint64_t bytes, void **out);
 int nm_dev_free(int device, void *p);

@@ -1,9 +1,9 @@
 """`newmap track`: unique-length arrays -> single-read BED / multi-read WIG mappability tracks
-(reference: newmap/track.py).  Downstream consumer of the `search` output, host numpy for now
-(SURVEY.md section 8(f) rank 2 lists a device version as a later widening step).
-
-Same functions, arguments and output bytes as the reference; the WIG writer formats each DISTINCT
-value once (a track has at most k+1 of them) instead of one Python call per base.
+(reference: newmap/track.py).  Downstream consumer of the `search` output (SURVEY.md section 8(f)
+rank 2).  `write_mappability_files` runs on the device (csrc/nm_track.hip: scans, stream compaction,
+text scatter) when a GPU is visible; the numpy functions below are the same arithmetic on the host,
+kept because `track` is a post-processing tool that is also run on machines without a GPU.  Both
+write the reference's bytes (tests/test_track.py, tests/test_gpu_parity.py).
 """
 from __future__ import annotations
 
@@ -79,6 +79,19 @@ def safe_remove(filename):
         Path(filename).unlink()
 
 
+def _device_for_track():
+    """GPU to use, or None (NEWMAP_AMD_TRACK=host forces the numpy path)"""
+    import os
+    if os.environ.get("NEWMAP_AMD_TRACK", "") == "host":
+        return None
+    try:
+        from . import _lib
+        from .engine import default_device, device_count
+        return default_device() if device_count() > 0 else None
+    except Exception:
+        return None
+
+
 def write_mappability_files(unique_count_filenames, kmer_length: int, single_read_bed_filename,
                             multi_read_wig_filename, verbose: bool):
     """newmap/track.py:131-237"""
@@ -96,6 +109,21 @@ def write_mappability_files(unique_count_filenames, kmer_length: int, single_rea
             raise ValueError(f"Unknown extension on unique length file: \"{unique_path.suffix}\"")
         verbose_print(verbose, f"Calculating mappability regions from minimum unique k-mer lengths in "
                                f"file: {unique_path}")
+        device = _device_for_track()
+        if device is not None and STDOUT_FILENAME not in (single_read_bed_filename, multi_read_wig_filename):
+            import ctypes
+            import os
+            from . import _lib
+            n_pos, n_runs = ctypes.c_uint64(0), ctypes.c_uint64(0)
+            rc = _lib.lib().nm_track_file(
+                device, os.fsencode(unique_path), chr_name.encode(), np.dtype(_DTYPES[unique_path.suffix]).itemsize,
+                int(kmer_length), os.fsencode(single_read_bed_filename) if single_read_bed_filename else None,
+                os.fsencode(multi_read_wig_filename) if multi_read_wig_filename else None,
+                ctypes.byref(n_pos), ctypes.byref(n_runs))
+            _lib.raise_for(rc)
+            verbose_print(verbose, "Chromosome size:")
+            verbose_print(verbose, f"{chr_name}\t{n_pos.value}")
+            continue
         mm = create_multiread_mappability_from_unique_file(unique_path, kmer_length, _DTYPES[unique_path.suffix])
         verbose_print(verbose, "Chromosome size:")
         verbose_print(verbose, f"{chr_name}\t{mm.shape[0]}")

@@ -3,6 +3,7 @@ Needs a real MI355X:  python -m pytest tests -m gpu"""
 import ctypes
 import io
 import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -460,3 +461,37 @@ def test_native_driver_equals_python_driver(tmp_path, golden_search, eng, monkey
     with pytest.raises(ValueError, match="None of the included sequences"):
         run(fa, idx, d / "none", False, include_sequence_ids=[b"zzz"], **kw)
     eng.close_all()
+
+
+def test_track_on_device_matches_reference(tmp_path, eng):
+    """csrc/nm_track.hip: BED + WIG bytes equal the reference's newmap/track.py (fixtures written by the
+    reference itself) and the host numpy path, incl. a multi-tile input for the hierarchical scans"""
+    import json
+    from newmap_amd import track
+    golden = json.loads((Path(__file__).resolve().parent / "golden" / "golden_track.json").read_text())
+    files = []
+    for name, a in golden["arrays"].items():
+        p = tmp_path / f"{name}.unique.{a['dtype']}"
+        np.array(a["values"], dtype=a["dtype"]).tofile(p)
+        files.append(p)
+    for c in golden["cases"]:
+        bed, wig = tmp_path / "d.bed", tmp_path / "d.wig"
+        track.write_mappability_files(files, c["k"], str(bed), str(wig), False)
+        assert bed.read_text() == c["bed"], c["k"]
+        assert wig.read_text() == c["wig"], c["k"]
+    # larger than one scan tile, three levels deep for the flag scan
+    rng = np.random.default_rng(8)
+    big = np.where(rng.random(20_000_000) < 0.4, 0, rng.integers(20, 120, 20_000_000)).astype(np.uint8)
+    big[5_000_000:5_300_000] = 0
+    p = tmp_path / "big.unique.uint8"
+    big.tofile(p)
+    for k in (24, 100):
+        out = {}
+        for mode in ("device", "host"):
+            os.environ["NEWMAP_AMD_TRACK"] = mode
+            bed, wig = tmp_path / f"{mode}.bed", tmp_path / f"{mode}.wig"
+            track.write_mappability_files([p], k, str(bed), str(wig), False)
+            out[mode] = (bed.read_bytes(), wig.read_bytes())
+        os.environ.pop("NEWMAP_AMD_TRACK")
+        assert out["device"][0] == out["host"][0]
+        assert out["device"][1] == out["host"][1]

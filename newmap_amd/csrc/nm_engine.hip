@@ -613,7 +613,9 @@ static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table) {
 static uint32_t nm_auto_seed_len(const nm_index *ix) {
     uint32_t s = 1;
     while (s < 16 && (1ULL << (2 * s)) < ix->h.n) s++;     // s = ceil(log4 n)
-    s = s + 1 > 16 ? 16 : s + 1;
+    uint32_t bonus = 1;                                   // NEWMAP_AMD_SEED_BONUS: measurement knob
+    if (const char *b = getenv("NEWMAP_AMD_SEED_BONUS")) bonus = (uint32_t)atoi(b);
+    s = s + bonus > 16 ? 16 : s + bonus;
     if (s < 4) s = 4;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)

@@ -221,26 +221,42 @@ def main():
     units = parallel.units_for_slice(lengths, lo, hi, args.batch, KMAX)
     segs = [(int(rec_off[u.record]) + u.start, u.seg_len, u.count) for u in units]
     per = -(-n // world)
-    gather_buf = torch.empty(per * world, dtype=torch.uint8, device=dev) if world > 1 and rank == 0 else None
-    pad_out = torch.zeros(per, dtype=torch.uint8, device=dev) if world > 1 else None
+    # final gather of the per-rank uint8 slices on rank 0 (RCCL).  Double-buffered and asynchronous:
+    # the gather of pass i travels over xGMI while pass i+1 computes; every pass is gathered inside
+    # the timed region.
+    gather_bufs = [torch.empty(per * world, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 and rank == 0 else None
+    pads = [torch.zeros(per, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
     seq_ptr, out_ptr, st_ptr = d_seq.data_ptr(), d_out.data_ptr(), d_status.data_ptr()
+    state = {"pending": None, "i": 0}
 
     def step():
         for (p, seg_len, nk) in segs:
             ix.min_unique_segment_dev(seq_ptr + p, seg_len, nk, KMIN, KMAX, True, 1, out_ptr + p, st_ptr, stream)
         if world > 1:
-            pad_out[:hi - lo].copy_(d_out[lo:hi])
-            dist.gather(pad_out, list(gather_buf.split(per)) if rank == 0 else None, dst=0)
+            b = state["i"] & 1
+            state["i"] += 1
+            pads[b][:hi - lo].copy_(d_out[lo:hi])
+            if state["pending"] is not None:
+                state["pending"].wait()
+            state["pending"] = dist.gather(pads[b], list(gather_bufs[b].split(per)) if rank == 0 else None,
+                                           dst=0, async_op=True)
+
+    def finish_steps():
+        if state["pending"] is not None:
+            state["pending"].wait()
+            state["pending"] = None
 
     for _ in range(args.warmup):
         step()
+    finish_steps()
     torch.cuda.synchronize()
     barrier()
     ix.set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    finish_steps()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

@@ -81,3 +81,42 @@ def test_plan_covers_every_position_once():
                 assert u.start + u.seg_len <= lengths[u.record]
                 assert u.seg_len == min(u.count + 39, lengths[u.record] - u.start)
         assert (seen == 1).all()
+
+
+def _gather_worker(rank, world, port, outdir):
+    """the double-buffered asynchronous gather of bench.py's N>1 step, on CPU tensors"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, steps = 1003, 5
+    per = -(-n // world)
+    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+    gather_bufs = [torch.empty(per * world, dtype=torch.uint8) for _ in range(2)] if rank == 0 else None
+    pads = [torch.zeros(per, dtype=torch.uint8) for _ in range(2)]
+    pending, seen = None, []
+    for i in range(steps):
+        d_out = ((torch.arange(n) * 7 + i) % 251).to(torch.uint8)          # this pass's full result
+        b = i & 1
+        pads[b][:hi - lo].copy_(d_out[lo:hi])
+        if pending is not None:
+            pending.wait()
+            if rank == 0:
+                seen.append(gather_bufs[(i - 1) & 1].clone())
+        pending = dist.gather(pads[b], list(gather_bufs[b].split(per)) if rank == 0 else None, dst=0, async_op=True)
+    pending.wait()
+    if rank == 0:
+        seen.append(gather_bufs[(steps - 1) & 1].clone())
+        for i, g in enumerate(seen):
+            want = ((torch.arange(n) * 7 + i) % 251).to(torch.uint8)
+            got = torch.cat([g[r * per: r * per + (min((r + 1) * per, n) - min(r * per, n))] for r in range(world)])
+            assert torch.equal(got, want), i
+        Path(outdir, "gather_ok").write_text("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_double_buffered_gather_pattern(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_gather_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert (tmp_path / "gather_ok").exists()

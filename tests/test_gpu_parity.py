@@ -276,15 +276,16 @@ def test_torch_tensors_share_the_runtime(mixed_genome):
 
 # ------------------------------------------------------------------ larger sizes: properties
 def test_large_random_genome_properties(tmp_path, eng):
-    """20 Mbp uniform genome (a fifth of BASELINE configs[1]): seed-table independence,
-    batch independence, and minimality re-checked through the count seam."""
+    """BASELINE configs[1] at FULL size (100 Mbp uniform genome, the bench workload): table
+    independence, batch independence, and minimality re-checked through the count seam."""
+    from newmap_amd import synth
     rng = np.random.default_rng(20260515)
-    rec = _random_dna(rng, 20_000_000)
+    rec = synth.config_genome("c2")[0][1].tobytes()
     fa, idx = _build_index(tmp_path, b">chr1\n" + rec + b"\n", "big")
     kmin, kmax = 20, 200
-    with eng.Index(idx, 0, 12) as ix:
+    with eng.Index(idx, 0) as ix:                         # automatic tables: the pair kernel, as in bench.py
         whole, amb = ix.min_unique_segment(rec, len(rec), kmin, kmax)
-        assert amb == 0
+        assert amb == 0 and ix.info()["last_range_kernel"] == 4
         parts = [ix.min_unique_segment(s.data, rd.num_kmers_of(s, kmax), kmin, kmax)[0]
                  for s in rd.record_segments(b"c", rec, 10_000_000 + kmax - 1, kmax - 1)]
         assert np.array_equal(np.concatenate(parts), whole)
@@ -303,6 +304,9 @@ def test_large_random_genome_properties(tmp_path, eng):
         tot2 = ix.count_from_sequence(rec, pos[longer], k[longer] - 1) + \
             ix.count_from_sequence(rcrec, len(rec) - pos[longer] - (k[longer] - 1), k[longer] - 1)
         assert (tot2 > 1).all()
+    with eng.Index(idx, 0, 12) as ix12:                   # the reference's default seed length, simple kernel
+        seed12, _ = ix12.min_unique_segment(rec, len(rec), kmin, kmax)
+        assert ix12.info()["last_range_kernel"] == 1 and np.array_equal(seed12, whole)
     with eng.Index(idx, 0, 0) as ix0:
         no_seed, _ = ix0.min_unique_segment(rec[:3_000_000 + kmax], 3_000_000, kmin, kmax)
         assert np.array_equal(no_seed, whole[:3_000_000])

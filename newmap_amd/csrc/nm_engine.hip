@@ -59,6 +59,41 @@ __global__ __launch_bounds__(NM_BLOCK) void k_encode(const uint8_t *__restrict__
     }
 }
 
+// 16 bases per lane (one 16-byte load), four lanes OR their 16-bit pieces into one 64-base word:
+// 1 KiB per wave-instruction instead of the 64 B of k_encode.  Needs a 16-byte aligned `seq`.
+__global__ __launch_bounds__(NM_BLOCK) void k_encode16(const uint8_t *__restrict__ seq, uint64_t seq_len,
+                                                       nm_enc_word *__restrict__ enc, uint64_t n_words) {
+    const uint64_t t = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (t >= n_words * 4) return;                       // groups of 4 lanes stay whole
+    const uint64_t base = t * 16;
+    uint32_t b[4] = {0, 0, 0, 0};
+    uint32_t valid = 16;
+    if (base + 16 <= seq_len) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(seq + base);
+        b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+    } else {
+        valid = base < seq_len ? (uint32_t)(seq_len - base) : 0;
+        for (uint32_t j = 0; j < valid; j++) b[j >> 2] |= (uint32_t)seq[base + j] << (8 * (j & 3));
+    }
+    uint32_t lo = 0, hi = 0, amb = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t code = j < valid ? nm_base_code((b[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 4u;
+        lo |= ((code & 1u) & (code < 4)) << j;
+        hi |= (((code >> 1) & 1u) & (code < 4)) << j;
+        amb |= (uint32_t)(code > 3) << j;
+    }
+    const uint32_t sub = threadIdx.x & 3;
+    uint64_t wlo = (uint64_t)lo << (16 * sub), whi = (uint64_t)hi << (16 * sub), wamb = (uint64_t)amb << (16 * sub);
+    wlo |= __shfl_xor(wlo, 1, NM_WAVE);  whi |= __shfl_xor(whi, 1, NM_WAVE);  wamb |= __shfl_xor(wamb, 1, NM_WAVE);
+    wlo |= __shfl_xor(wlo, 2, NM_WAVE);  whi |= __shfl_xor(whi, 2, NM_WAVE);  wamb |= __shfl_xor(wamb, 2, NM_WAVE);
+    if (sub == 0) {
+        nm_enc_word w;
+        w.lo = wlo; w.hi = whi; w.amb = wamb; w.pad = 0;
+        enc[t >> 2] = w;
+    }
+}
+
 template <bool BIG>
 __global__ __launch_bounds__(NM_BLOCK) void k_seed(nm_view ix, uint64_t *__restrict__ table, uint64_t first_slot,
                                                    uint64_t n_slots, uint32_t s) {
@@ -879,8 +914,12 @@ static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStrea
     int rc = nm_grow(ix->enc, n_words * sizeof(nm_enc_word));
     if (rc != NM_OK) return rc;
     ix->enc_words = n_words;
-    hipLaunchKernelGGL(k_encode, dim3(nm_grid(n_words * 64)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
-                       (nm_enc_word *)ix->enc.p, n_words);
+    if (((uintptr_t)d_seq & 15) == 0)
+        hipLaunchKernelGGL(k_encode16, dim3(nm_grid(n_words * 4)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
+                           (nm_enc_word *)ix->enc.p, n_words);
+    else
+        hipLaunchKernelGGL(k_encode, dim3(nm_grid(n_words * 64)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
+                           (nm_enc_word *)ix->enc.p, n_words);
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }

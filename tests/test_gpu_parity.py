@@ -251,6 +251,15 @@ def test_device_pointer_api_matches_host_api(mixed_genome, eng):
         assert int(st[0]) == amb and int(st[1]) == 0
         assert int(st[7]) == len(rec) - amb and int(st[3]) > 0 and int(st[4]) >= int(st[3])
         ix.set_count_steps(False)
+        # a segment that starts at an odd device address takes the byte-wise encode kernel
+        off = 12_345
+        sub = rec[off:]
+        want_sub, _ = ix.min_unique_segment(sub, len(sub), 20, 200)
+        ix.min_unique_segment_dev(d_seq.value + off, len(sub), len(sub), 20, 200, True, 1, d_out.value, d_st.value)
+        assert L.nm_dev_sync(0) == 0
+        got_sub = np.zeros(len(sub), np.uint8)
+        assert L.nm_dev_download(0, got_sub.ctypes.data, d_out, got_sub.size) == 0
+        assert np.array_equal(got_sub, want_sub)
         for p in (d_seq, d_out, d_st):
             L.nm_dev_free(0, p)
 

@@ -111,7 +111,7 @@ def measured_traffic(kernel: str, config: str, positions_per_launch: float):
         return None, None
     scale = positions_per_launch / 10_000_000
     read_b = vals["TCC_EA0_RDREQ_sum"] * 128.0
-    write_b = 11_150.6 * 1024.0            # WRITE_SIZE of k_min_unique on the same launch (profiles/round1/pmc_auto_WRITE_S_summary.csv)
+    write_b = vals.get("WRITE_SIZE", 0.0) * 1024.0     # rocprofv3 reports WRITE_SIZE in KB (exact for stores)
     return (read_b + write_b) * scale, str(f.relative_to(ROOT))
 
 

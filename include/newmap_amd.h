@@ -93,6 +93,16 @@ int nm_fixed_k_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint6
                        const uint32_t *ks, uint32_t nk, int use_revcomp, int elem_bytes, void *out,
                        uint64_t *n_ambiguous, uint64_t *bad_pos);
 
+/* Several FASTA files processed in lock-step against several index files -- the reference's
+ * bisulfite-style mode (newmap/search.py:251-265, 461, 656-697): the count of a position is summed over
+ * every (index, sequence) pair and a position is unique when the total equals n_seqs.  seqs[i] are the
+ * n_seqs segments (equal length seq_len; mask, upper bound and geometry come from seqs[0]).  ks / nk /
+ * range_mode as in nm_search_fasta.  At most 4 indexes (all open on one device) and 4 sequences. */
+int nm_search_segment_multi(nm_index *const *indexes, uint32_t n_indexes, const uint8_t *const *seqs,
+                            uint32_t n_seqs, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks,
+                            uint32_t nk, int range_mode, int use_revcomp, int elem_bytes, void *out,
+                            uint64_t *n_ambiguous, uint64_t *bad_pos);
+
 /* newmap/search.py:744-766 + :769-882 in one launch: out[p] (uint32) = per-position inclusive
  * upper search length; ambiguous positions keep kmax. */
 int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,

@@ -306,6 +306,127 @@ NM_HD uint32_t nm_fixed_k_one(const nm_view &ix, const nm_enc_word *enc, uint64_
     return 0;
 }
 
+// ---- several FASTA files in lock-step x several indexes (newmap/search.py:251-265, 461, 656-697) ----
+// total(k) = sum over index f and sequence i of the count of sequence i's k-mer in index f (both
+// strands, or forward only); a position is unique when total == number of sequences.  Mask, upper
+// bound and record geometry come from the FIRST sequence (:263-265, :393-400).  Every (f, i) pair keeps
+// its own interval; the total is non-increasing in k, so the first k with total <= n_seq decides.
+#define NM_MAX_MULTI 4
+
+struct nm_multi_args {
+    nm_view view[NM_MAX_MULTI];
+    const nm_enc_word *enc[NM_MAX_MULTI];
+    uint32_t n_idx, n_seq;
+};
+
+struct nm_multi_state {
+    uint64_t lo[NM_MAX_MULTI][NM_MAX_MULTI], hi[NM_MAX_MULTI][NM_MAX_MULTI];   // [index][sequence]
+    nm_window w[NM_MAX_MULTI];
+    uint32_t k, kbase;
+};
+
+NM_HD void nm_multi_reset(const nm_multi_args &a, nm_multi_state &st, uint64_t p) {
+#pragma unroll
+    for (uint32_t i = 0; i < NM_MAX_MULTI; i++)
+        if (i < a.n_seq) st.w[i] = nm_load_window(a.enc[i], p);
+#pragma unroll
+    for (uint32_t f = 0; f < NM_MAX_MULTI; f++)
+#pragma unroll
+        for (uint32_t i = 0; i < NM_MAX_MULTI; i++) { st.lo[f][i] = 0; st.hi[f][i] = f < a.n_idx && i < a.n_seq ? a.view[f].n : 0; }
+    st.k = 0;
+    st.kbase = 0;
+}
+
+template <bool RC>
+NM_HD uint64_t nm_multi_total(const nm_multi_args &a, const nm_multi_state &st) {
+    uint64_t total = 0;
+#pragma unroll
+    for (uint32_t f = 0; f < NM_MAX_MULTI; f++)
+#pragma unroll
+        for (uint32_t i = 0; i < NM_MAX_MULTI; i++)
+            if (f < a.n_idx && i < a.n_seq && st.hi[f][i] > st.lo[f][i])
+                total += RC ? st.hi[f][i] - st.lo[f][i]
+                            : nm_strand_rank(a.view[f], st.hi[f][i]) - nm_strand_rank(a.view[f], st.lo[f][i]);
+    return total;
+}
+
+// extend every live interval by base k of its own sequence; false = the FIRST sequence is ambiguous there
+NM_HD bool nm_multi_step(const nm_multi_args &a, nm_multi_state &st, uint64_t p) {
+    uint32_t j = st.k - st.kbase;
+    if (j >= 64) {
+#pragma unroll
+        for (uint32_t i = 0; i < NM_MAX_MULTI; i++)
+            if (i < a.n_seq) st.w[i] = nm_load_window(a.enc[i], p + st.k);
+        st.kbase = st.k;
+        j = 0;
+    }
+    if ((st.w[0].amb >> j) & 1ULL) return false;
+#pragma unroll
+    for (uint32_t i = 0; i < NM_MAX_MULTI; i++) {
+        if (i >= a.n_seq) continue;
+        const bool amb_i = (st.w[i].amb >> j) & 1ULL;      // another sequence ambiguous here: it matches nothing
+        const uint32_t c = 3u - nm_window_code(st.w[i], j);
+#pragma unroll
+        for (uint32_t f = 0; f < NM_MAX_MULTI; f++) {
+            if (f >= a.n_idx || st.hi[f][i] <= st.lo[f][i]) continue;
+            if (amb_i) { st.hi[f][i] = st.lo[f][i]; continue; }
+            st.lo[f][i] = nm_lf<true>(a.view[f], c, st.lo[f][i]);
+            st.hi[f][i] = nm_lf<true>(a.view[f], c, st.hi[f][i]);
+        }
+    }
+    st.k++;
+    return true;
+}
+
+template <bool RC>
+NM_HD uint32_t nm_min_unique_multi_one(const nm_multi_args &a, uint64_t p, uint32_t kmin, uint32_t kmax,
+                                       bool &amb0, bool &err) {
+    nm_multi_state st;
+    nm_multi_reset(a, st, p);
+    amb0 = (st.w[0].amb & 1ULL) != 0;
+    err = false;
+    if (amb0) return 0;
+    for (;;) {
+        const uint64_t total = nm_multi_total<RC>(a, st);
+        if (total == 0) { err = true; return 0; }             // search.py:699-722
+        if (total <= a.n_seq) break;                          // == in the reference; < would never end there
+        if (st.k >= kmax) return 0;
+        if (!nm_multi_step(a, st, p)) return 0;
+    }
+    const uint32_t ans = st.k > kmin ? st.k : kmin;
+    if (!nm_all_valid(a.enc[0], p, st.w[0], st.kbase, st.k, ans)) return 0;
+    return ans;
+}
+
+template <bool RC>
+NM_HD uint32_t nm_fixed_k_multi_one(const nm_multi_args &a, uint64_t p, uint64_t seq_len, const uint32_t *ks,
+                                    uint32_t nk, bool &amb0, bool &err) {
+    nm_multi_state st;
+    nm_multi_reset(a, st, p);
+    amb0 = (st.w[0].amb & 1ULL) != 0;
+    err = false;
+    if (amb0) return 0;
+    const uint64_t rem = seq_len - p;
+    uint32_t checked = 1;
+    for (uint32_t q = 0; q < nk; q++) {
+        const uint32_t K = ks[q];
+        const uint32_t L = (uint64_t)K < rem ? K : (uint32_t)rem;
+        if (L > checked) {
+            nm_window w0 = st.w[0];
+            uint32_t kb = st.kbase;
+            if (!nm_all_valid(a.enc[0], p, w0, kb, checked, L)) return 0;
+            checked = L;
+        }
+        if (L < st.k) nm_multi_reset(a, st, p);
+        while (st.k < L)
+            if (!nm_multi_step(a, st, p)) return 0;
+        const uint64_t total = nm_multi_total<RC>(a, st);
+        if (total == 0) { err = true; return 0; }
+        if (total <= a.n_seq) return K;                       // search.py:627-636
+    }
+    return 0;
+}
+
 // forward-strand occurrences of one raw k-mer (any byte; non-ACGT -> 0)
 template <bool BIG>
 NM_HD uint32_t nm_count_fwd_one(const nm_view &ix, const uint8_t *kmer, uint64_t len, nm_tally &t) {

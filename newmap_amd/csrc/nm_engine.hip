@@ -546,6 +546,23 @@ __global__ __launch_bounds__(NM_BLOCK) void k_upper(const nm_enc_word *__restric
     if (p < num_kmers) out[p] = nm_upper_one(enc, p, kmax);
 }
 
+// several sequences in lock-step x several indexes; nk == 0: range mode
+template <bool RC>
+__global__ __launch_bounds__(NM_BLOCK) void k_multi(nm_multi_args a, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin,
+                                                    uint32_t kmax, const uint32_t *__restrict__ ks, uint32_t nk,
+                                                    void *__restrict__ out, int elem_bytes, uint64_t *__restrict__ status) {
+    const uint64_t p = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    const bool inb = p < num_kmers;
+    bool amb0 = false, err = false;
+    nm_tally t = {0, 0, 0, 0};
+    if (inb) {
+        const uint32_t r = nk == 0 ? nm_min_unique_multi_one<RC>(a, p, kmin, kmax, amb0, err)
+                                   : nm_fixed_k_multi_one<RC>(a, p, seq_len, ks, nk, amb0, err);
+        nm_store(out, elem_bytes, p, r);
+    }
+    nm_epilogue<false>(inb, amb0, err, p, t, status);
+}
+
 __global__ void k_reset_status(uint64_t *__restrict__ status, unsigned long long *__restrict__ work) {
     if (threadIdx.x < NM_STATUS_WORDS) status[threadIdx.x] = threadIdx.x == 2 ? ~0ULL : 0ULL;
     if (threadIdx.x == 0 && work) *work = 0ULL;
@@ -1161,6 +1178,60 @@ extern "C" int nm_count_kmers(nm_index *ix, const uint8_t *kmers, const uint64_t
         lens[i] = offsets[i + 1] - offsets[i];
     }
     return nm_count_from_sequence(ix, kmers + offsets[0], offsets[n] - offsets[0], starts.data(), lens.data(), n, counts_out);
+}
+
+extern "C" int nm_search_segment_multi(nm_index *const *indexes, uint32_t n_indexes, const uint8_t *const *seqs,
+                                       uint32_t n_seqs, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks,
+                                       uint32_t nk, int range_mode, int use_revcomp, int elem_bytes, void *out,
+                                       uint64_t *n_ambiguous, uint64_t *bad_pos) {
+    if (!indexes || !seqs || n_indexes == 0 || n_seqs == 0 || !ks || nk == 0) { nm_set_error("null or empty argument"); return NM_E_ARGUMENT; }
+    if (n_indexes > NM_MAX_MULTI || n_seqs > NM_MAX_MULTI) { nm_set_error("at most %d index files and %d FASTA files are supported", NM_MAX_MULTI, NM_MAX_MULTI); return NM_E_ARGUMENT; }
+    nm_index *ix0 = indexes[0];
+    int rc = nm_check_segment_args(ix0, seq_len, num_kmers, elem_bytes);
+    if (rc != NM_OK) return rc;
+    uint32_t kmin = ks[0], kmax = ks[0];
+    for (uint32_t i = 1; i < nk; i++) { if (ks[i] < kmin) kmin = ks[i]; if (ks[i] > kmax) kmax = ks[i]; }
+    if (kmin < 1) { nm_set_error("k-mer lengths must be >= 1"); return NM_E_ARGUMENT; }
+    if ((elem_bytes == 1 && kmax > 0xFF) || (elem_bytes == 2 && kmax > 0xFFFF)) { nm_set_error("k %u does not fit in %d-byte elements", kmax, elem_bytes); return NM_E_ARGUMENT; }
+    nm_multi_args a;
+    memset(&a, 0, sizeof a);
+    a.n_idx = n_indexes;
+    a.n_seq = n_seqs;
+    for (uint32_t f = 0; f < n_indexes; f++) {
+        if (!indexes[f] || indexes[f]->device != ix0->device) { nm_set_error("all indexes must be open on the same device"); return NM_E_ARGUMENT; }
+        a.view[f] = indexes[f]->view;
+        a.view[f].seed = nullptr;           // the multi kernels walk from the first base
+        a.view[f].seed_len = 0;
+    }
+    HIP_TRY(hipSetDevice(ix0->device));
+    hipStream_t st = ix0->stream;
+    const uint64_t n_words = seq_len / 64 + 3;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    void *d_seq = nullptr;
+    if (hipMalloc(&d_seq, seq_len + 64) != hipSuccess) { nm_set_error("hipMalloc failed"); return NM_E_ALLOC; }
+    tmp.push_back(d_seq);
+    for (uint32_t i = 0; i < n_seqs; i++) {
+        void *d_enc = nullptr;
+        if (hipMalloc(&d_enc, n_words * sizeof(nm_enc_word)) != hipSuccess) { cleanup(); nm_set_error("hipMalloc failed"); return NM_E_ALLOC; }
+        tmp.push_back(d_enc);
+        a.enc[i] = (const nm_enc_word *)d_enc;
+        if (hipMemcpyAsync(d_seq, seqs[i], seq_len, hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); nm_set_error("copy to device failed"); return NM_E_DEVICE; }
+        hipLaunchKernelGGL(k_encode16, dim3(nm_grid(n_words * 4)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len, (nm_enc_word *)d_enc, n_words);
+    }
+    const uint64_t out_bytes = num_kmers * (uint64_t)elem_bytes;
+    if ((rc = nm_grow(ix0->out, out_bytes + 64)) != NM_OK || (rc = nm_grow(ix0->ks, (uint64_t)nk * 4)) != NM_OK) { cleanup(); return rc; }
+    if ((rc = nm_reset_status(ix0, (uint64_t *)ix0->status.p, st)) != NM_OK) { cleanup(); return rc; }
+    if (hipMemcpyAsync(ix0->ks.p, ks, (uint64_t)nk * 4, hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); nm_set_error("copy to device failed"); return NM_E_DEVICE; }
+    if (num_kmers) {
+        const uint32_t list_n = range_mode ? 0u : nk;
+        if (use_revcomp) hipLaunchKernelGGL(k_multi<true>, dim3(nm_grid(num_kmers)), dim3(NM_BLOCK), 0, st, a, seq_len, num_kmers, kmin, kmax, (const uint32_t *)ix0->ks.p, list_n, ix0->out.p, elem_bytes, (uint64_t *)ix0->status.p);
+        else             hipLaunchKernelGGL(k_multi<false>, dim3(nm_grid(num_kmers)), dim3(NM_BLOCK), 0, st, a, seq_len, num_kmers, kmin, kmax, (const uint32_t *)ix0->ks.p, list_n, ix0->out.p, elem_bytes, (uint64_t *)ix0->status.p);
+        if (hipGetLastError() != hipSuccess) { cleanup(); nm_set_error("kernel launch failed"); return NM_E_DEVICE; }
+    }
+    rc = nm_finish_segment(ix0, out, out_bytes, n_ambiguous, bad_pos);
+    cleanup();
+    return rc;
 }
 
 // small device helpers ------------------------------------------------------------------------

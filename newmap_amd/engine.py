@@ -235,6 +235,30 @@ class Index:
         _lib.raise_for(rc)
 
 
+def search_segment_multi(indexes: Sequence[Index], seqs: Sequence, num_kmers: int, kmer_lengths: Sequence[int],
+                         is_range: bool, use_revcomp: bool = True, dtype=None):
+    """nm_search_segment_multi: segments of several FASTA files in lock-step against several indexes
+    (newmap/search.py:251-265, 461, 656-697) -> (unique_lengths, n_ambiguous)."""
+    L = _lib.lib()
+    ks = np.ascontiguousarray([min(kmer_lengths), max(kmer_lengths)] if is_range else list(kmer_lengths), dtype=np.uint32)
+    kmax = int(ks.max())
+    if dtype is None:
+        dtype = np.uint8 if kmax <= 255 else (np.uint16 if kmax <= 65535 else np.uint32)
+    dtype = np.dtype(dtype)
+    bufs = [_as_u8(s) for s in seqs]
+    if len({b.size for b in bufs}) != 1:
+        raise ValueError("the segments of all FASTA files must have the same length")
+    hs = (ctypes.c_void_p * len(indexes))(*[ix.handle for ix in indexes])
+    ptrs = (ctypes.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+    out = np.zeros(max(int(num_kmers), 1), dtype=dtype)
+    amb, bad = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = L.nm_search_segment_multi(hs, len(indexes), ptrs, len(bufs), bufs[0].size, int(num_kmers), ks.ctypes.data,
+                                   ks.size, int(bool(is_range)), int(bool(use_revcomp)), dtype.itemsize,
+                                   out.ctypes.data, ctypes.byref(amb), ctypes.byref(bad))
+    _lib.raise_for(rc, indexes[0]._not_found(bufs[0], int(bad.value), int(ks.min())) if rc == _lib.NM_E_KMER_NOT_FOUND else None)
+    return out[:num_kmers], int(amb.value)
+
+
 # ---------------------------------------------------------------------------------------------
 # The reference's FFI is stateless by path (index loaded and freed inside every call).  Keep the
 # same call shape but hold the uploaded index across calls.

@@ -128,6 +128,12 @@ def _first_segment(segments: Sequence[SequenceSegment]) -> SequenceSegment:
 def binary_search(config: SearchConfig, sequence_segments: Sequence[SequenceSegment], min_kmer_length: int,
                   max_kmer_length: int, data_type):
     """newmap/search.py:383-548 -> (unique_lengths, ambiguous_positions_skipped), one launch."""
+    if len(sequence_segments) > 1 or len(config.fmindex_filepaths) > 1:
+        from .engine import search_segment_multi
+        indexes = [cached_index(p, config.device) for p in config.fmindex_filepaths]
+        return search_segment_multi(indexes, [s.data for s in sequence_segments],
+                                    get_num_kmers(sequence_segments[0], max_kmer_length),
+                                    [min_kmer_length, max_kmer_length], True, config.use_reverse_complement, data_type)
     seg = _first_segment(sequence_segments)
     ix = _single_index(config)
     num_kmers = get_num_kmers(seg, max_kmer_length)
@@ -140,6 +146,11 @@ def binary_search(config: SearchConfig, sequence_segments: Sequence[SequenceSegm
 
 def linear_search(config: SearchConfig, sequence_segments: Sequence[SequenceSegment], num_kmers: int, data_type):
     """newmap/search.py:551-644 -> (unique_lengths, ambiguous_positions_skipped), one launch."""
+    if len(sequence_segments) > 1 or len(config.fmindex_filepaths) > 1:
+        from .engine import search_segment_multi
+        indexes = [cached_index(p, config.device) for p in config.fmindex_filepaths]
+        return search_segment_multi(indexes, [s.data for s in sequence_segments], num_kmers, config.kmer_lengths,
+                                    False, config.use_reverse_complement, data_type)
     seg = _first_segment(sequence_segments)
     ix = _single_index(config)
     unique, n_amb = ix.fixed_k_segment(seg.data, num_kmers, config.kmer_lengths, config.use_reverse_complement,
@@ -193,6 +204,8 @@ def write_unique_counts(config: SearchConfig):
     kernels overlapped with parsing and file appends); NEWMAP_AMD_PYTHON_DRIVER=1 selects the
     segment-by-segment Python loop below, which produces the same files."""
     import os
+    if len(config.fasta_filepaths) > 1 or len(config.fmindex_filepaths) > 1:
+        return _write_unique_counts_multi(config)
     if os.environ.get("NEWMAP_AMD_PYTHON_DRIVER", "") != "1":
         return _write_unique_counts_native(config)
     return _write_unique_counts_python(config)
@@ -206,8 +219,6 @@ def _check_range(config: SearchConfig, min_kmer_length: int, max_kmer_length: in
             raise ValueError("math domain error: a k-mer range needs two different lengths")
         config.log("Max {} iterations over range {}-{}".format(
             ceil(log2(max_kmer_length - min_kmer_length) + 1), min_kmer_length, max_kmer_length))
-    if len(config.fasta_filepaths) != 1:
-        _first_segment([None] * len(config.fasta_filepaths))
 
 
 def _nothing_processed(config: SearchConfig):
@@ -239,6 +250,48 @@ def _write_unique_counts_native(config: SearchConfig):
                                config.include_sequence_ids, config.exclude_sequence_ids,
                                on_record if config.verbose else None)
     if total["records"] == 0:
+        _nothing_processed(config)
+
+
+def _write_unique_counts_multi(config: SearchConfig):
+    """Several FASTA files in lock-step and/or several index files (newmap/search.py:251-265, 461,
+    656-697): ids, ambiguity mask and upper bounds come from the first FASTA; the count of a position
+    is summed over every (index, sequence) pair (`nm_search_segment_multi`)."""
+    from .engine import search_segment_multi
+    max_kmer_length, min_kmer_length = max(config.kmer_lengths), min(config.kmer_lengths)
+    data_type, suffix = output_type(max_kmer_length)
+    _check_range(config, min_kmer_length, max_kmer_length)
+    indexes = [cached_index(p, config.device) for p in config.fmindex_filepaths]
+    lookahead = max_kmer_length - 1
+    requested = config.kmer_batch_size + lookahead
+    processed_any = False
+    summary = _Summary(min_kmer_length, max_kmer_length)
+    current_id, current_path = None, None
+    with ExitStack() as stack:
+        files = [stack.enter_context(optional_gzip_open(p, "rb")) for p in config.fasta_filepaths]
+        streams = [sequence_segments(f, requested, lookahead) for f in files]
+        for segs in zip(*streams):                                    # :260
+            seg = segs[0]                                             # :265
+            if seg.id != current_id:
+                if not _wanted(config, seg.id):
+                    continue
+                if current_id is not None:
+                    summary.report(config, current_id)
+                processed_any = True
+                current_id = seg.id
+                current_path = Path(config.output_directory) / UNIQUE_COUNT_FILENAME_FORMAT.format(
+                    seg.id.decode(), suffix)
+                open(current_path, "wb").close()
+                config.log(f"Writing unique lengths for sequence ID: {seg.id.decode()}")
+            num_kmers = get_num_kmers(seg, max_kmer_length)
+            arr, n_amb = search_segment_multi(indexes, [s.data for s in segs], num_kmers, config.kmer_lengths,
+                                              config.is_binary_search, config.use_reverse_complement, data_type)
+            summary.add(arr, num_kmers, n_amb)
+            with open(current_path, "ab") as fh:
+                arr.tofile(fh)
+        if current_id is not None:
+            summary.report(config, current_id)
+    if not processed_any:
         _nothing_processed(config)
 
 

@@ -402,3 +402,103 @@ def ref_binary_search_segment_c(index: OracleIndex, data: bytes, num_kmers: int,
                            "Possibly a mismatch between the sequence and the index.")
     return out[:num_kmers], int(amb.value), {"probes": int(stats[0]), "probe_len": int(stats[1]),
                                               "iterations": int(stats[2])}
+
+
+# ----------------------------------------------------------------------------- several FASTA / indexes
+# newmap/search.py:251-265 (lock-step segments of several FASTA files), :461 (num_sequences),
+# :656-697 (counts summed over index files x sequences).  Mask, upper bound and ids come from the
+# FIRST sequence (:263-265, :393-400).
+
+def total_counts_multi(indexes: Sequence[OracleIndex], seqs: Sequence[bytes], starts, lens,
+                       use_rc: bool = True) -> np.ndarray:
+    c = np.zeros(len(starts), dtype=np.uint32)
+    for ix in indexes:                                              # :656
+        for seq in seqs:                                            # :659
+            c = c + ix.count_from_sequence(seq, starts, lens)
+            if use_rc:
+                rc = seq.translate(_COMPLEMENT)[::-1]
+                c = c + ix.count_from_sequence(rc, len(seq) - np.asarray(starts, np.int64) - np.asarray(lens, np.int64), lens)
+    if c.size and not np.all(c):                                   # :702-722
+        raise RuntimeError("The following generated k-mer was not found in the index")
+    return c
+
+
+def binary_search_segments_multi(indexes, segs: Sequence[Segment], kmin: int, kmax: int, dtype,
+                                 use_rc: bool = True, max_iterations: int = 64):
+    first = segs[0]
+    ns = len(segs)                                                  # :461
+    n = num_kmers_of(first, kmax)
+    finished = ambiguity_mask(first.data, n)
+    n_amb = int(finished.sum())
+    lower = np.full(n, kmin, dtype=np.int64)
+    upper = upper_search_bound(finished, kmax, len(first.data))
+    query = (upper + lower) // 2
+    finished = finished | (upper < kmin)
+    unique = np.zeros(n, dtype=np.int64)
+    it = 0
+    while not finished.all():
+        it += 1
+        if it > max_iterations:
+            raise RuntimeError("a total strictly between 0 and num_sequences: the reference never terminates (SURVEY A.3.7)")
+        act = np.flatnonzero(~finished)
+        q = query[act]
+        cnt = total_counts_multi(indexes, [s.data for s in segs], act, q, use_rc)
+        one = cnt == ns                                             # :489-490
+        many = cnt > ns                                             # :513-514
+        u = unique[act]
+        unique[act] = np.where(one & ((u == 0) | (q < u)), q, u)
+        fin = finished[act]
+        fin = np.where(one, q == lower[act], fin)
+        fin = np.where(many, q == upper[act], fin)
+        finished[act] = fin
+        upper[act] = np.where(one, q - 1, upper[act])
+        lower[act] = np.where(many, q + 1, lower[act])
+        query[act] = (upper[act] + lower[act]) // 2
+    return unique.astype(dtype), n_amb
+
+
+def linear_search_segments_multi(indexes, segs: Sequence[Segment], kmer_lengths: Sequence[int], kmax: int,
+                                 dtype, use_rc: bool = True):
+    first = segs[0]
+    ns = len(segs)
+    data = first.data
+    n = num_kmers_of(first, kmax)
+    finished = ambiguity_mask(data, n)
+    n_amb = int(finished.sum())
+    unique = np.zeros(n, dtype=np.uint32)
+    is_N = np.frombuffer(data, dtype=np.uint8) == ord("N")
+    n_before = np.concatenate(([0], np.cumsum(is_N)))
+    for k in kmer_lengths:
+        act = np.flatnonzero(~finished)
+        end = np.minimum(act + k, len(data))
+        has_N = (n_before[end] - n_before[act]) > 0
+        finished[act[has_N]] = True
+        act = act[~has_N]
+        lens = end[~has_N] - act
+        if act.size == 0:
+            break
+        cnt = total_counts_multi(indexes, [s.data for s in segs], act, lens, use_rc)
+        u = unique[act]
+        unique[act] = np.where((cnt == ns) & (u == 0), k, u)         # :627-636
+        finished[act] = cnt == 1                                     # :639 -- literal 1
+    return unique.astype(dtype), n_amb
+
+
+def unique_counts_multi(fastas: Sequence, indexes: Sequence[OracleIndex], kmer_lengths: Sequence[int],
+                        is_binary: bool, batch: int = 10_000_000, use_rc: bool = True) -> dict[bytes, np.ndarray]:
+    kmax, kmin = max(kmer_lengths), min(kmer_lengths)
+    dtype, _ = output_dtype(kmax)
+    lookahead = kmax - 1
+    streams = [list(sequence_segments(f, batch + lookahead, lookahead)) for f in fastas]
+    out: dict[bytes, list[np.ndarray]] = {}
+    cur = None
+    for segs in zip(*streams):                                       # :260
+        if segs[0].id != cur:
+            cur = segs[0].id
+            out[cur] = []
+        if is_binary:
+            arr, _ = binary_search_segments_multi(indexes, segs, kmin, kmax, dtype, use_rc)
+        else:
+            arr, _ = linear_search_segments_multi(indexes, segs, kmer_lengths, kmax, dtype, use_rc)
+        out[cur].append(arr)
+    return {k: np.concatenate(v) for k, v in out.items()}

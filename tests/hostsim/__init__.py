@@ -36,6 +36,8 @@ def lib():
     L.hs_fixed_k.argtypes = [vp, vp, u64, u64, vp, u32, i32, i32, vp, vp]
     L.hs_count.argtypes = [vp, vp, vp, vp, u64, vp]
     L.hs_upper.argtypes = [vp, u64, u64, u32, vp]
+    L.hs_multi.restype = i32
+    L.hs_multi.argtypes = [vp, u32, vp, u32, u64, u64, u32, u32, vp, u32, i32, i32, vp, vp]
     _lib = L
     return L
 
@@ -89,3 +91,18 @@ class HostSim:
         out = np.zeros(max(num_kmers, 1), dtype=np.uint32)
         lib().hs_upper(buf.ctypes.data, buf.size, num_kmers, kmax, out.ctypes.data)
         return out[:num_kmers]
+
+
+def multi(sims, seqs, num_kmers, kmin, kmax, ks=None, use_rc=True, dtype=np.uint8):
+    """several sequences in lock-step x several indexes; ks=None: range mode"""
+    L = lib()
+    hs = (ctypes.c_void_p * len(sims))(*[s.h for s in sims])
+    bufs = [np.frombuffer(s, dtype=np.uint8) for s in seqs]
+    ptrs = (ctypes.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+    out = np.zeros(max(num_kmers, 1), dtype=dtype)
+    status = np.zeros(8, dtype=np.uint64)
+    k = np.asarray(ks if ks is not None else [], dtype=np.uint32)
+    rc = L.hs_multi(hs, len(sims), ptrs, len(bufs), len(seqs[0]), num_kmers, kmin, kmax,
+                    k.ctypes.data if k.size else None, k.size, int(use_rc), out.dtype.itemsize,
+                    out.ctypes.data, status.ctypes.data)
+    return out[:num_kmers], status, rc

@@ -160,6 +160,33 @@ void hs_count(hs_index *ix, const uint8_t *seq, const uint64_t *starts, const ui
     }
 }
 
+// several sequences in lock-step x several indexes; range mode when nk == 0
+int hs_multi(hs_index **ixs, uint32_t n_idx, const uint8_t **seqs, uint32_t n_seq, uint64_t seq_len,
+             uint64_t num_kmers, uint32_t kmin, uint32_t kmax, const uint32_t *ks, uint32_t nk, int use_rc,
+             int elem_bytes, void *out, uint64_t *status) {
+    nm_multi_args a;
+    std::vector<std::vector<nm_enc_word>> enc(n_seq);
+    a.n_idx = n_idx; a.n_seq = n_seq;
+    for (uint32_t f = 0; f < n_idx; f++) { a.view[f] = ixs[f]->v; a.view[f].seed = nullptr; a.view[f].seed_len = 0; }
+    for (uint32_t i = 0; i < n_seq; i++) { hs_encode(seqs[i], seq_len, enc[i]); a.enc[i] = enc[i].data(); }
+    for (int i = 0; i < 8; i++) status[i] = 0;
+    status[2] = ~0ULL;
+    for (uint64_t p = 0; p < num_kmers; p++) {
+        bool amb0 = false, err = false;
+        uint32_t r;
+        if (nk == 0) r = use_rc ? nm_min_unique_multi_one<true>(a, p, kmin, kmax, amb0, err)
+                                : nm_min_unique_multi_one<false>(a, p, kmin, kmax, amb0, err);
+        else         r = use_rc ? nm_fixed_k_multi_one<true>(a, p, seq_len, ks, nk, amb0, err)
+                                : nm_fixed_k_multi_one<false>(a, p, seq_len, ks, nk, amb0, err);
+        if (elem_bytes == 1) ((uint8_t *)out)[p] = (uint8_t)r;
+        else if (elem_bytes == 2) ((uint16_t *)out)[p] = (uint16_t)r;
+        else ((uint32_t *)out)[p] = r;
+        status[0] += amb0;
+        if (err) { status[1] = 1; if (p < status[2]) status[2] = p; }
+    }
+    return status[1] ? 8 : 0;
+}
+
 void hs_upper(const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmax, uint32_t *out) {
     std::vector<nm_enc_word> enc;
     hs_encode(seq, seq_len, enc);

@@ -508,3 +508,28 @@ def test_track_on_device_matches_reference(tmp_path, eng):
         os.environ.pop("NEWMAP_AMD_TRACK")
         assert out["device"][0] == out["host"][0]
         assert out["device"][1] == out["host"][1]
+
+
+def test_multi_fasta_multi_index_mode(tmp_path, eng):
+    """several FASTA files in lock-step x several indexes through write_unique_counts,
+    against fixtures written by the reference driver in that mode (tests/golden/make_golden_multi.py)"""
+    import json
+    from newmap_amd.search import SearchConfig, write_unique_counts
+    cases = json.loads((Path(__file__).resolve().parent / "golden" / "golden_multi.json").read_text())["cases"]
+    for n, c in enumerate(cases):
+        d = tmp_path / f"m{n}"
+        d.mkdir()
+        fas, idxs = [], []
+        for i, t in enumerate(c["fastas"]):
+            fa, idx = _build_index(d, t.encode("latin-1"), f"g{i}")
+            fas.append(fa)
+            idxs.append(idx)
+        out = d / "out"
+        out.mkdir()
+        write_unique_counts(SearchConfig(fasta_filepaths=fas, fmindex_filepaths=idxs, kmer_lengths=c["kmer_lengths"],
+                                         is_binary_search=c["is_binary"], kmer_batch_size=c["batch"],
+                                         output_directory=out, use_reverse_complement=c["use_reverse_complement"]))
+        for rid, e in c["expected"].items():
+            got = np.fromfile(out / f"{rid}.unique.{e['dtype']}", dtype=e["dtype"])
+            assert got.tolist() == e["values"], (c["name"], rid)
+    eng.close_all()

@@ -187,3 +187,33 @@ def test_pair_table_entries_equal_seed_entries(tmp_path):
         sim = HostSim(idx, 0, big)
         for m in (3, 5):
             assert sim.check_pair(m) == 0
+
+
+def test_core_multi_fasta_multi_index_matches_reference(tmp_path):
+    """nm_min_unique_multi_one / nm_fixed_k_multi_one (lock-step FASTA files x several indexes) against
+    fixtures written by the reference driver in that mode"""
+    import json
+    from tests import hostsim
+    cases = json.loads((ROOT_DIR / "tests" / "golden" / "golden_multi.json").read_text())["cases"]
+    for c in cases:
+        texts = [t.encode("latin-1") for t in c["fastas"]]
+        sims = []
+        for i, t in enumerate(texts):
+            fa = tmp_path / f"m{i}.fa"
+            fa.write_bytes(t)
+            idx = tmp_path / f"m{i}.awfmi"
+            generate_fm_index(str(fa), str(idx), 8, 12)
+            sims.append(HostSim(idx, 0))
+        kmin, kmax = min(c["kmer_lengths"]), max(c["kmer_lengths"])
+        dtype, _ = rd.output_dtype(kmax)
+        streams = [list(rd.sequence_segments(io.BytesIO(t).readlines(), c["batch"] + kmax - 1, kmax - 1)) for t in texts]
+        got = {}
+        for segs in zip(*streams):
+            n = rd.num_kmers_of(segs[0], kmax)
+            arr, status, rc = hostsim.multi(sims, [s.data for s in segs], n, kmin, kmax,
+                                            None if c["is_binary"] else c["kmer_lengths"],
+                                            c["use_reverse_complement"], dtype)
+            assert rc == 0
+            got.setdefault(segs[0].id, []).append(arr.copy())
+        for rid, exp in c["expected"].items():
+            assert np.concatenate(got[rid.encode()]).tolist() == exp["values"], (c["name"], rid)

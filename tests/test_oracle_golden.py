@@ -134,3 +134,18 @@ def test_sa_and_fm_counters_agree_on_random_queries():
     a = index.count_from_sequence(seq, starts, lens, fm=False)
     b = index.count_from_sequence(seq, starts, lens, fm=True)
     assert np.array_equal(a, b) and a.min() >= 1
+
+
+def test_multi_fasta_multi_index_matches_reference_driver():
+    """lock-step FASTA files x several indexes (newmap/search.py:251-265,656-697)"""
+    import json
+    cases = json.loads((GOLDEN / "golden_multi.json").read_text())["cases"]
+    for c in cases:
+        texts = [t.encode("latin-1") for t in c["fastas"]]
+        lines = [io.BytesIO(t).readlines() for t in texts]
+        indexes = [rd.OracleIndex([d for _, d in rd.read_records(l)]) for l in lines]
+        got = rd.unique_counts_multi(lines, indexes, c["kmer_lengths"], c["is_binary"], c["batch"],
+                                     c["use_reverse_complement"])
+        for rid, exp in c["expected"].items():
+            assert got[rid.encode()].dtype == np.dtype(exp["dtype"])
+            assert got[rid.encode()].tolist() == exp["values"], (c["name"], rid)

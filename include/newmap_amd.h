@@ -56,6 +56,11 @@ const char *nm_version(void);
  * device seed table built at nm_index_open time. */
 int nm_index_build(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len);
 
+/* The same build with the suffix array computed on `device` (prefix doubling over rocPRIM radix sorts,
+ * csrc/nm_build_device.hip); the index file is byte-identical to nm_index_build's.  Texts of 2^31
+ * symbols or more (genomes beyond ~1.07 Gbp) are sorted by the host sorter as in nm_index_build. */
+int nm_index_build_device(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len, int device);
+
 /* Read an index file and upload it to HBM of `device` (>= 0).  seed_len_override: -1 keeps the
  * length recorded in the file (the reference's --seed-length, default 12), -2 = automatic
  * (ceil(log4 n) + 1 bases, at most 16 and at most a quarter of the free HBM: with 288 GB the table

@@ -26,7 +26,7 @@ EXPORTS = [
     "nm_index_info", "nm_count_kmers", "nm_count_from_sequence", "nm_min_unique_segment",
     "nm_fixed_k_segment", "nm_upper_bound_segment", "nm_min_unique_segment_dev",
     "nm_fixed_k_segment_dev", "nm_set_option", "nm_dev_alloc", "nm_dev_free", "nm_dev_upload",
-    "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read", "nm_search_fasta", "nm_track_file", "nm_search_segment_multi",
+    "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read", "nm_search_fasta", "nm_track_file", "nm_search_segment_multi", "nm_index_build_device",
 ]
 
 _lib = None
@@ -93,6 +93,8 @@ def lib():
     L.nm_version.restype = c.c_char_p
     L.nm_index_build.restype = i32
     L.nm_index_build.argtypes = [c.c_char_p, c.c_char_p, u8, u8]
+    L.nm_index_build_device.restype = i32
+    L.nm_index_build_device.argtypes = [c.c_char_p, c.c_char_p, u8, u8, i32]
     L.nm_index_open.restype = i32
     L.nm_index_open.argtypes = [c.c_char_p, i32, i32, pp]
     L.nm_index_close.restype = None

@@ -121,7 +121,8 @@ int read_fasta(const char *path, FastaText &ft) {
 }
 
 template <class I>
-int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_ratio, uint8_t seed_len) {
+int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_ratio, uint8_t seed_len,
+                    nm_sa32_provider provider = nullptr, void *provider_ctx = nullptr) {
     const uint64_t nf = ft.f.size();
     const uint64_t n = 2 * nf + 1;
     // T = F . RC . '#'
@@ -145,9 +146,13 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
     {
         const char *want = getenv("NEWMAP_AMD_SA");
         const bool use_pd = want ? strcmp(want, "pd") == 0 : (nm::pd_threads() > 1 && n > (1u << 16));
-        if (use_pd) nm::pd_suffix_array<I>(T.data(), n, SA.data());
+        if (provider && sizeof(I) == 4) {
+            // suffix array computed elsewhere (the device builder, nm_build_device.hip)
+            int rc = provider(T.data(), n, (int32_t *)SA.data(), provider_ctx);
+            if (rc != NM_OK) return rc;
+        } else if (use_pd) nm::pd_suffix_array<I>(T.data(), n, SA.data());
         else nm::sais<uint8_t, I>(T.data(), SA.data(), (I)n, (I)6);
-        if (verbose) { fprintf(stderr, "[build] suffix array (%s, %d threads): %.2fs\n", use_pd ? "prefix doubling" : "SA-IS", nm::pd_threads(), nm::pd_now() - tv); tv = nm::pd_now(); }
+        if (verbose) { fprintf(stderr, "[build] suffix array (%s, %d threads): %.2fs\n", provider ? "device prefix doubling" : (use_pd ? "prefix doubling" : "SA-IS"), nm::pd_threads(), nm::pd_now() - tv); tv = nm::pd_now(); }
     }
 
     nm_file_header h;
@@ -272,7 +277,8 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
 
 }  // namespace
 
-extern "C" int nm_index_build(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len) {
+int nm_index_build_impl(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len,
+                        nm_sa32_provider provider, void *provider_ctx) {
     if (!fasta_path || !index_path) { nm_set_error("null path"); return NM_E_ARGUMENT; }
     if (seed_len > 16) { nm_set_error("seed length %d is larger than the supported maximum 16", (int)seed_len); return NM_E_ARGUMENT; }
     try {
@@ -285,8 +291,8 @@ extern "C" int nm_index_build(const char *fasta_path, const char *index_path, ui
         int rc = read_fasta(fasta_path, ft);
         if (rc != NM_OK) return rc;
         const uint64_t n = 2 * (uint64_t)ft.f.size() + 1;
-        if (n < (1ULL << 31) - 8) return build_and_write<int32_t>(ft, index_path, sa_ratio, seed_len);
-        return build_and_write<int64_t>(ft, index_path, sa_ratio, seed_len);
+        if (n < (1ULL << 31) - 8) return build_and_write<int32_t>(ft, index_path, sa_ratio, seed_len, provider, provider_ctx);
+        return build_and_write<int64_t>(ft, index_path, sa_ratio, seed_len);   // beyond 2^31 symbols: host sorter
     } catch (const std::bad_alloc &) {
         nm_set_error("Could not allocate enough memory to create index");
         return NM_E_ALLOC;
@@ -294,4 +300,8 @@ extern "C" int nm_index_build(const char *fasta_path, const char *index_path, ui
         nm_set_error("index build failed: %s", e.what());
         return NM_E_FILE_WRITE;
     }
+}
+
+extern "C" int nm_index_build(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len) {
+    return nm_index_build_impl(fasta_path, index_path, sa_ratio, seed_len, nullptr, nullptr);
 }

@@ -4,7 +4,12 @@
 #ifdef __cplusplus
 extern "C++" {
 #endif
+#include <stdint.h>
 void nm_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+// suffix array of T[0..n) (symbols 0..5, T[n-1] == 0 unique) supplied by another translation unit
+typedef int (*nm_sa32_provider)(const uint8_t *T, uint64_t n, int32_t *SA, void *ctx);
+int nm_index_build_impl(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len,
+                        nm_sa32_provider provider, void *provider_ctx);
 #ifdef __cplusplus
 }
 #endif

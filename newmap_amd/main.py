@@ -46,6 +46,8 @@ def build_parser() -> ArgumentParser:
     g.add_argument("--seed-length", "-s", type=int, default=DEFAULT_SEED_LENGTH, metavar="LENGTH",
                    help="Length of k-mers memoized in the device seed table (4^LENGTH entries of 8 bytes "
                         f"in HBM, built when the index is opened). (default: {DEFAULT_SEED_LENGTH})")
+    g.add_argument("--device", "-d", type=int, default=None, metavar="GPU",
+                   help="sort the suffixes on this MI355X instead of the host cores (same index file)")
 
     p = sub.add_parser(UNIQUE_LENGTHS_SUBCOMMAND,
                        help="Find the shortest unique sequence length at each position in sequences")

@@ -533,3 +533,25 @@ def test_multi_fasta_multi_index_mode(tmp_path, eng):
             got = np.fromfile(out / f"{rid}.unique.{e['dtype']}", dtype=e["dtype"])
             assert got.tolist() == e["values"], (c["name"], rid)
     eng.close_all()
+
+
+def test_device_index_builder_writes_the_same_file(tmp_path, eng):
+    """suffix array by prefix doubling on the GPU (rocPRIM radix sorts) -> index file
+    byte-identical to the host builder's, on uniform, repeat-heavy and multi-record inputs"""
+    from newmap_amd import synth
+    from newmap_amd._c_newmap_generate_index import generate_fm_index
+    rng = np.random.default_rng(17)
+    inputs = {
+        "uniform": b">u\n" + synth.config_genome("c2", 3.0)[0][1].tobytes() + b"\n",
+        "tandem": b">t\n" + synth.tandem_dna(2_000_000, 5).tobytes() + b"\n",
+        "mixed": (b">a x\n" + _random_dna(rng, 300_000) + b"NNNN" + b"A" * 50_000 + b"\n>b\n" + b"ACG" * 40_000 +
+                  _random_dna(rng, 100_000).lower() + b"\n>c\nT\n"),
+        "tiny": b">x\nACGT\n",
+    }
+    for name, text in inputs.items():
+        fa = tmp_path / f"{name}.fa"
+        fa.write_bytes(text)
+        host, dev = tmp_path / f"{name}.host.awfmi", tmp_path / f"{name}.dev.awfmi"
+        generate_fm_index(str(fa), str(host), 8, 12)
+        generate_fm_index(str(fa), str(dev), 8, 12, device=0)
+        assert host.read_bytes() == dev.read_bytes(), name

@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--seed-length", default="auto",
                     help="device seed table length: auto (default, ceil(log4 n)+1), file (the index's, 12), or 0..16")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--index-builder", choices=["host", "device"], default="host",
+                    help="suffix sort on the host cores (default) or on the GPU (same index file; not timed in `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--workdir", default=os.environ.get("NEWMAP_AMD_BENCH_DIR", "/tmp/newmap_amd_bench"))
@@ -70,7 +72,7 @@ def prepare_workload(args, rank, world, barrier):
     """rank 0 generates the FASTA and builds the index; everybody then opens the same file"""
     from newmap_amd import synth
     from newmap_amd._c_newmap_generate_index import generate_fm_index
-    wd = Path(args.workdir) / f"{args.config}_{args.mbp:g}mbp"
+    wd = Path(args.workdir) / f"{args.config}_{args.mbp:g}mbp_{args.index_builder}"
     fa, idx = wd / "genome.fa", wd / "genome.awfmi"
     t_gen = t_build = 0.0
     t0 = time.time()
@@ -84,7 +86,7 @@ def prepare_workload(args, rank, world, barrier):
             synth.write_fasta(fa, recs)
             t_gen = time.time() - t0
             t0 = time.time()
-            generate_fm_index(str(fa), str(idx), 8, 12)
+            generate_fm_index(str(fa), str(idx), 8, 12, device=0 if args.index_builder == "device" else None)
             t_build = time.time() - t0
             (wd / "ok").write_text("ok")
             log(f"[bench] wrote {fa} ({t_gen:.1f}s), built index ({t_build:.1f}s, {idx.stat().st_size / 1e6:.0f} MB)")

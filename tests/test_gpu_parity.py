@@ -555,3 +555,36 @@ def test_device_index_builder_writes_the_same_file(tmp_path, eng):
         generate_fm_index(str(fa), str(host), 8, 12)
         generate_fm_index(str(fa), str(dev), 8, 12, device=0)
         assert host.read_bytes() == dev.read_bytes(), name
+
+
+def test_cli_end_to_end(tmp_path):
+    """reference tests/test_end_to_end.sh, with assertions: `index`, `search`, `track` through the CLI"""
+    import json
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    golden = root / "tests" / "golden"
+    env = dict(os.environ, PYTHONPATH=str(root))
+
+    def cli(*args):
+        return subprocess.run([sys.executable, "-m", "newmap_amd.main", *args], cwd=tmp_path, env=env, check=True,
+                              capture_output=True)
+
+    cli("index", "--compression-ratio=32", "--seed-length=1", str(golden / "genome.fa"))
+    assert (tmp_path / "genome.awfmi").read_bytes()[:8] == b"NMAPGFX1"          # index.py:12-15 default name
+    cli("search", "--search-range=4:10", "--kmer-batch-size=15", "--verbose", str(golden / "genome.fa"), "genome.awfmi")
+    chr1 = np.fromfile(tmp_path / "chr1.unique.uint8", dtype=np.uint8).tolist()
+    chr2 = np.fromfile(tmp_path / "chr2.unique.uint8", dtype=np.uint8).tolist()
+    assert chr1 == [0, 10, 9, 8, 7, 6, 5, 4, 4, 4, 6, 5, 4, 4, 4, 0, 0, 0, 0, 0]       # tests/test_unique_counts.py:17-21
+    assert chr2 == [10, 10, 9, 8, 7, 6, 5, 4, 4, 4] + [0] * 20
+    cli("track", "10", "--multi-read", "genome.10.wig", "--single-read", "genome.10.bed",
+        "chr1.unique.uint8", "chr2.unique.uint8")
+    want = [c for c in json.loads((golden / "golden_track.json").read_text())["cases"] if c["k"] == 10][0]
+    got_bed = (tmp_path / "genome.10.bed").read_text().splitlines()
+    want_bed = [l for l in want["bed"].splitlines() if l.startswith(("chr1\t", "chr2\t"))]
+    assert got_bed == want_bed
+    bed_stdout = cli("track", "chr1.unique.uint8").stdout.decode()              # k defaults to 24, BED to stdout
+    assert bed_stdout.startswith("chr1\t0\t")
+    # list mode and a fixed k through the CLI
+    cli("search", "--search-range=4,6,10", "-o", "lin", str(golden / "genome.fa"), "genome.awfmi")
+    assert (tmp_path / "lin" / "chr1.unique.uint8").stat().st_size == 20

@@ -577,7 +577,7 @@ def test_cli_end_to_end(tmp_path):
     chr2 = np.fromfile(tmp_path / "chr2.unique.uint8", dtype=np.uint8).tolist()
     assert chr1 == [0, 10, 9, 8, 7, 6, 5, 4, 4, 4, 6, 5, 4, 4, 4, 0, 0, 0, 0, 0]       # tests/test_unique_counts.py:17-21
     assert chr2 == [10, 10, 9, 8, 7, 6, 5, 4, 4, 4] + [0] * 20
-    cli("track", "10", "--multi-read", "genome.10.wig", "--single-read", "genome.10.bed",
+    cli("track", "--multi-read", "genome.10.wig", "--single-read", "genome.10.bed", "10",
         "chr1.unique.uint8", "chr2.unique.uint8")
     want = [c for c in json.loads((golden / "golden_track.json").read_text())["cases"] if c["k"] == 10][0]
     got_bed = (tmp_path / "genome.10.bed").read_text().splitlines()

@@ -480,7 +480,7 @@ NM_HD uint64_t nm_pair_entry(const nm_view &ix, uint64_t slot, uint32_t m, uint3
     }
     uint64_t cnt = hi > lo ? hi - lo : 0;
     if (cnt >= NM_SEED_CNT_SAT) cnt = NM_SEED_CNT_SAT;
-    return (lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS);
+    return cnt ? ((lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS)) : 0;     // empty intervals are stored as 0
 }
 
 // seed-table entry of slot `slot`: interval of the reverse complement of the s-mer it spells
@@ -494,7 +494,37 @@ NM_HD uint64_t nm_seed_entry(const nm_view &ix, uint64_t slot, uint32_t s) {
     }
     uint64_t cnt = hi > lo ? hi - lo : 0;
     if (cnt >= NM_SEED_CNT_SAT) cnt = NM_SEED_CNT_SAT;
-    return (lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS);
+    return cnt ? ((lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS)) : 0;     // empty intervals are stored as 0
+}
+
+// ---- level-wise table construction: an s-mer's interval is ONE LF step away from the interval of
+// its first s-1 bases, so level s is derived from level s-1 instead of walking s steps per entry
+NM_HD uint64_t nm_seed_parent_slot(uint64_t slot, uint32_t s) {
+    const uint64_t m = (1ULL << (s - 1)) - 1ULL;
+    return (slot & m) | (((slot >> s) & m) << (s - 1));
+}
+
+template <bool BIG>
+NM_HD uint64_t nm_seed_entry_from_parent(const nm_view &ix, uint64_t parent_entry, uint64_t slot, uint32_t s) {
+    const uint32_t pc = (uint32_t)(parent_entry >> NM_SEED_LO_BITS);
+    if (pc == NM_SEED_CNT_SAT) return nm_seed_entry<BIG>(ix, slot, s);      // parent size unknown: walk
+    if (pc == 0) return 0;
+    uint64_t lo = parent_entry & NM_SEED_LO_MASK, hi = lo + pc;
+    const uint32_t c = 3u - nm_seed_slot_code(slot, s, s - 1);
+    lo = nm_lf<BIG>(ix, c, lo);
+    hi = nm_lf<BIG>(ix, c, hi);
+    const uint64_t cnt = hi > lo ? hi - lo : 0;                              // < parent's, so not saturated
+    return cnt ? ((lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS)) : 0;
+}
+
+// seed-table slot (level m+1) of the (m+1)-mer a pair-table entry stands for
+NM_HD uint64_t nm_pair_seed_slot(uint64_t core_slot, uint32_t m, uint32_t e) {
+    const uint32_t s = m + 1;
+    const uint64_t mask = (1ULL << m) - 1ULL;
+    const uint64_t ylo = core_slot & mask, yhi = core_slot >> m;
+    if (e < 4) return (uint64_t)(e & 1u) | (ylo << 1) | ((uint64_t)(e >> 1) << s) | (yhi << (s + 1));
+    const uint32_t b = e - 4;
+    return ylo | ((uint64_t)(b & 1u) << m) | (yhi << s) | ((uint64_t)(b >> 1) << (s + m));
 }
 
 #endif

@@ -357,6 +357,21 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
     }
 }
 
+// level s of the seed table from level s-1 (one LF step per entry instead of s)
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_seed_level(nm_view ix, const uint64_t *__restrict__ parent, uint64_t *__restrict__ table,
+                                                         uint64_t first_slot, uint64_t n_slots, uint32_t s) {
+    const uint64_t slot = first_slot + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (slot < n_slots) table[slot] = nm_seed_entry_from_parent<BIG>(ix, parent[nm_seed_parent_slot(slot, s)], slot, s);
+}
+
+// the pair table is a rearrangement of the seed table of level m+1
+__global__ __launch_bounds__(NM_BLOCK) void k_pair_gather(const uint64_t *__restrict__ seed, uint64_t *__restrict__ table,
+                                                          uint64_t first, uint64_t n_entries, uint32_t m) {
+    const uint64_t i = first + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (i < n_entries) table[i] = seed[nm_pair_seed_slot(i >> 3, m, (uint32_t)(i & 7))];
+}
+
 template <bool BIG>
 __global__ __launch_bounds__(NM_BLOCK) void k_pair(nm_view ix, uint64_t *__restrict__ table, uint64_t first,
                                                    uint64_t n_entries, uint32_t m) {
@@ -643,6 +658,25 @@ extern "C" int nm_device_count(void) {
 }
 
 // build the 4^s table on the device; launches are sliced so that grid * block stays below 2^32
+static int nm_seed_launch(nm_index *ix, const nm_view &v, const uint64_t *parent, uint64_t *table, uint32_t s) {
+    const uint64_t n_slots = 1ULL << (2 * s), slice = 1ULL << 30;
+    for (uint64_t first = 0; first < n_slots; first += slice) {
+        const uint64_t m = n_slots - first < slice ? n_slots - first : slice;
+        const dim3 grid(nm_grid(m)), block(NM_BLOCK);
+        if (parent) {
+            if (ix->big) hipLaunchKernelGGL(k_seed_level<true>, grid, block, 0, ix->stream, v, parent, table, first, n_slots, s);
+            else         hipLaunchKernelGGL(k_seed_level<false>, grid, block, 0, ix->stream, v, parent, table, first, n_slots, s);
+        } else {
+            if (ix->big) hipLaunchKernelGGL(k_seed<true>, grid, block, 0, ix->stream, v, table, first, n_slots, s);
+            else         hipLaunchKernelGGL(k_seed<false>, grid, block, 0, ix->stream, v, table, first, n_slots, s);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return NM_OK;
+}
+
+// build the 4^s table on the device: level 8 entry by entry, every further level from the one
+// below it (launches sliced so that grid * block stays below 2^32)
 static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table) {
     const uint64_t n_slots = 1ULL << (2 * s);
     HIP_TRY(hipMalloc(d_table, n_slots * sizeof(uint64_t)));
@@ -650,22 +684,26 @@ static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table) {
     nm_view v = ix->view;
     v.seed = nullptr;
     v.seed_len = 0;
-    const uint64_t slice = 1ULL << 30;
-    for (uint64_t first = 0; first < n_slots; first += slice) {
-        const uint64_t m = n_slots - first < slice ? n_slots - first : slice;
-        if (ix->big) hipLaunchKernelGGL(k_seed<true>, dim3(nm_grid(m)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)*d_table, first, n_slots, s);
-        else         hipLaunchKernelGGL(k_seed<false>, dim3(nm_grid(m)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)*d_table, first, n_slots, s);
-        HIP_TRY(hipGetLastError());
+    const uint32_t s0 = s < 8 ? s : 8;
+    void *cur = nullptr;
+    int rc = NM_OK;
+    for (uint32_t level = s0; level <= s && rc == NM_OK; level++) {
+        void *dst = *d_table;
+        if (level < s && hipMalloc(&dst, (8ULL << (2 * level))) != hipSuccess) { nm_set_error("hipMalloc failed for a seed level"); rc = NM_E_ALLOC; break; }
+        rc = nm_seed_launch(ix, v, level == s0 ? nullptr : (const uint64_t *)cur, (uint64_t *)dst, level);
+        if (rc == NM_OK && hipStreamSynchronize(ix->stream) != hipSuccess) { nm_set_error("seed table kernel failed"); rc = NM_E_DEVICE; }
+        if (cur) (void)hipFree(cur);
+        cur = level < s ? dst : nullptr;
     }
-    HIP_TRY(hipStreamSynchronize(ix->stream));
-    return NM_OK;
+    if (cur) (void)hipFree(cur);
+    return rc;
 }
 
-// seed length that makes most positions resolve in the table: one more base than log4(n)
+// seed length that makes nearly all positions resolve in the table: two more bases than log4(n)
 static uint32_t nm_auto_seed_len(const nm_index *ix) {
     uint32_t s = 1;
     while (s < 16 && (1ULL << (2 * s)) < ix->h.n) s++;     // s = ceil(log4 n)
-    uint32_t bonus = 1;                                   // NEWMAP_AMD_SEED_BONUS: measurement knob
+    uint32_t bonus = 2;                                   // NEWMAP_AMD_SEED_BONUS: measurement knob
     if (const char *b = getenv("NEWMAP_AMD_SEED_BONUS")) bonus = (uint32_t)atoi(b);
     s = s + bonus > 16 ? 16 : s + bonus;
     if (s < 4) s = 4;
@@ -687,9 +725,11 @@ static int nm_build_pair(nm_index *ix, uint32_t m) {
     v.seed = nullptr;
     v.seed_len = 0;
     const uint64_t slice = 1ULL << 30;
+    const bool gather = ix->view.seed && ix->view.seed_len == m + 1;      // rearrange the seed table
     for (uint64_t first = 0; first < n_entries; first += slice) {
         const uint64_t cnt = n_entries - first < slice ? n_entries - first : slice;
-        if (ix->big) hipLaunchKernelGGL(k_pair<true>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_pair, first, n_entries, m);
+        if (gather) hipLaunchKernelGGL(k_pair_gather, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, ix->view.seed, (uint64_t *)ix->d_pair, first, n_entries, m);
+        else if (ix->big) hipLaunchKernelGGL(k_pair<true>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_pair, first, n_entries, m);
         else         hipLaunchKernelGGL(k_pair<false>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_pair, first, n_entries, m);
         HIP_TRY(hipGetLastError());
     }

@@ -19,13 +19,15 @@ def lib():
     stale = (not _SO.exists() or _SO.stat().st_mtime < max(src.stat().st_mtime, core.stat().st_mtime))
     if stale:
         _SO.parent.mkdir(exist_ok=True)
-        subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", str(_SO), str(src)],
+        subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-o", str(_SO), str(src)],
                        check=True)
     L = ctypes.CDLL(str(_SO))
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
     L.hs_open.restype = vp
     L.hs_open.argtypes = [ctypes.c_char_p, i32, i32]
     L.hs_close.argtypes = [vp]
+    L.hs_check_levels.restype = u64
+    L.hs_check_levels.argtypes = [vp, u32]
     L.hs_check_pair.restype = u64
     L.hs_check_pair.argtypes = [vp, u32]
     L.hs_info.restype = u64
@@ -53,6 +55,9 @@ class HostSim:
         if getattr(self, "h", None):
             self.L.hs_close(self.h)
             self.h = None
+
+    def check_levels(self, s):
+        return int(self.L.hs_check_levels(self.h, s))
 
     def check_pair(self, m):
         return int(self.L.hs_check_pair(self.h, m))

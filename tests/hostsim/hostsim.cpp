@@ -88,6 +88,7 @@ uint64_t hs_check_pair(hs_index *ix, uint32_t m) {
             uint64_t sl;
             if (e < 4) sl = (uint64_t)(e & 1) | (ylo << 1) | ((uint64_t)(e >> 1) << s) | (yhi << (s + 1));
             else { const uint32_t b = e - 4; sl = ylo | ((uint64_t)(b & 1) << m) | (yhi << s) | ((uint64_t)(b >> 1) << (s + m)); }
+            if (sl != nm_pair_seed_slot(slot, m, e)) bad++;
             const uint64_t want = ix->big ? nm_seed_entry<true>(ix->v, sl, s) : nm_seed_entry<false>(ix->v, sl, s);
             const uint64_t got = ix->big ? nm_pair_entry<true>(ix->v, slot, m, e) : nm_pair_entry<false>(ix->v, slot, m, e);
             // an empty interval may sit anywhere: compare sizes, and starts only when non-empty
@@ -97,6 +98,21 @@ uint64_t hs_check_pair(hs_index *ix, uint32_t m) {
     }
     return bad;
 }
+// level-wise seed construction must reproduce the entry-by-entry one
+uint64_t hs_check_levels(hs_index *ix, uint32_t s) {
+    uint64_t bad = 0;
+    std::vector<uint64_t> parent(1ULL << (2 * (s - 1)));
+    for (uint64_t slot = 0; slot < parent.size(); slot++)
+        parent[slot] = ix->big ? nm_seed_entry<true>(ix->v, slot, s - 1) : nm_seed_entry<false>(ix->v, slot, s - 1);
+    for (uint64_t slot = 0; slot < (1ULL << (2 * s)); slot++) {
+        const uint64_t p = parent[nm_seed_parent_slot(slot, s)];
+        const uint64_t got = ix->big ? nm_seed_entry_from_parent<true>(ix->v, p, slot, s) : nm_seed_entry_from_parent<false>(ix->v, p, slot, s);
+        const uint64_t want = ix->big ? nm_seed_entry<true>(ix->v, slot, s) : nm_seed_entry<false>(ix->v, slot, s);
+        if (got != want) bad++;
+    }
+    return bad;
+}
+
 uint64_t hs_info(hs_index *ix, int what) {
     switch (what) { case 0: return ix->h.n; case 1: return ix->h.n_fwd; case 2: return ix->h.n_sep;
                     case 3: return ix->h.n_records; case 4: return ix->h.raw_bases; case 5: return ix->v.seed_len;

@@ -187,6 +187,8 @@ def test_pair_table_entries_equal_seed_entries(tmp_path):
         sim = HostSim(idx, 0, big)
         for m in (3, 5):
             assert sim.check_pair(m) == 0
+        for level in (2, 4, 6):                                # level-wise seed construction == entry by entry
+            assert sim.check_levels(level) == 0
 
 
 def test_core_multi_fasta_multi_index_matches_reference(tmp_path):

@@ -50,6 +50,8 @@ struct nm_view {                // the index as the kernels see it
     uint32_t seed_policy;       // experiment knob: cache policy of the seed-table load (0 = default)
     uint32_t pair_m;            // core length of the pair table (0 = none)
     const uint64_t *pair;       // 4^pair_m blocks of 8 entries: [a] interval of a.Y, [4+b] interval of Y.b
+    const nm_rank2_block *rank2;   // two-step rank blocks (nullptr = not built)
+    const uint64_t *superC2;    // [n_super][16]: first row of the suffixes starting "y x" + pairs before the superblock
 };
 
 struct nm_tally {               // counter build only
@@ -116,6 +118,33 @@ NM_HD uint64_t nm_strand_rank(const nm_view &ix, uint64_t i) {
 }
 NM_HD bool nm_strand_bit(const nm_view &ix, uint64_t i) {
     return (ix.strand[i >> 6].bits >> (i & 63)) & 1ULL;
+}
+
+// is BWT row i a base (not a separator), and which one
+NM_HD bool nm_bwt_code(const nm_view &ix, uint64_t i, uint32_t &code) {
+    const nm_rank_block *b = ix.rank + (i >> 6);
+    const uint32_t off = (uint32_t)(i & 63);
+    code = (uint32_t)((b->lo >> off) & 1ULL) | ((uint32_t)((b->hi >> off) & 1ULL) << 1);
+    if (b->cnt[0] & NM_SEP_FLAG) return nm_sep_between(ix, i, i + 1) == 0;
+    return true;
+}
+
+// one step and two steps from the same 128-byte block: out1 = LF_x(i), out2 = LF_y(LF_x(i))
+NM_HD void nm_lf12(const nm_view &ix, uint32_t x, uint32_t y, uint64_t i, uint64_t &out1, uint64_t &out2) {
+    const nm_rank2_block *b = ix.rank2 + (i >> 6);
+    const uint64_t low = (1ULL << (i & 63)) - 1ULL;
+    const uint64_t m1 = ((x & 1u) ? b->c1lo : ~b->c1lo) & ((x & 2u) ? b->c1hi : ~b->c1hi) & low;
+    const uint64_t m2 = ((y & 1u) ? b->c2lo : ~b->c2lo) & ((y & 2u) ? b->c2hi : ~b->c2hi);
+    const uint64_t sb = i >> NM_SUPER_SHIFT;
+    out1 = ix.superC[sb * 4 + x] + b->cnt1[x] + nm_popc64(b->valid1 & m1);
+    out2 = ix.superC2[sb * 16 + x * 4 + y] + b->cnt2[x * 4 + y] + nm_popc64(b->valid2 & m1 & m2);
+}
+
+NM_HD uint64_t nm_lf1_r2(const nm_view &ix, uint32_t x, uint64_t i) {
+    const nm_rank2_block *b = ix.rank2 + (i >> 6);
+    const uint64_t low = (1ULL << (i & 63)) - 1ULL;
+    const uint64_t m1 = ((x & 1u) ? b->c1lo : ~b->c1lo) & ((x & 2u) ? b->c1hi : ~b->c1hi) & low;
+    return ix.superC[(i >> NM_SUPER_SHIFT) * 4 + x] + b->cnt1[x] + nm_popc64(b->valid1 & m1);
 }
 
 struct nm_window { uint64_t lo, hi, amb; };      // sequence positions [pos, pos+64)
@@ -205,6 +234,52 @@ NM_HD uint32_t nm_min_unique_walk(const nm_view &ix, const nm_enc_word *enc, uin
     return ans;
 }
 
+// The same walk, two bases per memory round trip (both strands only): each iteration reads the two-step
+// rank blocks of lo and hi (one 128-byte line each) and obtains the intervals after one AND after two
+// more bases, so the first length with a single occurrence is still found exactly.
+NM_HD uint32_t nm_min_unique_walk2(const nm_view &ix, const nm_enc_word *enc, uint64_t p, nm_window w,
+                                   uint32_t kbase, uint64_t lo, uint64_t hi, uint32_t k, uint32_t kmin,
+                                   uint32_t kmax, bool &err, nm_tally &t) {
+    for (;;) {
+        const uint64_t cnt = hi - lo;
+        if (cnt == 0) { err = true; return 0; }
+        if (cnt == 1) break;
+        if (k >= kmax) return 0;
+        uint32_t j = k - kbase;
+        if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+        if ((w.amb >> j) & 1ULL) return 0;
+        const uint32_t x = 3u - nm_window_code(w, j);
+        const bool two = j < 63 && k + 1 < kmax && !((w.amb >> (j + 1)) & 1ULL);
+        t.blocks += ((lo >> 6) == (hi >> 6)) ? 4u : 8u;    // 128-byte blocks, counted in 32-byte units
+        if (!two) {
+            lo = nm_lf1_r2(ix, x, lo);
+            hi = nm_lf1_r2(ix, x, hi);
+            k++;
+            t.steps++;
+            continue;
+        }
+        const uint32_t y = 3u - nm_window_code(w, j + 1);
+        uint64_t lo1, lo2, hi1, hi2;
+        nm_lf12(ix, x, y, lo, lo1, lo2);
+        nm_lf12(ix, x, y, hi, hi1, hi2);
+        t.steps += 2;
+        if (hi1 - lo1 <= 1) { lo = lo1; hi = hi1; k += 1; continue; }    // decided after ONE base (0 -> err, 1 -> found)
+        lo = lo2; hi = hi2; k += 2;
+    }
+    const uint32_t ans = k > kmin ? k : kmin;
+    if (!nm_all_valid(enc, p, w, kbase, k, ans)) return 0;
+    return ans;
+}
+
+// picks the two-step walk when its blocks exist (both-strand searches)
+template <bool BIG, bool RC>
+NM_HD uint32_t nm_min_unique_walk_any(const nm_view &ix, const nm_enc_word *enc, uint64_t p, const nm_window &w,
+                                      uint64_t lo, uint64_t hi, uint32_t k, uint32_t kmin, uint32_t kmax,
+                                      bool &err, nm_tally &t) {
+    if (RC && ix.rank2) return nm_min_unique_walk2(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);
+    return nm_min_unique_walk<BIG, RC>(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);
+}
+
 // Range mode, first half: what the window alone decides.  Returns true when the position is
 // settled without touching the index (result 0): its own byte is ambiguous (amb0), or an ambiguous
 // byte sits inside the first s <= kmin bases (U_p < kmin, search.py:437).
@@ -244,7 +319,7 @@ NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint
         if (nm_seed_decode(NM_SEED_LOAD(ix, nm_seed_slot(w, s)), lo, hi)) k = s;
         else { lo = 0; hi = ix.n; }
     }
-    return nm_min_unique_walk<BIG, RC>(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);
+    return nm_min_unique_walk_any<BIG, RC>(ix, enc, p, w, lo, hi, k, kmin, kmax, err, t);
 }
 
 // One position of list mode.

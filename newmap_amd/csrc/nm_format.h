@@ -39,6 +39,16 @@ struct nm_rank_block {             /* 32 bytes, 64 BWT positions */
     uint64_t lo, hi;
 };
 
+/* Two-step rank block, built on the device when the index is opened (not stored in the file):
+ * one 128-byte line per 64 BWT positions that answers BOTH "prepend x" and "prepend x, then y".
+ * c1 = BWT[i] (the base in front of suffix i), c2 = BWT[LF(i)] (the base in front of that). */
+struct nm_rank2_block {
+    uint32_t cnt2[16];             /* rows before the block with (c1, c2) = (t >> 2, t & 3), superblock-relative */
+    uint32_t cnt1[4];              /* rows before the block with c1 = c, superblock-relative */
+    uint64_t c1lo, c1hi, c2lo, c2hi;
+    uint64_t valid1, valid2;       /* c1 is a base; c1 and c2 are both bases */
+};
+
 struct nm_strand_block {           /* 16 bytes, 64 suffix-array positions */
     uint64_t before;
     uint64_t bits;
@@ -67,6 +77,7 @@ struct nm_file_header {            /* 1024 bytes */
 #ifdef __cplusplus
 static_assert(sizeof(nm_rank_block) == 32, "rank block must be 32 bytes");
 static_assert(sizeof(nm_strand_block) == 16, "strand block must be 16 bytes");
+static_assert(sizeof(nm_rank2_block) == 128, "two-step rank block must be one 128-byte line");
 static_assert(sizeof(nm_file_header) == 1024, "header must be 1024 bytes");
 #endif
 

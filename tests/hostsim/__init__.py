@@ -26,6 +26,9 @@ def lib():
     L.hs_open.restype = vp
     L.hs_open.argtypes = [ctypes.c_char_p, i32, i32]
     L.hs_close.argtypes = [vp]
+    L.hs_enable_rank2.argtypes = [vp, i32]
+    L.hs_check_rank2.restype = u64
+    L.hs_check_rank2.argtypes = [vp, u64]
     L.hs_check_levels.restype = u64
     L.hs_check_levels.argtypes = [vp, u32]
     L.hs_check_pair.restype = u64
@@ -55,6 +58,12 @@ class HostSim:
         if getattr(self, "h", None):
             self.L.hs_close(self.h)
             self.h = None
+
+    def enable_rank2(self, on=True):
+        self.L.hs_enable_rank2(self.h, int(on))
+
+    def check_rank2(self, stride=1):
+        return int(self.L.hs_check_rank2(self.h, stride))
 
     def check_levels(self, s):
         return int(self.L.hs_check_levels(self.h, s))

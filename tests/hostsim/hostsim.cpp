@@ -16,10 +16,50 @@ struct hs_index {
     nm_file_header h;
     std::vector<nm_rank_block> rank;
     std::vector<nm_strand_block> strand;
-    std::vector<uint64_t> sep, seed, superC;
+    std::vector<uint64_t> sep, seed, superC, superC2;
+    std::vector<nm_rank2_block> rank2;
     nm_view v;
     bool big;
 };
+
+// host mirror of the device construction of the two-step rank blocks (nm_engine.hip: k_rank2_*)
+static void hs_build_rank2(hs_index *ix) {
+    const nm_view &v = ix->v;
+    const uint64_t n = v.n, nblk = n / 64 + 1;
+    ix->rank2.assign(nblk, nm_rank2_block{});
+    std::vector<uint64_t> run(20, 0);                       // running absolute counts: 16 pairs + 4 singles
+    std::vector<std::vector<uint64_t>> at_super;            // absolute counts at superblock starts
+    const uint64_t per_super = 1ULL << (NM_SUPER_SHIFT - 6);
+    std::vector<uint64_t> sup(20, 0);
+    for (uint64_t b = 0; b < nblk; b++) {
+        if (b % per_super == 0) { sup = run; at_super.push_back(run); }
+        nm_rank2_block &r = ix->rank2[b];
+        for (int t = 0; t < 16; t++) r.cnt2[t] = (uint32_t)(run[t] - sup[t]);
+        for (int c = 0; c < 4; c++) r.cnt1[c] = (uint32_t)(run[16 + c] - sup[16 + c]);
+        for (uint64_t i = b * 64; i < b * 64 + 64 && i < n; i++) {
+            uint32_t c1 = 0, c2 = 0;
+            const bool v1 = nm_bwt_code(v, i, c1);
+            bool v2 = false;
+            if (v1) {
+                const uint64_t j = ix->big ? nm_lf<true>(v, c1, i) : nm_lf<false>(v, c1, i);
+                v2 = nm_bwt_code(v, j, c2);
+            }
+            const uint64_t bit = 1ULL << (i & 63);
+            if (v1) { r.valid1 |= bit; if (c1 & 1) r.c1lo |= bit; if (c1 & 2) r.c1hi |= bit; run[16 + c1]++; }
+            if (v2) { r.valid2 |= bit; if (c2 & 1) r.c2lo |= bit; if (c2 & 2) r.c2hi |= bit; run[c1 * 4 + c2]++; }
+        }
+    }
+    ix->superC2.assign(at_super.size() * 16, 0);
+    for (size_t sb = 0; sb < at_super.size(); sb++)
+        for (uint32_t x = 0; x < 4; x++)
+            for (uint32_t y = 0; y < 4; y++) {
+                // first row of the suffixes starting "y x": LF_y of the first row starting with x
+                const uint64_t base = ix->big ? nm_lf<true>(v, y, v.C[x]) : nm_lf<false>(v, y, v.C[x]);
+                ix->superC2[sb * 16 + x * 4 + y] = base + at_super[sb][x * 4 + y];
+            }
+    ix->v.rank2 = ix->rank2.data();
+    ix->v.superC2 = ix->superC2.data();
+}
 
 static void hs_encode(const uint8_t *seq, uint64_t seq_len, std::vector<nm_enc_word> &enc) {
     const uint64_t n_words = seq_len / 64 + 3;
@@ -62,7 +102,7 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
     v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
     v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
-    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pair_m = 0; v.pair = nullptr;
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pair_m = 0; v.pair = nullptr; v.rank2 = nullptr; v.superC2 = nullptr;
     uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
     if (s > 12) s = 12;                     // keep the simulated table small
     if (s && h.n >= 2) {
@@ -76,6 +116,28 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
 }
 
 void hs_close(hs_index *ix) { delete ix; }
+void hs_enable_rank2(hs_index *ix, int on) {
+    if (on && ix->rank2.empty()) hs_build_rank2(ix);
+    ix->v.rank2 = on ? ix->rank2.data() : nullptr;
+    ix->v.superC2 = on ? ix->superC2.data() : nullptr;
+}
+// two-step blocks against the one-step structure: LF_x and LF_y(LF_x) at every row and base pair
+uint64_t hs_check_rank2(hs_index *ix, uint64_t stride) {
+    const nm_view &v = ix->v;
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i <= v.n; i += stride)
+        for (uint32_t x = 0; x < 4; x++) {
+            const uint64_t want1 = ix->big ? nm_lf<true>(v, x, i) : nm_lf<false>(v, x, i);
+            if (nm_lf1_r2(v, x, i) != want1) bad++;
+            for (uint32_t y = 0; y < 4; y++) {
+                uint64_t o1, o2;
+                nm_lf12(v, x, y, i, o1, o2);
+                const uint64_t want2 = ix->big ? nm_lf<true>(v, y, want1) : nm_lf<false>(v, y, want1);
+                if (o1 != want1 || o2 != want2) bad++;
+            }
+        }
+    return bad;
+}
 
 // pair-table entries must equal the plain seed entries of the (m+1)-mers they stand for
 uint64_t hs_check_pair(hs_index *ix, uint32_t m) {

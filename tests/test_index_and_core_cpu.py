@@ -219,3 +219,31 @@ def test_core_multi_fasta_multi_index_matches_reference(tmp_path):
             got.setdefault(segs[0].id, []).append(arr.copy())
         for rid, exp in c["expected"].items():
             assert np.concatenate(got[rid.encode()]).tolist() == exp["values"], (c["name"], rid)
+
+
+def test_two_step_rank_blocks(tmp_path, golden_search):
+    """the two-step rank structure (one 128-byte line answers LF_x and LF_y(LF_x)) against the one-step
+    blocks at every row, and the two-bases-per-round-trip walk against the reference fixtures"""
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    text = (b">x\n" + bytes(alpha[rng.integers(0, 4, 3000)]) + b"NN" + b"ACGT" * 40 + b"A" * 300 + b"\n>y\nAAAACCCCGGGGT\n>z\nT\n")
+    fa = tmp_path / "r2.fa"
+    fa.write_bytes(text)
+    idx = tmp_path / "r2.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    for big in (False, True):
+        sim = HostSim(idx, 0, big)
+        sim.enable_rank2()
+        assert sim.check_rank2(1) == 0
+    for c in golden_search:
+        if "quirk" in c["name"] or not c["is_binary"] or not c["use_reverse_complement"]:
+            continue
+        t = c["fasta"].encode("latin-1")
+        fa = _write(tmp_path, t)
+        generate_fm_index(str(fa), str(idx), 8, 12)
+        for seed in (0, 4):
+            sim = HostSim(idx, seed)
+            sim.enable_rank2()
+            got = _engine_unique(sim, t, c["kmer_lengths"], True, c["batch"], True)
+            for rid, exp in c["expected"].items():
+                assert got[rid.encode()].tolist() == exp["values"], (c["name"], rid, seed)

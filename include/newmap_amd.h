@@ -138,7 +138,8 @@ enum {
                                       pairs on the pair table (one 128-byte line per two positions) */
     NM_OPT_PERSISTENT_BLOCKS = 5,  /* grid size of the persistent kernel (default 8 x CUs) */
     NM_OPT_FORCE_BIG = 6,          /* tests: use the kernels for indexes beyond 2^31 positions */
-    NM_OPT_SEED_POLICY = 7         /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */
+    NM_OPT_SEED_POLICY = 7,        /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */
+    NM_OPT_TWO_STEP = 8            /* walks on the two-step rank blocks (default when built) or the one-step ones */
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_mp(nm_view ix, const nm
                 else { lo = 0; hi = ix.n; }
             }
             bool err = false;
-            r = nm_min_unique_walk<BIG, RC>(ix, enc, p, win[j], 0, lo, hi, k, kmin, kmax, err, t);
+            r = nm_min_unique_walk_any<BIG, RC>(ix, enc, p, win[j], lo, hi, k, kmin, kmax, err, t);
             if (err) { any_err = true; if (p < err_pos) err_pos = p; }
         }
         if (STATS && !amb0[j]) n_searched++;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
         if (q_cnt[i] == 0) { lo = 0; hi = ix.n; k = 0; }
         bool err = false;
         const nm_window w = nm_load_window(enc, p);
-        const uint32_t r = nm_min_unique_walk<BIG, true>(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);
+        const uint32_t r = nm_min_unique_walk_any<BIG, true>(ix, enc, p, w, lo, hi, k, kmin, kmax, err, t);
         if (err) { any_err = true; if (p < err_pos) err_pos = p; }
         nm_store(out, elem_bytes, p, r);
     }
@@ -377,6 +377,62 @@ __global__ __launch_bounds__(NM_BLOCK) void k_pair(nm_view ix, uint64_t *__restr
                                                    uint64_t n_entries, uint32_t m) {
     const uint64_t i = first + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     if (i < n_entries) table[i] = nm_pair_entry<BIG>(ix, i >> 3, m, (uint32_t)(i & 7));
+}
+
+// ---- two-step rank blocks (nm_format.h: nm_rank2_block), built on the device at open -----------
+// one wave per block of 64 BWT rows: row -> (c1, c2) by one LF step, six ballots give the planes,
+// lanes 0..19 count the block's 16 pairs and 4 singles
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_rank2_planes(nm_view ix, nm_rank2_block *__restrict__ r2, uint64_t n_blocks,
+                                                           uint64_t *__restrict__ counts /* [20][n_blocks] */) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t b = (blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x) >> 6;
+    if (b >= n_blocks) return;                              // whole waves
+    const uint64_t i = b * 64 + lane;
+    uint32_t c1 = 0, c2 = 0;
+    bool v1 = false, v2 = false;
+    if (i < ix.n) {
+        v1 = nm_bwt_code(ix, i, c1);
+        if (v1) v2 = nm_bwt_code(ix, nm_lf<BIG>(ix, c1, i), c2);
+    }
+    const uint64_t valid1 = __ballot(v1), valid2 = __ballot(v2);
+    const uint64_t c1lo = __ballot(v1 && (c1 & 1u)), c1hi = __ballot(v1 && (c1 & 2u));
+    const uint64_t c2lo = __ballot(v2 && (c2 & 1u)), c2hi = __ballot(v2 && (c2 & 2u));
+    if (lane == 0) {
+        nm_rank2_block &o = r2[b];
+        o.c1lo = c1lo; o.c1hi = c1hi; o.c2lo = c2lo; o.c2hi = c2hi; o.valid1 = valid1; o.valid2 = valid2;
+    }
+    if (lane < 20) {
+        uint64_t m;
+        if (lane < 16) {
+            const uint32_t x = lane >> 2, y = lane & 3;
+            m = valid2 & ((x & 1u) ? c1lo : ~c1lo) & ((x & 2u) ? c1hi : ~c1hi) & ((y & 1u) ? c2lo : ~c2lo) & ((y & 2u) ? c2hi : ~c2hi);
+        } else {
+            const uint32_t x = lane - 16;
+            m = valid1 & ((x & 1u) ? c1lo : ~c1lo) & ((x & 2u) ? c1hi : ~c1hi);
+        }
+        counts[(uint64_t)lane * n_blocks + b] = (uint64_t)__popcll(m);
+    }
+}
+
+// counts[] now holds exclusive prefix sums per counter: make them superblock-relative and fill the
+// superblock table (first row of the suffixes starting "y x" + pairs before the superblock)
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_rank2_finish(nm_view ix, nm_rank2_block *__restrict__ r2, uint64_t n_blocks,
+                                                           const uint64_t *__restrict__ counts, uint64_t *__restrict__ superC2) {
+    const uint64_t t = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    const uint64_t b = t / 20;
+    const uint32_t c = (uint32_t)(t % 20);
+    if (b >= n_blocks) return;
+    const uint64_t per_super = 1ULL << (NM_SUPER_SHIFT - 6);
+    const uint64_t sb = b / per_super, b0 = sb * per_super;
+    const uint64_t at_super = counts[(uint64_t)c * n_blocks + b0];
+    const uint32_t rel = (uint32_t)(counts[(uint64_t)c * n_blocks + b] - at_super);
+    if (c < 16) r2[b].cnt2[c] = rel; else r2[b].cnt1[c - 16] = rel;
+    if (b == b0 && c < 16) {
+        const uint32_t x = c >> 2, y = c & 3;
+        superC2[sb * 16 + c] = nm_lf<BIG>(ix, y, ix.C[x]) + at_super;
+    }
 }
 
 // ---- k_min_unique_v2: persistent waves, one lane = one position AT A TIME --------------------
@@ -609,6 +665,7 @@ struct nm_index {
     void *d_seed2 = nullptr;              // small secondary seed table (nm_view_for)
     uint32_t seed2_len = 0;
     void *d_pair = nullptr;               // pair table (k_min_unique_pair)
+    void *d_rank2 = nullptr, *d_super2 = nullptr;   // two-step rank blocks + their superblock table
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
@@ -711,6 +768,47 @@ static uint32_t nm_auto_seed_len(const nm_index *ix) {
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
         while (s > 4 && (8ULL << (2 * s)) > free_b / 4) s--;   // never more than a quarter of free HBM
     return s;
+}
+
+#include "nm_scan.hip.h"
+
+// two-step rank blocks: 128 B per 64 BWT rows, derived on the device from the one-step structure
+static int nm_build_rank2(nm_index *ix) {
+    const uint64_t n_blocks = ix->h.n / 64 + 1;
+    void *d_counts = nullptr, *d_scratch = nullptr, *d_total = nullptr;
+    HIP_TRY(hipMalloc(&ix->d_rank2, n_blocks * sizeof(nm_rank2_block)));
+    HIP_TRY(hipMalloc(&ix->d_super2, (uint64_t)ix->h.n_super * 16 * sizeof(uint64_t)));
+    ix->device_bytes += n_blocks * sizeof(nm_rank2_block);
+    const uint64_t scratch_n = n_blocks / TILE + n_blocks / ((uint64_t)TILE * TILE) + 8192;
+    int rc = NM_OK;
+    if (hipMalloc(&d_counts, 20 * n_blocks * sizeof(uint64_t)) != hipSuccess || hipMalloc(&d_scratch, scratch_n * 8) != hipSuccess ||
+        hipMalloc(&d_total, 16) != hipSuccess) {
+        nm_set_error("hipMalloc failed while building the two-step rank blocks");
+        rc = NM_E_ALLOC;
+    }
+    nm_view v = ix->view;
+    if (rc == NM_OK) {
+        const dim3 block(NM_BLOCK);
+        const unsigned g1 = nm_grid(n_blocks * 64);
+        if (ix->big) hipLaunchKernelGGL(k_rank2_planes<true>, dim3(g1), block, 0, ix->stream, v, (nm_rank2_block *)ix->d_rank2, n_blocks, (uint64_t *)d_counts);
+        else         hipLaunchKernelGGL(k_rank2_planes<false>, dim3(g1), block, 0, ix->stream, v, (nm_rank2_block *)ix->d_rank2, n_blocks, (uint64_t *)d_counts);
+        for (int c = 0; c < 20 && rc == NM_OK; c++)
+            rc = scan_exclusive((uint64_t *)d_counts + (uint64_t)c * n_blocks, n_blocks, (uint64_t *)d_scratch, (uint64_t *)d_total, ix->stream);
+        if (rc == NM_OK) {
+            const unsigned g2 = nm_grid(n_blocks * 20);
+            if (ix->big) hipLaunchKernelGGL(k_rank2_finish<true>, dim3(g2), block, 0, ix->stream, v, (nm_rank2_block *)ix->d_rank2, n_blocks, (const uint64_t *)d_counts, (uint64_t *)ix->d_super2);
+            else         hipLaunchKernelGGL(k_rank2_finish<false>, dim3(g2), block, 0, ix->stream, v, (nm_rank2_block *)ix->d_rank2, n_blocks, (const uint64_t *)d_counts, (uint64_t *)ix->d_super2);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess) { nm_set_error("building the two-step rank blocks failed"); rc = NM_E_DEVICE; }
+        }
+    }
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_scratch) (void)hipFree(d_scratch);
+    if (d_total) (void)hipFree(d_total);
+    if (rc == NM_OK) {
+        ix->view.rank2 = (const nm_rank2_block *)ix->d_rank2;
+        ix->view.superC2 = (const uint64_t *)ix->d_super2;
+    }
+    return rc;
 }
 
 // pair table for cores of m bases: 4^m blocks x 8 entries x 8 bytes
@@ -860,6 +958,8 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.seed_policy = 0;
     v.pair_m = 0;
     v.pair = nullptr;
+    v.rank2 = nullptr;
+    v.superC2 = nullptr;
 
     uint32_t s = seed_len_override == -1 ? h.seed_len
                : (seed_len_override < -1 ? nm_auto_seed_len(ix) : (uint32_t)seed_len_override);
@@ -875,6 +975,14 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
             while (m > 4 && (64ULL << (2 * m)) > free_b * 2 / 5) m--;   // at most 40 % of what is still free
         rc = nm_build_pair(ix, m);
         if (rc != NM_OK) { nm_index_close(ix); return rc; }
+    }
+    if (seed_len_override < -1 && ix->h.n >= 2) {
+        // automatic sizing also builds the two-step rank blocks (2 bytes per BWT row)
+        const char *off = getenv("NEWMAP_AMD_TWO_STEP");
+        if (!(off && off[0] == '0')) {
+            rc = nm_build_rank2(ix);
+            if (rc != NM_OK) { nm_index_close(ix); return rc; }
+        }
     }
     rc = nm_grow(ix->status, NM_STATUS_WORDS * sizeof(uint64_t));
     if (rc == NM_OK) rc = nm_grow(ix->work, sizeof(unsigned long long));
@@ -892,7 +1000,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_super, ix->enc.p, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_rank2, ix->d_super2, ix->d_super, ix->enc.p, ix->seq.p,
                     ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -923,6 +1031,11 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
     if (option == NM_OPT_COUNT_STEPS) { ix->count_steps = value != 0; return NM_OK; }
     if (option == NM_OPT_TIMING) { ix->timing = value != 0; ix->ev_used = 0; return NM_OK; }
+    if (option == NM_OPT_TWO_STEP) {       // A/B: walks use the two-step rank blocks (if built) or the one-step ones
+        ix->view.rank2 = value ? (const nm_rank2_block *)ix->d_rank2 : nullptr;
+        ix->view.superC2 = value ? (const uint64_t *)ix->d_super2 : nullptr;
+        return NM_OK;
+    }
     if (option == NM_OPT_SEED_POLICY) {
         if (value < 0 || value > 2) { nm_set_error("seed policy must be 0, 1 or 2"); return NM_E_ARGUMENT; }
         ix->view.seed_policy = (uint32_t)value;

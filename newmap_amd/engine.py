@@ -98,6 +98,10 @@ class Index:
     def set_persistent_blocks(self, blocks: int):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_PERSISTENT_BLOCKS, int(blocks)))
 
+    def set_two_step(self, on: bool):
+        """walks read the two-step rank blocks (two bases per memory round trip) or the one-step ones"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_TWO_STEP, int(bool(on))))
+
     def set_force_big(self, on: bool):
         """tests: exercise the code path of indexes beyond 2^31 positions on a small index"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_FORCE_BIG, int(bool(on))))

@@ -403,6 +403,15 @@ def test_both_range_kernels_agree(mixed_genome, eng):
                 ix.set_kernel(1)
                 b, amb_b = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                 assert np.array_equal(a, b) and amb_a == amb_b
+                # walks on the one-step rank blocks instead of the two-step ones
+                for kernel in (0, 1, 3):
+                    ix.set_kernel(kernel)
+                    ix.set_two_step(False)
+                    c, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                    ix.set_two_step(True)
+                    d, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                    assert np.array_equal(a, c) and np.array_equal(a, d), (kernel, kmin, kmax)
+                ix.set_kernel(0)
 
 
 def test_big_index_code_path(mixed_genome, eng):

@@ -139,7 +139,8 @@ enum {
     NM_OPT_PERSISTENT_BLOCKS = 5,  /* grid size of the persistent kernel (default 8 x CUs) */
     NM_OPT_FORCE_BIG = 6,          /* tests: use the kernels for indexes beyond 2^31 positions */
     NM_OPT_SEED_POLICY = 7,        /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */
-    NM_OPT_TWO_STEP = 8            /* walks on the two-step rank blocks (default when built) or the one-step ones */
+    NM_OPT_TWO_STEP = 8,           /* walks on the two-step rank blocks (built only with NEWMAP_AMD_TWO_STEP=1) */
+    NM_OPT_LF_BLOCKS = 9           /* LF steps on the 16-byte LF entries (default when built) or the packed rank blocks */
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 

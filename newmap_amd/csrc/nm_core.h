@@ -50,6 +50,7 @@ struct nm_view {                // the index as the kernels see it
     uint32_t seed_policy;       // experiment knob: cache policy of the seed-table load (0 = default)
     uint32_t pair_m;            // core length of the pair table (0 = none)
     const uint64_t *pair;       // 4^pair_m blocks of 8 entries: [a] interval of a.Y, [4+b] interval of Y.b
+    const nm_lf_entry *lfb;     // LF blocks: one 16-byte load per LF step (nullptr = use the packed rank blocks)
     const nm_rank2_block *rank2;   // two-step rank blocks (nullptr = not built)
     const uint64_t *superC2;    // [n_super][16]: first row of the suffixes starting "y x" + pairs before the superblock
 };
@@ -108,7 +109,30 @@ NM_HD uint64_t nm_lf_blk(const nm_view &ix, uint32_t c, uint64_t i, const nm_blk
 
 template <bool BIG>
 NM_HD uint64_t nm_lf(const nm_view &ix, uint32_t c, uint64_t i) {
+    if (ix.lfb) {                                         // one 16-byte load per step
+        const nm_lf_entry *e = ix.lfb + ((i >> 6) * 4 + c);
+        return e->base + nm_popc64(e->bits & ((1ULL << (i & 63)) - 1ULL));
+    }
     return nm_lf_blk<BIG>(ix, c, i, nm_load_blk(ix, i));
+}
+
+// the four LF entries of rank block b, from the packed structure (device build at open; host mirror)
+template <bool BIG>
+NM_HD void nm_lf_entries_of_block(const nm_view &ix, uint64_t b, nm_lf_entry out[4]) {
+    const nm_rank_block *rb = ix.rank + b;
+    uint64_t sepmask = 0;
+    if (rb->cnt[0] & NM_SEP_FLAG) {
+        uint64_t lo = 0, hi = ix.n_sep;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ix.sep[mid] < b * 64) lo = mid + 1; else hi = mid; }
+        for (; lo < ix.n_sep && ix.sep[lo] < b * 64 + 64; lo++) sepmask |= 1ULL << (ix.sep[lo] & 63);
+    }
+    const uint64_t rows = b * 64 < ix.n ? (ix.n - b * 64 >= 64 ? ~0ULL : ((1ULL << (ix.n - b * 64)) - 1ULL)) : 0ULL;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+        const uint32_t cnt = c == 0 ? (rb->cnt[0] & ~NM_SEP_FLAG) : rb->cnt[c];
+        out[c].base = (BIG ? ix.superC[((b * 64) >> NM_SUPER_SHIFT) * 4 + c] : ix.C[c]) + cnt;
+        out[c].bits = ((c & 1u) ? rb->lo : ~rb->lo) & ((c & 2u) ? rb->hi : ~rb->hi) & ~sepmask & rows;
+    }
 }
 
 // suffixes of the RC half among suffix-array positions [0, i)

@@ -379,6 +379,17 @@ __global__ __launch_bounds__(NM_BLOCK) void k_pair(nm_view ix, uint64_t *__restr
     if (i < n_entries) table[i] = nm_pair_entry<BIG>(ix, i >> 3, m, (uint32_t)(i & 7));
 }
 
+// ---- LF blocks (nm_format.h: nm_lf_entry): re-layout of the packed rank blocks, built at open ----
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_lf_blocks(nm_view ix, nm_lf_entry *__restrict__ lfb, uint64_t n_blocks) {
+    const uint64_t b = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (b >= n_blocks) return;
+    nm_lf_entry e[4];
+    nm_lf_entries_of_block<BIG>(ix, b, e);
+#pragma unroll
+    for (int c = 0; c < 4; c++) lfb[b * 4 + c] = e[c];
+}
+
 // ---- two-step rank blocks (nm_format.h: nm_rank2_block), built on the device at open -----------
 // one wave per block of 64 BWT rows: row -> (c1, c2) by one LF step, six ballots give the planes,
 // lanes 0..19 count the block's 16 pairs and 4 singles
@@ -666,6 +677,7 @@ struct nm_index {
     uint32_t seed2_len = 0;
     void *d_pair = nullptr;               // pair table (k_min_unique_pair)
     void *d_rank2 = nullptr, *d_super2 = nullptr;   // two-step rank blocks + their superblock table
+    void *d_lfb = nullptr;                // LF blocks
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
@@ -771,6 +783,21 @@ static uint32_t nm_auto_seed_len(const nm_index *ix) {
 }
 
 #include "nm_scan.hip.h"
+
+// LF blocks: 64 B per 64 BWT rows (one 16-byte entry per base)
+static int nm_build_lf_blocks(nm_index *ix) {
+    const uint64_t n_blocks = ix->h.n / 64 + 1;
+    HIP_TRY(hipMalloc(&ix->d_lfb, n_blocks * 4 * sizeof(nm_lf_entry)));
+    ix->device_bytes += n_blocks * 4 * sizeof(nm_lf_entry);
+    nm_view v = ix->view;
+    v.lfb = nullptr;
+    if (ix->big) hipLaunchKernelGGL(k_lf_blocks<true>, dim3(nm_grid(n_blocks)), dim3(NM_BLOCK), 0, ix->stream, v, (nm_lf_entry *)ix->d_lfb, n_blocks);
+    else         hipLaunchKernelGGL(k_lf_blocks<false>, dim3(nm_grid(n_blocks)), dim3(NM_BLOCK), 0, ix->stream, v, (nm_lf_entry *)ix->d_lfb, n_blocks);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->view.lfb = (const nm_lf_entry *)ix->d_lfb;
+    return NM_OK;
+}
 
 // two-step rank blocks: 128 B per 64 BWT rows, derived on the device from the one-step structure
 static int nm_build_rank2(nm_index *ix) {
@@ -960,7 +987,15 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.pair = nullptr;
     v.rank2 = nullptr;
     v.superC2 = nullptr;
+    v.lfb = nullptr;
 
+    if (seed_len_override < -1 && h.n >= 2) {
+        const char *off = getenv("NEWMAP_AMD_LF_BLOCKS");
+        if (!(off && off[0] == '0')) {
+            rc = nm_build_lf_blocks(ix);
+            if (rc != NM_OK) { nm_index_close(ix); return rc; }
+        }
+    }
     uint32_t s = seed_len_override == -1 ? h.seed_len
                : (seed_len_override < -1 ? nm_auto_seed_len(ix) : (uint32_t)seed_len_override);
     if (s > 16) s = 16;
@@ -977,9 +1012,10 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         if (rc != NM_OK) { nm_index_close(ix); return rc; }
     }
     if (seed_len_override < -1 && ix->h.n >= 2) {
-        // automatic sizing also builds the two-step rank blocks (2 bytes per BWT row)
-        const char *off = getenv("NEWMAP_AMD_TWO_STEP");
-        if (!(off && off[0] == '0')) {
+        // opt-in (NEWMAP_AMD_TWO_STEP=1): the two-step rank blocks, 2 bytes per BWT row; measured no faster
+        // than one-step walks, kept for A/B
+        const char *on = getenv("NEWMAP_AMD_TWO_STEP");
+        if (on && on[0] == '1') {
             rc = nm_build_rank2(ix);
             if (rc != NM_OK) { nm_index_close(ix); return rc; }
         }
@@ -1000,7 +1036,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_rank2, ix->d_super2, ix->d_super, ix->enc.p, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_rank2, ix->d_super2, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
                     ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1031,6 +1067,10 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
     if (option == NM_OPT_COUNT_STEPS) { ix->count_steps = value != 0; return NM_OK; }
     if (option == NM_OPT_TIMING) { ix->timing = value != 0; ix->ev_used = 0; return NM_OK; }
+    if (option == NM_OPT_LF_BLOCKS) {      // A/B: LF steps read the 16-byte LF entries (if built) or the packed blocks
+        ix->view.lfb = value ? (const nm_lf_entry *)ix->d_lfb : nullptr;
+        return NM_OK;
+    }
     if (option == NM_OPT_TWO_STEP) {       // A/B: walks use the two-step rank blocks (if built) or the one-step ones
         ix->view.rank2 = value ? (const nm_rank2_block *)ix->d_rank2 : nullptr;
         ix->view.superC2 = value ? (const uint64_t *)ix->d_super2 : nullptr;

@@ -49,6 +49,17 @@ struct nm_rank2_block {
     uint64_t valid1, valid2;       /* c1 is a base; c1 and c2 are both bases */
 };
 
+/* LF block, built on the device when the index is opened: per 64 BWT rows and per base c one
+ * 16-byte entry {C[c] + occurrences of c before the block, indicator bits of c}.  LF_c(i) is then ONE
+ * 16-byte load, one popcount and one add -- half the load instructions of the packed rank block
+ * (walks with wide intervals are bound by the L1's divergent-address rate), no
+ * superblock table, and separators need no exception path (their rows match no base).
+ * Layout: entry (64-row block b, base c) at index b * 4 + c. */
+struct nm_lf_entry {
+    uint64_t base;
+    uint64_t bits;
+};
+
 struct nm_strand_block {           /* 16 bytes, 64 suffix-array positions */
     uint64_t before;
     uint64_t bits;
@@ -78,6 +89,7 @@ struct nm_file_header {            /* 1024 bytes */
 static_assert(sizeof(nm_rank_block) == 32, "rank block must be 32 bytes");
 static_assert(sizeof(nm_strand_block) == 16, "strand block must be 16 bytes");
 static_assert(sizeof(nm_rank2_block) == 128, "two-step rank block must be one 128-byte line");
+static_assert(sizeof(nm_lf_entry) == 16, "LF entry must be 16 bytes");
 static_assert(sizeof(nm_file_header) == 1024, "header must be 1024 bytes");
 #endif
 

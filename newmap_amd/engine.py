@@ -98,6 +98,10 @@ class Index:
     def set_persistent_blocks(self, blocks: int):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_PERSISTENT_BLOCKS, int(blocks)))
 
+    def set_lf_blocks(self, on: bool):
+        """LF steps read one 16-byte LF entry (default) or the packed 32-byte rank block"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LF_BLOCKS, int(bool(on))))
+
     def set_two_step(self, on: bool):
         """walks read the two-step rank blocks (two bases per memory round trip) or the one-step ones"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_TWO_STEP, int(bool(on))))

@@ -27,6 +27,9 @@ def lib():
     L.hs_open.argtypes = [ctypes.c_char_p, i32, i32]
     L.hs_close.argtypes = [vp]
     L.hs_enable_rank2.argtypes = [vp, i32]
+    L.hs_enable_lfb.argtypes = [vp, i32]
+    L.hs_check_lfb.restype = u64
+    L.hs_check_lfb.argtypes = [vp]
     L.hs_check_rank2.restype = u64
     L.hs_check_rank2.argtypes = [vp, u64]
     L.hs_check_levels.restype = u64
@@ -58,6 +61,12 @@ class HostSim:
         if getattr(self, "h", None):
             self.L.hs_close(self.h)
             self.h = None
+
+    def enable_lfb(self, on=True):
+        self.L.hs_enable_lfb(self.h, int(on))
+
+    def check_lfb(self):
+        return int(self.L.hs_check_lfb(self.h))
 
     def enable_rank2(self, on=True):
         self.L.hs_enable_rank2(self.h, int(on))

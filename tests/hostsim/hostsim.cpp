@@ -18,6 +18,7 @@ struct hs_index {
     std::vector<nm_strand_block> strand;
     std::vector<uint64_t> sep, seed, superC, superC2;
     std::vector<nm_rank2_block> rank2;
+    std::vector<nm_lf_entry> lfb;
     nm_view v;
     bool big;
 };
@@ -102,7 +103,7 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
     v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
     v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
-    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pair_m = 0; v.pair = nullptr; v.rank2 = nullptr; v.superC2 = nullptr;
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pair_m = 0; v.pair = nullptr; v.rank2 = nullptr; v.superC2 = nullptr; v.lfb = nullptr;
     uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
     if (s > 12) s = 12;                     // keep the simulated table small
     if (s && h.n >= 2) {
@@ -116,6 +117,32 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
 }
 
 void hs_close(hs_index *ix) { delete ix; }
+// LF blocks (one 16-byte entry per block and base), host mirror of k_lf_blocks
+void hs_enable_lfb(hs_index *ix, int on) {
+    if (on && ix->lfb.empty()) {
+        const uint64_t nb = ix->v.n / 64 + 1;
+        ix->lfb.resize(nb * 4);
+        ix->v.lfb = nullptr;
+        for (uint64_t b = 0; b < nb; b++) {
+            if (ix->big) nm_lf_entries_of_block<true>(ix->v, b, &ix->lfb[b * 4]);
+            else nm_lf_entries_of_block<false>(ix->v, b, &ix->lfb[b * 4]);
+        }
+    }
+    ix->v.lfb = on ? ix->lfb.data() : nullptr;
+}
+// LF blocks against the packed rank blocks at every row
+uint64_t hs_check_lfb(hs_index *ix) {
+    nm_view packed = ix->v;
+    packed.lfb = nullptr;
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i <= ix->v.n; i++)
+        for (uint32_t c = 0; c < 4; c++) {
+            const uint64_t a = ix->big ? nm_lf<true>(ix->v, c, i) : nm_lf<false>(ix->v, c, i);
+            const uint64_t b = ix->big ? nm_lf<true>(packed, c, i) : nm_lf<false>(packed, c, i);
+            if (a != b) bad++;
+        }
+    return bad;
+}
 void hs_enable_rank2(hs_index *ix, int on) {
     if (on && ix->rank2.empty()) hs_build_rank2(ix);
     ix->v.rank2 = on ? ix->rank2.data() : nullptr;

@@ -412,6 +412,10 @@ def test_both_range_kernels_agree(mixed_genome, eng):
                     d, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                     assert np.array_equal(a, c) and np.array_equal(a, d), (kernel, kmin, kmax)
                 ix.set_kernel(0)
+                ix.set_lf_blocks(False)                           # packed 32-byte rank blocks instead of LF entries
+                e, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                ix.set_lf_blocks(True)
+                assert np.array_equal(a, e)
 
 
 def test_big_index_code_path(mixed_genome, eng):

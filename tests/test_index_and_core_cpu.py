@@ -235,15 +235,21 @@ def test_two_step_rank_blocks(tmp_path, golden_search):
         sim = HostSim(idx, 0, big)
         sim.enable_rank2()
         assert sim.check_rank2(1) == 0
+        sim.enable_lfb()                                       # one 16-byte entry per LF step
+        assert sim.check_lfb() == 0
+        assert sim.check_rank2(1) == 0                         # (the two-step check now walks the LF blocks)
     for c in golden_search:
         if "quirk" in c["name"] or not c["is_binary"] or not c["use_reverse_complement"]:
             continue
         t = c["fasta"].encode("latin-1")
         fa = _write(tmp_path, t)
         generate_fm_index(str(fa), str(idx), 8, 12)
-        for seed in (0, 4):
+        for seed, lfb in ((0, False), (4, False), (3, True)):
             sim = HostSim(idx, seed)
             sim.enable_rank2()
+            if lfb:
+                sim.enable_rank2(False)
+                sim.enable_lfb()
             got = _engine_unique(sim, t, c["kmer_lengths"], True, c["batch"], True)
             for rid, exp in c["expected"].items():
                 assert got[rid.encode()].tolist() == exp["values"], (c["name"], rid, seed)

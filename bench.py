@@ -287,10 +287,11 @@ def main():
     if rank == 0:
         my_pos = hi - lo
         steps_pp = tallies[3] / max(tallies[7], 1)
-        # algorithmic bytes (DESIGN.md "Measurement"): 32 B per distinct rank block an LF step reads
-        # (lo and hi in one block count once), 8 B per seed-table entry, 1 sequence byte and one
-        # output element per position
-        alg_bytes = tallies[4] * 32 + tallies[5] * 8 + my_pos * (1 + 1)
+        # algorithmic bytes (DESIGN.md "Measurement"): per distinct rank structure an LF step reads (lo and
+        # hi in one block count once) 16 B with LF blocks / 32 B with the packed rank blocks, 8 B per
+        # table entry, 1 sequence byte and one output element per position
+        rank_bytes = 16 if ix.info()["lf_blocks"] and not ix.info()["two_step_blocks"] else 32
+        alg_bytes = tallies[4] * rank_bytes + tallies[5] * 8 + my_pos * (1 + 1)
         per_launch_bytes = alg_bytes / max(len(segs), 1)
         avg_launch_ms = kern_ms / max(n_launch, 1)
         achieved = per_launch_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0

@@ -73,7 +73,8 @@ void nm_index_close(nm_index *ix);
 
 /* index facts: 0 n (BWT length), 1 forward text length, 2 separators, 3 records, 4 raw bases,
  * 5 seed length in use, 6 device bytes held, 7 sa_ratio recorded, 8 range kernel used by the last
- * launch (see NM_OPT_KERNEL), 9 core length of the pair table (0 = none), 10 device index */
+ * launch (see NM_OPT_KERNEL), 9 core length of the pair table (0 = none), 10 device index,
+ * 11 LF blocks in use, 12 two-step rank blocks in use */
 uint64_t nm_index_info(const nm_index *ix, int what);
 
 /* ------------------------------------------------------------------------- compat seam ------

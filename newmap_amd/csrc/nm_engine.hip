@@ -1059,6 +1059,8 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 8: return (uint64_t)ix->last_kernel;
         case 9: return ix->view.pair_m;
         case 10: return (uint64_t)ix->device;
+        case 11: return ix->view.lfb ? 1 : 0;
+        case 12: return ix->view.rank2 ? 1 : 0;
         default: return 0;
     }
 }

@@ -85,7 +85,8 @@ class Index:
 
     def info(self) -> dict:
         names = ["bwt_length", "forward_text_length", "separators", "records", "raw_bases",
-                 "seed_length", "device_bytes", "sa_ratio", "last_range_kernel", "pair_core_length"]
+                 "seed_length", "device_bytes", "sa_ratio", "last_range_kernel", "pair_core_length", "device",
+                 "lf_blocks", "two_step_blocks"]
         return {n: int(self._L.nm_index_info(self.handle, i)) for i, n in enumerate(names)}
 
     def set_count_steps(self, on: bool):

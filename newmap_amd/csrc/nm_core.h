@@ -116,6 +116,24 @@ NM_HD uint64_t nm_lf(const nm_view &ix, uint32_t c, uint64_t i) {
     return nm_lf_blk<BIG>(ix, c, i, nm_load_blk(ix, i));
 }
 
+// LF step of an interval [lo, hi): when both ends fall into the same 64-row block the second
+// load is skipped (the common case once an interval is narrow)
+template <bool BIG>
+NM_HD void nm_lf_interval(const nm_view &ix, uint32_t c, uint64_t &lo, uint64_t &hi) {
+    if (ix.lfb) {
+        const nm_lf_entry *e = ix.lfb + ((lo >> 6) * 4 + c);
+        const uint64_t base = e->base, bits = e->bits;
+        const bool same = (lo >> 6) == (hi >> 6);
+        uint64_t hbase = base, hbits = bits;
+        if (!same) { const nm_lf_entry *f = ix.lfb + ((hi >> 6) * 4 + c); hbase = f->base; hbits = f->bits; }
+        lo = base + nm_popc64(bits & ((1ULL << (lo & 63)) - 1ULL));
+        hi = hbase + nm_popc64(hbits & ((1ULL << (hi & 63)) - 1ULL));
+        return;
+    }
+    lo = nm_lf<BIG>(ix, c, lo);
+    hi = nm_lf<BIG>(ix, c, hi);
+}
+
 // the four LF entries of rank block b, from the packed structure (device build at open; host mirror)
 template <bool BIG>
 NM_HD void nm_lf_entries_of_block(const nm_view &ix, uint64_t b, nm_lf_entry out[4]) {
@@ -249,8 +267,7 @@ NM_HD uint32_t nm_min_unique_walk(const nm_view &ix, const nm_enc_word *enc, uin
         const uint32_t c = 3u - nm_window_code(w, j);     // prepend the complement: search rc(k-mer)
         t.steps++;
         t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u;
-        lo = nm_lf<BIG>(ix, c, lo);
-        hi = nm_lf<BIG>(ix, c, hi);
+        nm_lf_interval<BIG>(ix, c, lo, hi);
         k++;
     }
     const uint32_t ans = k > kmin ? k : kmin;             // k <= kmax here, kmin <= kmax
@@ -381,8 +398,7 @@ NM_HD uint32_t nm_fixed_k_one(const nm_view &ix, const nm_enc_word *enc, uint64_
             const uint32_t c = 3u - nm_window_code(w, j);
             t.steps++;
             t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u;
-            lo = nm_lf<BIG>(ix, c, lo);
-            hi = nm_lf<BIG>(ix, c, hi);
+            nm_lf_interval<BIG>(ix, c, lo, hi);
             k++;
         }
         const uint64_t cnt = hi - lo;

@@ -1,9 +1,9 @@
 """`newmap track`: unique-length arrays -> single-read BED / multi-read WIG mappability tracks
 (reference: newmap/track.py).  Downstream consumer of the `search` output (SURVEY.md section 8(f)
 rank 2).  `write_mappability_files` runs on the device (csrc/nm_track.hip: scans, stream compaction,
-text scatter) when a GPU is visible; the numpy functions below are the same arithmetic on the host,
-kept because `track` is a post-processing tool that is also run on machines without a GPU.  Both
-write the reference's bytes (tests/test_track.py, tests/test_gpu_parity.py).
+text scatter) and fails loudly when no GPU is visible.  The numpy functions below are the same
+arithmetic as a separate HOST tool, used only when asked for explicitly (NEWMAP_AMD_TRACK=host) -- never
+as a silent fallback.  Both write the reference's bytes (tests/test_track.py, tests/test_gpu_parity.py).
 """
 from __future__ import annotations
 
@@ -80,16 +80,15 @@ def safe_remove(filename):
 
 
 def _device_for_track():
-    """GPU to use, or None (NEWMAP_AMD_TRACK=host forces the numpy path)"""
+    """GPU to use; None only when the host tool was asked for explicitly (NEWMAP_AMD_TRACK=host)"""
     import os
     if os.environ.get("NEWMAP_AMD_TRACK", "") == "host":
         return None
-    try:
-        from . import _lib
-        from .engine import default_device, device_count
-        return default_device() if device_count() > 0 else None
-    except Exception:
-        return None
+    from .engine import default_device, device_count
+    if device_count() < 1:
+        raise RuntimeError("newmap track: no HIP device visible (set NEWMAP_AMD_TRACK=host to run the "
+                           "host numpy tool instead)")
+    return default_device()
 
 
 def write_mappability_files(unique_count_filenames, kmer_length: int, single_read_bed_filename,
@@ -110,17 +109,31 @@ def write_mappability_files(unique_count_filenames, kmer_length: int, single_rea
         verbose_print(verbose, f"Calculating mappability regions from minimum unique k-mer lengths in "
                                f"file: {unique_path}")
         device = _device_for_track()
-        if device is not None and STDOUT_FILENAME not in (single_read_bed_filename, multi_read_wig_filename):
+        if device is not None:
             import ctypes
             import os
+            import tempfile
             from . import _lib
             n_pos, n_runs = ctypes.c_uint64(0), ctypes.c_uint64(0)
-            rc = _lib.lib().nm_track_file(
-                device, os.fsencode(unique_path), chr_name.encode(), np.dtype(_DTYPES[unique_path.suffix]).itemsize,
-                int(kmer_length), os.fsencode(single_read_bed_filename) if single_read_bed_filename else None,
-                os.fsencode(multi_read_wig_filename) if multi_read_wig_filename else None,
-                ctypes.byref(n_pos), ctypes.byref(n_runs))
-            _lib.raise_for(rc)
+            with tempfile.TemporaryDirectory() as td:
+                # standard output: the device writes a scratch file that is then streamed out
+                bed = single_read_bed_filename
+                wig = multi_read_wig_filename
+                if bed == STDOUT_FILENAME:
+                    bed = os.path.join(td, "stdout.bed")
+                if wig == STDOUT_FILENAME:
+                    wig = os.path.join(td, "stdout.wig")
+                rc = _lib.lib().nm_track_file(
+                    device, os.fsencode(unique_path), chr_name.encode(), np.dtype(_DTYPES[unique_path.suffix]).itemsize,
+                    int(kmer_length), os.fsencode(bed) if bed else None, os.fsencode(wig) if wig else None,
+                    ctypes.byref(n_pos), ctypes.byref(n_runs))
+                _lib.raise_for(rc)
+                for name, path in ((single_read_bed_filename, bed), (multi_read_wig_filename, wig)):
+                    if name == STDOUT_FILENAME:
+                        with open(path, "rb") as fh:
+                            for chunk in iter(lambda: fh.read(1 << 24), b""):
+                                sys.stdout.buffer.write(chunk)
+                        sys.stdout.buffer.flush()
             verbose_print(verbose, "Chromosome size:")
             verbose_print(verbose, f"{chr_name}\t{n_pos.value}")
             continue

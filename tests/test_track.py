@@ -1,5 +1,7 @@
-"""`track` (host): byte-identical BED / WIG to the reference's newmap/track.py on fixtures produced by
-the reference itself (tests/golden/make_golden_track.py)."""
+"""`track`, the HOST numpy tool (selected explicitly with NEWMAP_AMD_TRACK=host): byte-identical BED / WIG
+to the reference's newmap/track.py on fixtures produced by the reference itself
+(tests/golden/make_golden_track.py).  The device implementation is checked against the same fixtures
+in tests/test_gpu_parity.py."""
 import argparse
 import json
 from pathlib import Path
@@ -8,6 +10,11 @@ import numpy as np
 import pytest
 
 GOLDEN = Path(__file__).resolve().parent / "golden" / "golden_track.json"
+
+
+@pytest.fixture(autouse=True)
+def _host_tool(monkeypatch):
+    monkeypatch.setenv("NEWMAP_AMD_TRACK", "host")
 
 
 @pytest.fixture(scope="module")
@@ -55,3 +62,14 @@ def test_track_main_defaults_and_errors(tmp_path, golden, capsysbinary):
     bad.write_bytes(b"\0" * 4)
     with pytest.raises(ValueError, match="Unknown extension"):
         track.write_mappability_files([bad], 10, str(tmp_path / "b.bed"), None, False)
+
+
+def test_track_without_gpu_fails_loudly(tmp_path, golden, monkeypatch):
+    from newmap_amd import track
+    from newmap_amd.engine import device_count
+    if device_count() > 0:
+        pytest.skip("a GPU is visible")
+    monkeypatch.delenv("NEWMAP_AMD_TRACK")
+    files = _write_arrays(tmp_path, golden)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        track.write_mappability_files(files, 10, str(tmp_path / "x.bed"), None, False)

@@ -278,10 +278,13 @@ def main():
     # counter build of the kernel: LF steps / rank blocks / seed lookups per launch (untimed)
     ix.set_count_steps(True)
     tallies = np.zeros(8, dtype=np.int64)
+    probe = {"lf_steps": 0, "rank_blocks": 0, "seed_lookups": 0, "settled": 0}
     for (p, seg_len, nk) in segs:
         ix.min_unique_segment_dev(seq_ptr + p, seg_len, nk, KMIN, KMAX, True, 1, out_ptr + p, st_ptr, stream)
         torch.cuda.synchronize()
         tallies += d_status.cpu().numpy()
+        for k_, v_ in ix.probe_tally().items():
+            probe[k_] += v_
     ix.set_count_steps(False)
 
     if rank == 0:
@@ -320,6 +323,11 @@ def main():
                          "lf_steps_per_position": float(steps_pp),
                          "rank_blocks_per_position": float(tallies[4] / max(tallies[7], 1)),
                          "seed_lookups_per_position": float(tallies[5] / max(tallies[7], 1))},
+            # k_repeat_probe runs before the range kernel (one lane per 64 positions); its work is not in `roofline`
+            "repeat_probes": {"enabled": bool(info.get("repeat_probes", 0)),
+                              "settled_fraction": probe["settled"] / max(my_pos, 1),
+                              "lf_steps_per_position": probe["lf_steps"] / max(my_pos, 1),
+                              "seed_lookups_per_position": probe["seed_lookups"] / max(my_pos, 1)},
             "host": {"index_build_s": t_build, "index_open_s": t_open},
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":      # the oracle's comparison-based

@@ -74,7 +74,10 @@ void nm_index_close(nm_index *ix);
 /* index facts: 0 n (BWT length), 1 forward text length, 2 separators, 3 records, 4 raw bases,
  * 5 seed length in use, 6 device bytes held, 7 sa_ratio recorded, 8 range kernel used by the last
  * launch (see NM_OPT_KERNEL), 9 core length of the pair table (0 = none), 10 device index,
- * 11 LF blocks in use, 12 two-step rank blocks in use */
+ * 11 LF blocks in use, 12 two-step rank blocks in use, 13 repeat probes enabled; of the last
+ * range-mode launch's repeat probes (waits for the device; 14..16 need
+ * NM_OPT_COUNT_STEPS): 14 LF steps, 15 rank blocks read, 16 seed entries read, 17 positions
+ * settled without a search */
 uint64_t nm_index_info(const nm_index *ix, int what);
 
 /* ------------------------------------------------------------------------- compat seam ------
@@ -141,7 +144,9 @@ enum {
     NM_OPT_FORCE_BIG = 6,          /* tests: use the kernels for indexes beyond 2^31 positions */
     NM_OPT_SEED_POLICY = 7,        /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */
     NM_OPT_TWO_STEP = 8,           /* walks on the two-step rank blocks (built only with NEWMAP_AMD_TWO_STEP=1) */
-    NM_OPT_LF_BLOCKS = 9           /* LF steps on the 16-byte LF entries (default when built) or the packed rank blocks */
+    NM_OPT_LF_BLOCKS = 9,          /* LF steps on the 16-byte LF entries (default when built) or the packed rank blocks */
+    NM_OPT_REPEAT_PROBES = 10      /* both-strand range mode: one probe per 64 positions settles stretches that occur
+                                      twice over more than kmax bases (default 1; 0 = every position searches for itself) */
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 

@@ -363,6 +363,50 @@ NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint
     return nm_min_unique_walk_any<BIG, RC>(ix, enc, p, w, lo, hi, k, kmin, kmax, err, t);
 }
 
+// Repeat probe (both-strand range mode).  A k-mer that is a substring of a string occurring twice
+// occurs twice itself, so ONE walk from P that is still not unique at length L settles every
+// position q in [P, P + L - kmax]: its kmax-mer lies inside S[P .. P+L), has no unique prefix of any
+// length <= kmax, and the element stored for it is 0 whatever kmin is (U_q = kmax: the span is free
+// of ambiguous bytes).  The probe extends to at most kmax + stride - 1 bases and returns how many
+// positions from P on are settled that way (0 .. stride); inside long repeats this replaces `stride`
+// walks of kmax steps by one walk of kmax + stride steps.  Never changes a result -- positions it does
+// not settle take the ordinary path.
+template <bool BIG>
+NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64_t P, uint32_t kmax,
+                               uint32_t stride, nm_tally &t) {
+    nm_window w = nm_load_window(enc, P);
+    if (w.amb & 1ULL) return 0;
+    const uint32_t cap = kmax + stride - 1;
+    const uint32_t s = ix.seed_len;
+    uint64_t lo = 0, hi = ix.n;
+    uint32_t k = 0, kbase = 0;
+    if (ix.seed && s && s <= kmax && (w.amb & ((1ULL << s) - 1ULL)) == 0) {
+        t.seeds++;
+        if (nm_seed_decode(NM_SEED_LOAD(ix, nm_seed_slot(w, s)), lo, hi)) {
+            if (hi - lo <= 1) return 0;                   // unique (or absent) within the seed: nothing to skip
+            k = s;
+        } else { lo = 0; hi = ix.n; }
+    }
+    uint32_t first_unique;                                // a lower bound of the least unique length at P
+    for (;;) {
+        const uint64_t cnt = hi - lo;
+        if (cnt == 0) return 0;                           // absent k-mer: the ordinary path reports it
+        if (cnt == 1) { first_unique = k; break; }        // every shorter prefix occurs twice
+        if (k >= cap) { first_unique = cap + 1; break; }
+        uint32_t j = k - kbase;
+        if (j >= 64) { w = nm_load_window(enc, P + k); kbase = k; j = 0; }
+        if ((w.amb >> j) & 1ULL) { first_unique = k + 1; break; }   // S[P .. P+k) occurs twice and ends the run
+        const uint32_t c = 3u - nm_window_code(w, j);
+        t.steps++;
+        t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u;
+        nm_lf_interval<BIG>(ix, c, lo, hi);
+        k++;
+    }
+    if (first_unique <= kmax) return 0;
+    const uint32_t settled = first_unique - kmax;         // q - P < first_unique - kmax
+    return settled < stride ? settled : stride;
+}
+
 // One position of list mode.
 template <bool BIG, bool RC>
 NM_HD uint32_t nm_fixed_k_one(const nm_view &ix, const nm_enc_word *enc, uint64_t p, uint64_t seq_len,

@@ -138,18 +138,49 @@ __device__ __forceinline__ void nm_store(void *out, int elem_bytes, uint64_t p, 
     else ((uint32_t *)out)[p] = v;
 }
 
+// ---- k_repeat_probe: one lane per NM_PROBE_STRIDE positions (nm_core.h: nm_repeat_probe) -------
+// Runs before the range kernel.  settled[j] = how many positions from j * NM_PROBE_STRIDE on lie
+// inside a stretch that occurs twice over at least kmax bases; the range kernel stores 0 for them and
+// neither reads a table line nor walks.  Lanes of a wave probe neighbouring strides, so inside a long
+// repeat they walk in step.  probe_tally (counter builds): LF steps, blocks, seed entries, settled.
+#define NM_PROBE_STRIDE 64u
+template <bool BIG, bool STATS>
+__global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_probes,
+                                                           uint32_t kmax, uint8_t *__restrict__ settled,
+                                                           unsigned long long *__restrict__ probe_tally) {
+    const uint64_t j = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    nm_tally t = {0, 0, 0, 0};
+    uint32_t c = 0;
+    if (j < n_probes) {
+        c = nm_repeat_probe<BIG>(ix, enc, j * NM_PROBE_STRIDE, kmax, NM_PROBE_STRIDE, t);
+        settled[j] = (uint8_t)c;
+    }
+    if (STATS) {
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), d = wave_sum(t.seeds), e = wave_sum(c);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&probe_tally[0], (unsigned long long)a);
+            atomicAdd(&probe_tally[1], (unsigned long long)b);
+            atomicAdd(&probe_tally[2], (unsigned long long)d);
+            atomicAdd(&probe_tally[3], (unsigned long long)e);
+        }
+    }
+}
+
 template <bool BIG, bool RC, bool STATS>
 __global__ __launch_bounds__(NM_BLOCK) void k_min_unique(nm_view ix, const nm_enc_word *__restrict__ enc,
                                                          uint64_t num_kmers, uint32_t kmin, uint32_t kmax,
                                                          void *__restrict__ out, int elem_bytes,
-                                                         uint64_t *__restrict__ status) {
+                                                         uint64_t *__restrict__ status,
+                                                         const uint8_t *__restrict__ settled) {
     const uint64_t p = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     const bool inb = p < num_kmers;
     bool amb0 = false, err = false;
     nm_tally t = {0, 0, 0, 0};
     uint32_t r = 0;
     if (inb) {
-        r = nm_min_unique_one<BIG, RC>(ix, enc, p, kmin, kmax, amb0, err, t);
+        // positions a repeat probe has settled (k_repeat_probe) store 0 without touching the index
+        if (!(settled && (uint32_t)(p & (NM_PROBE_STRIDE - 1)) < settled[p / NM_PROBE_STRIDE]))
+            r = nm_min_unique_one<BIG, RC>(ix, enc, p, kmin, kmax, amb0, err, t);
         nm_store(out, elem_bytes, p, r);
     }
     nm_epilogue<STATS>(inb, amb0, err, p, t, status);
@@ -254,7 +285,8 @@ template <bool BIG, bool STATS>
 __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const nm_enc_word *__restrict__ enc,
                                                               uint64_t n_enc_words, uint64_t num_kmers,
                                                               uint32_t kmin, uint32_t kmax, void *__restrict__ out,
-                                                              int elem_bytes, uint64_t *__restrict__ status) {
+                                                              int elem_bytes, uint64_t *__restrict__ status,
+                                                              const uint8_t *__restrict__ settled) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * 128ull;
@@ -279,8 +311,11 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
     const bool in0 = p0 < num_kmers, in1 = p1 < num_kmers;
     const bool amb0 = (win0.amb & 1ULL) != 0, amb1 = (win0.amb & 2ULL) != 0;
     const bool core_ok = ((win0.amb >> 1) & core_mask) == 0;
-    const bool go0 = in0 && !amb0 && core_ok;                                   // bases 0..m unambiguous
-    const bool go1 = in1 && core_ok && !((win0.amb >> s) & 1ULL);               // bases 1..m+1 unambiguous
+    // positions a repeat probe has settled store 0 and read nothing (p0, p1 share a probe stride)
+    const uint32_t n_settled = (settled && in0) ? settled[p0 / NM_PROBE_STRIDE] : 0u;
+    const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
+    const bool go0 = in0 && !amb0 && core_ok && off0 >= n_settled;               // bases 0..m unambiguous
+    const bool go1 = in1 && core_ok && !((win0.amb >> s) & 1ULL) && off0 + 1 >= n_settled;   // bases 1..m+1 unambiguous
     const uint64_t slot = ((win0.lo >> 1) & core_mask) | (((win0.hi >> 1) & core_mask) << m);
     const uint64_t *blk = ix.pair + slot * 8;
     uint64_t e0 = 0, e1 = 0;
@@ -645,9 +680,10 @@ __global__ __launch_bounds__(NM_BLOCK) void k_multi(nm_multi_args a, uint64_t se
     nm_epilogue<false>(inb, amb0, err, p, t, status);
 }
 
+#define NM_WORK_WORDS 8
 __global__ void k_reset_status(uint64_t *__restrict__ status, unsigned long long *__restrict__ work) {
     if (threadIdx.x < NM_STATUS_WORDS) status[threadIdx.x] = threadIdx.x == 2 ? ~0ULL : 0ULL;
-    if (threadIdx.x == 0 && work) *work = 0ULL;
+    if (threadIdx.x < NM_WORK_WORDS && work) work[threadIdx.x] = 0ULL;   // [0] chunk counter of k_min_unique_v2, [1..4] probe tally
 }
 
 // ------------------------------------------------------------------------------ host side ---
@@ -681,7 +717,8 @@ struct nm_index {
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
-    nm_buffer enc, seq, out, status, ks, starts, lens, work;
+    nm_buffer enc, seq, out, status, ks, starts, lens, work, settled;
+    bool repeat_probes = true;            // k_repeat_probe before the both-strand range kernels (NM_OPT_REPEAT_PROBES)
     uint64_t enc_words = 0;               // words written by the last nm_encode
     int kernel_version = 0;               // 0 = automatic (pair kernel when its table exists, else 1); 1..4 force a kernel
     unsigned persistent_blocks = 2048;    // set from the device properties at open
@@ -1021,7 +1058,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         }
     }
     rc = nm_grow(ix->status, NM_STATUS_WORDS * sizeof(uint64_t));
-    if (rc == NM_OK) rc = nm_grow(ix->work, sizeof(unsigned long long));
+    if (rc == NM_OK) rc = nm_grow(ix->work, NM_WORK_WORDS * sizeof(unsigned long long));
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     {
         hipDeviceProp_t prop;
@@ -1037,7 +1074,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_rank2, ix->d_super2, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
-                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p};
+                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p, ix->settled.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
@@ -1061,6 +1098,13 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 10: return (uint64_t)ix->device;
         case 11: return ix->view.lfb ? 1 : 0;
         case 12: return ix->view.rank2 ? 1 : 0;
+        case 13: return ix->repeat_probes ? 1 : 0;
+        case 14: case 15: case 16: case 17: {              // probe tally of the last range-mode launch
+            unsigned long long v = 0;
+            if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
+            if (hipMemcpy(&v, (const unsigned long long *)ix->work.p + 1 + (what - 14), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+            return v;
+        }
         default: return 0;
     }
 }
@@ -1085,6 +1129,10 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     }
     if (option == NM_OPT_FORCE_BIG) {      // tests: run the >2^31-position code path on a small index
         ix->big = value != 0 || ix->h.n_super > 1;
+        return NM_OK;
+    }
+    if (option == NM_OPT_REPEAT_PROBES) {
+        ix->repeat_probes = value != 0;
         return NM_OK;
     }
     if (option == NM_OPT_KERNEL) {
@@ -1150,10 +1198,22 @@ static int nm_check_segment_args(const nm_index *ix, uint64_t seq_len, uint64_t 
 }
 
 template <bool BIG, bool RC>
-static void launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, void *d_out,
+static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, void *d_out,
                               int elem_bytes, uint64_t *d_status, hipStream_t st) {
     const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    const bool pair_kernel = RC && (ix->kernel_version == 4 || ix->kernel_version == 0) && view.pair && kmin >= view.pair_m + 1;
+    // repeat probes feed the two kernels that take a `settled` array: the pair kernel and k_min_unique
+    const uint8_t *settled = nullptr;
+    if (RC && ix->repeat_probes && ix->kernel_version != 2 && ix->kernel_version != 3) {
+        const uint64_t n_probes = (num_kmers + NM_PROBE_STRIDE - 1) / NM_PROBE_STRIDE;
+        const int rc = nm_grow(ix->settled, n_probes);
+        if (rc != NM_OK) return rc;
+        unsigned long long *tally = (unsigned long long *)ix->work.p + 1;
+        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes)), block, 0, st, view, enc, n_probes, kmax, (uint8_t *)ix->settled.p, tally);
+        else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes)), block, 0, st, view, enc, n_probes, kmax, (uint8_t *)ix->settled.p, tally);
+        settled = (const uint8_t *)ix->settled.p;
+    }
     nm_timed timed(ix, st);
     if (RC && ix->kernel_version == 2) {
         ix->last_kernel = 2;
@@ -1165,15 +1225,15 @@ static void launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_km
         unsigned long long *work = (unsigned long long *)ix->work.p;
         if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_v2<BIG, true>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
         else                 hipLaunchKernelGGL((k_min_unique_v2<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
-        return;
+        return NM_OK;
     }
-    if (RC && (ix->kernel_version == 4 || ix->kernel_version == 0) && view.pair && kmin >= view.pair_m + 1) {
+    if (pair_kernel) {
         const uint64_t per_block = (uint64_t)NM_BLOCK * 2;
         const dim3 pgrid((unsigned)((num_kmers + per_block - 1) / per_block));
         ix->last_kernel = 4;
-        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_pair<BIG, true>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
-        else                 hipLaunchKernelGGL((k_min_unique_pair<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
-        return;
+        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_pair<BIG, true>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+        else                 hipLaunchKernelGGL((k_min_unique_pair<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+        return NM_OK;
     }
     if (ix->kernel_version == 3) {
         ix->last_kernel = 3;
@@ -1181,12 +1241,13 @@ static void launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_km
         const dim3 mgrid((unsigned)((num_kmers + per_block - 1) / per_block));
         if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_mp<BIG, RC, true>), mgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
         else                 hipLaunchKernelGGL((k_min_unique_mp<BIG, RC, false>), mgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
-        return;
+        return NM_OK;
     }
     const dim3 grid(nm_grid(num_kmers));
     ix->last_kernel = 1;
-    if (ix->count_steps) hipLaunchKernelGGL((k_min_unique<BIG, RC, true>), grid, block, 0, st, view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
-    else                 hipLaunchKernelGGL((k_min_unique<BIG, RC, false>), grid, block, 0, st, view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
+    if (ix->count_steps) hipLaunchKernelGGL((k_min_unique<BIG, RC, true>), grid, block, 0, st, view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+    else                 hipLaunchKernelGGL((k_min_unique<BIG, RC, false>), grid, block, 0, st, view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+    return NM_OK;
 }
 
 extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
@@ -1204,8 +1265,11 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
     if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
     nm_view view;
     if ((rc = nm_view_for(ix, kmin, &view)) != NM_OK) return rc;
-    if (ix->big) { if (use_revcomp) launch_min_unique<true, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); else launch_min_unique<true, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); }
-    else         { if (use_revcomp) launch_min_unique<false, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); else launch_min_unique<false, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st); }
+    if (ix->big) rc = use_revcomp ? launch_min_unique<true, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st)
+                                  : launch_min_unique<true, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st);
+    else         rc = use_revcomp ? launch_min_unique<false, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st)
+                                  : launch_min_unique<false, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st);
+    if (rc != NM_OK) return rc;
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }

@@ -59,6 +59,21 @@ public:
     T *data() { return p_; }
     T &operator[](uint64_t i) { return p_[i]; }
     void release() { free(p_); p_ = nullptr; }
+    // first touch by all threads, each on its own contiguous slice: page faults are then taken in
+    // parallel and sequentially instead of inside a random scatter
+    void touch(uint64_t n) {
+        const int nt = pd_threads();
+#pragma omp parallel num_threads(nt)
+        {
+#ifdef _OPENMP
+            const int t = omp_get_thread_num();
+#else
+            const int t = 0;
+#endif
+            const uint64_t a = n * (uint64_t)t / nt, b = n * (uint64_t)(t + 1) / nt;
+            if (b > a) memset((void *)(p_ + a), 0, (size_t)(b - a) * sizeof(T));
+        }
+    }
 private:
     T *p_;
 };
@@ -170,6 +185,7 @@ void pd_suffix_array(const uint8_t *s, uint64_t n, I *SA) {
 
     // ---- 2. group heads and ranks
     PdBuf<I> R(n);                                           // R[i] = index of the head of i's group
+    R.touch(n);
     PdBuf<I> &H = V2;                                        // H[j] = head index of sorted position j
     std::vector<std::vector<PdGroup<I>>> tg((size_t)nt);
     {

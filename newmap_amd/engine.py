@@ -55,6 +55,8 @@ class Index:
         self._lock = threading.Lock()
         if os.environ.get("NEWMAP_AMD_KERNEL"):            # A/B measurements, see set_kernel
             self.set_kernel(int(os.environ["NEWMAP_AMD_KERNEL"]))
+        if os.environ.get("NEWMAP_AMD_REPEAT_PROBES"):
+            self.set_repeat_probes(os.environ["NEWMAP_AMD_REPEAT_PROBES"] != "0")
         if os.environ.get("NEWMAP_AMD_SEED_POLICY"):
             _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SEED_POLICY,
                                                  int(os.environ["NEWMAP_AMD_SEED_POLICY"])))
@@ -86,8 +88,14 @@ class Index:
     def info(self) -> dict:
         names = ["bwt_length", "forward_text_length", "separators", "records", "raw_bases",
                  "seed_length", "device_bytes", "sa_ratio", "last_range_kernel", "pair_core_length", "device",
-                 "lf_blocks", "two_step_blocks"]
+                 "lf_blocks", "two_step_blocks", "repeat_probes"]
         return {n: int(self._L.nm_index_info(self.handle, i)) for i, n in enumerate(names)}
+
+    def probe_tally(self) -> dict:
+        """Repeat probes of the last range-mode launch: positions settled without a search and (with
+        set_count_steps) the LF steps, rank blocks and seed entries the probes read."""
+        names = ["lf_steps", "rank_blocks", "seed_lookups", "settled"]
+        return {n: int(self._L.nm_index_info(self.handle, 14 + i)) for i, n in enumerate(names)}
 
     def set_count_steps(self, on: bool):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_COUNT_STEPS, int(bool(on))))
@@ -98,6 +106,11 @@ class Index:
 
     def set_persistent_blocks(self, blocks: int):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_PERSISTENT_BLOCKS, int(blocks)))
+
+    def set_repeat_probes(self, on: bool):
+        """A/B: one probe per 64 positions settles stretches that occur twice over more than kmax bases
+        (default on); off = every position searches for itself.  Results are identical."""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_REPEAT_PROBES, int(bool(on))))
 
     def set_lf_blocks(self, on: bool):
         """LF steps read one 16-byte LF entry (default) or the packed 32-byte rank block"""

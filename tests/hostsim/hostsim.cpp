@@ -234,6 +234,22 @@ int hs_min_unique(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t n
     return status[1] ? 8 : 0;
 }
 
+// the repeat probes of one segment (k_repeat_probe): settled[j] for every stride; returns the LF steps spent
+uint64_t hs_repeat_probes(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmax,
+                          uint32_t stride, uint8_t *settled) {
+    std::vector<nm_enc_word> enc;
+    hs_encode(seq, seq_len, enc);
+    uint64_t steps = 0;
+    const uint64_t n_probes = (num_kmers + stride - 1) / stride;
+    for (uint64_t j = 0; j < n_probes; j++) {
+        nm_tally t = {0, 0, 0, 0};
+        settled[j] = (uint8_t)(ix->big ? nm_repeat_probe<true>(ix->v, enc.data(), j * stride, kmax, stride, t)
+                                       : nm_repeat_probe<false>(ix->v, enc.data(), j * stride, kmax, stride, t));
+        steps += t.steps;
+    }
+    return steps;
+}
+
 int hs_fixed_k(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks,
                uint32_t nk, int use_rc, int elem_bytes, void *out, uint64_t *status) {
     std::vector<nm_enc_word> enc;

@@ -371,6 +371,60 @@ def test_config5_tandem_repeats_20_255(tmp_path, eng):
     assert 0.2 < np.count_nonzero(want == 0) / want.size < 0.8      # repeats really are not unique
 
 
+def test_repeat_probes_change_the_work_not_the_result(tmp_path, mixed_genome, eng):
+    """k_repeat_probe: one probe per 64 positions settles the stretches that occur twice over more than
+    kmax bases.  Same output with probes on and off (both kernels that consume them), most zero
+    positions of a tandem-rich genome are settled, and the LF steps drop by an order of magnitude."""
+    from newmap_amd import _lib, synth
+    recs = synth.config_genome("c5", 2.0)
+    fa, idx = _build_index(tmp_path, _records_fasta(recs), "c5p")
+    rec = recs[0][1].tobytes()
+    L = _lib.lib()
+    d_seq, d_out, d_st = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.nm_dev_alloc(0, len(rec), ctypes.byref(d_seq)) == 0
+    assert L.nm_dev_alloc(0, len(rec), ctypes.byref(d_out)) == 0
+    assert L.nm_dev_alloc(0, 64, ctypes.byref(d_st)) == 0
+    buf = np.frombuffer(rec, np.uint8)
+    assert L.nm_dev_upload(0, d_seq, buf.ctypes.data, buf.size) == 0
+
+    def run(ix):
+        ix.min_unique_segment_dev(d_seq.value, len(rec), len(rec), 20, 255, True, 1, d_out.value, d_st.value)
+        assert L.nm_dev_sync(0) == 0
+        got, st = np.zeros(len(rec), np.uint8), np.zeros(8, np.uint64)
+        assert L.nm_dev_download(0, got.ctypes.data, d_out, got.size) == 0
+        assert L.nm_dev_download(0, st.ctypes.data, d_st, 64) == 0
+        return got, st
+
+    with eng.Index(idx, 0) as ix:
+        assert ix.info()["repeat_probes"] == 1
+        ix.set_count_steps(True)
+        for kernel in (0, 1):
+            ix.set_kernel(kernel)
+            ix.set_repeat_probes(True)
+            on, st_on = run(ix)
+            tally = ix.probe_tally()
+            steps_on = int(st_on[3]) + tally["lf_steps"]
+            ix.set_repeat_probes(False)
+            off, st_off = run(ix)
+            assert ix.probe_tally()["settled"] == 0
+            assert np.array_equal(on, off), kernel
+            assert int(st_on[0]) == int(st_off[0]) and int(st_on[7]) == int(st_off[7])
+            zeros = int(np.count_nonzero(off == 0))
+            assert tally["settled"] > 0.8 * zeros, (tally, zeros)
+            assert steps_on * 8 < int(st_off[3]), (kernel, steps_on, int(st_off[3]))
+    for d in (d_seq, d_out, d_st):
+        L.nm_dev_free(0, d)
+    g = mixed_genome                                               # N runs, soft-masked and reverse-complement copies
+    with eng.Index(g["idx"], 0) as ix:
+        for rec in (g["r1"], g["r2"]):
+            for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (3, 5)):
+                ix.set_repeat_probes(True)
+                a, amb_a = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                ix.set_repeat_probes(False)
+                b, amb_b = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                assert np.array_equal(a, b) and amb_a == amb_b, (kmin, kmax)
+
+
 @pytest.mark.parametrize("k", [36, 100])
 def test_config4_fixed_k(tmp_path, eng, k):
     """BASELINE configs[3] shape (fixed-k list mode, k = 36 and 100) on a scaled human-shaped genome

@@ -253,3 +253,45 @@ def test_two_step_rank_blocks(tmp_path, golden_search):
             got = _engine_unique(sim, t, c["kmer_lengths"], True, c["batch"], True)
             for rid, exp in c["expected"].items():
                 assert got[rid.encode()].tolist() == exp["values"], (c["name"], rid, seed)
+
+
+def test_repeat_probes_settle_only_zero_positions(tmp_path):
+    """nm_repeat_probe (the logic of k_repeat_probe): every position a probe settles has no unique
+    k-mer up to kmax according to the oracle, long repeats ARE settled, and the probes cost far fewer
+    LF steps than the walks they replace."""
+    rng = np.random.default_rng(2027)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    r1 = bytearray(bytes(alpha[rng.integers(0, 4, 24000)]))
+    unit = bytes(alpha[rng.integers(0, 4, 11)])
+    r1[3000:9000] = (unit * 600)[:6000]                    # tandem array
+    r1[15000:16200] = r1[1000:2200]                        # dispersed 1.2 kb copy
+    r1[15500:15503] = b"NNN"                               # ... broken by ambiguous bytes
+    rc_src = bytes(r1[20000:20900])[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+    r2 = bytes(alpha[rng.integers(0, 4, 5000)]) + rc_src    # reverse-complement copy in another record
+    text = b">one\n" + bytes(r1) + b"\n>two\n" + r2 + b"\n"
+    fa = _write(tmp_path, text)
+    idx = tmp_path / "p.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    oracle = rd.OracleIndex([bytes(r1), r2])
+    for seed in (0, 6):
+        sim = HostSim(idx, seed)
+        for rec in (bytes(r1), r2):
+            for kmax, stride in ((60, 64), (200, 64), (255, 64), (30, 16), (5, 64)):
+                dtype, _ = rd.output_dtype(kmax)
+                n = len(rec)
+                want = rd.closed_form_min_unique(rec, oracle, min(20, kmax), kmax, True)
+                settled, steps = sim.repeat_probes(rec, n, kmax, stride)
+                total = 0
+                for j, c in enumerate(settled):
+                    assert c <= stride
+                    lo = j * stride
+                    assert not want[lo:lo + int(c)].any(), (seed, kmax, stride, j)
+                    # a settled position's kmax-mer lies inside the record and has no ambiguous byte
+                    assert lo + int(c) + kmax - 1 <= n or c == 0
+                    total += int(c)
+                if rec is not r2 and kmax <= 255:
+                    zeros_in_array = int((want[3000:9000 - kmax] == 0).sum())
+                    assert total >= 0.9 * zeros_in_array, (total, zeros_in_array)
+        # the reverse-complement copy is seen through the both-strand index
+        settled, _ = sim.repeat_probes(r2, len(r2), 200, 64)
+        assert settled[5000 // 64 + 1:].sum() > 400

@@ -299,7 +299,7 @@ def main():
         avg_launch_ms = kern_ms / max(n_launch, 1)
         achieved = per_launch_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         kernel_name = {1: "k_min_unique", 2: "k_min_unique_v2", 3: "k_min_unique_mp",
-                       4: "k_min_unique_pair"}.get(ix.info()["last_range_kernel"], "?")
+                       4: "k_min_unique_pair", 5: "k_min_unique_quad"}.get(ix.info()["last_range_kernel"], "?")
         traffic, traffic_src = measured_traffic(kernel_name, args.config, my_pos / max(len(segs), 1))
         result = {
             "metric": f"genome positions/sec (min-unique-k search, {KMIN}:{KMAX})",
@@ -313,6 +313,7 @@ def main():
                        "records": len(recs),
                        "positions": n, "batch": args.batch, "segments_per_rank": len(segs),
                        "seed_length": info["seed_length"], "pair_core_length": info["pair_core_length"],
+                       "quad_core_length": info.get("quad_core_length", 0),
                        "index_bytes_hbm": info["device_bytes"],
                        "parallelism": f"positions sharded over {world} GPU(s), index replicated"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -322,7 +323,7 @@ def main():
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "lf_steps_per_position": float(steps_pp),
                          "rank_blocks_per_position": float(tallies[4] / max(tallies[7], 1)),
-                         "seed_lookups_per_position": float(tallies[5] / max(tallies[7], 1))},
+                         "table_words_per_position": float(tallies[5] / max(tallies[7], 1))},
             # k_repeat_probe runs before the range kernel (one lane per 64 positions); its work is not in `roofline`
             "repeat_probes": {"enabled": bool(info.get("repeat_probes", 0)),
                               "settled_fraction": probe["settled"] / max(my_pos, 1),

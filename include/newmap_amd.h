@@ -77,7 +77,7 @@ void nm_index_close(nm_index *ix);
  * 11 LF blocks in use, 12 two-step rank blocks in use, 13 repeat probes enabled; of the last
  * range-mode launch's repeat probes (waits for the device; 14..16 need
  * NM_OPT_COUNT_STEPS): 14 LF steps, 15 rank blocks read, 16 seed entries read, 17 positions
- * settled without a search */
+ * settled without a search; 18 core length of the quad table (0 = none) */
 uint64_t nm_index_info(const nm_index *ix, int what);
 
 /* ------------------------------------------------------------------------- compat seam ------
@@ -139,7 +139,9 @@ enum {
     NM_OPT_TIMING = 3,
     NM_OPT_KERNEL = 4,             /* range-mode kernel: 0 automatic (default), 1 one lane per position,
                                       2 persistent lanes, 3 several positions per lane, 4 position
-                                      pairs on the pair table (one 128-byte line per two positions) */
+                                      pairs on the pair table (one 128-byte line per two positions),
+                                      5 position quads on the quad table (one line per four positions;
+                                      needs kmin >= its core length + 3) */
     NM_OPT_PERSISTENT_BLOCKS = 5,  /* grid size of the persistent kernel (default 8 x CUs) */
     NM_OPT_FORCE_BIG = 6,          /* tests: use the kernels for indexes beyond 2^31 positions */
     NM_OPT_SEED_POLICY = 7,        /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */

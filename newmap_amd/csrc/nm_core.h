@@ -53,6 +53,8 @@ struct nm_view {                // the index as the kernels see it
     const nm_lf_entry *lfb;     // LF blocks: one 16-byte load per LF step (nullptr = use the packed rank blocks)
     const nm_rank2_block *rank2;   // two-step rank blocks (nullptr = not built)
     const uint64_t *superC2;    // [n_super][16]: first row of the suffixes starting "y x" + pairs before the superblock
+    const uint64_t *quad;       // quad table: 4^quad_m entries of 4 x u64 (nullptr = not built), see nm_quad_build_one
+    uint32_t quad_m;            // its core length; it answers windows of quad_m + 3 bases
 };
 
 struct nm_tally {               // counter build only
@@ -63,9 +65,14 @@ struct nm_tally {               // counter build only
 #define NM_SEED_LO_MASK ((1ULL << NM_SEED_LO_BITS) - 1)
 #define NM_SEED_CNT_SAT 0xFFFFFFu
 
-NM_HD uint32_t nm_base_code(uint32_t byte) {     // 0..3 for ACGTacgt, 4 otherwise
-    uint32_t u = byte & 0xDFu;
-    return u == 0x41u ? 0u : (u == 0x43u ? 1u : (u == 0x47u ? 2u : (u == 0x54u ? 3u : 4u)));
+// 0..3 for ACGTacgt, 4 otherwise.  Branch-free (a compare chain compiles to divergent branches per byte):
+// with bit 5 cleared the four letters are 0x41 0x43 0x47 0x54 -- bits 1 and 2 spell A=00 C=01 G=11 T=10,
+// and the letters are picked out of the 0x40..0x5F column by a 32-bit membership mask.
+NM_HD uint32_t nm_base_code(uint32_t byte) {
+    const uint32_t u = byte & 0xDFu;
+    const uint32_t is_base = (uint32_t)((u >> 5) == 2u) & ((0x0010008Au >> (u & 31u)) & 1u);
+    const uint32_t code = ((u >> 1) & 3u) ^ ((u >> 2) & 1u);
+    return is_base ? code : 4u;
 }
 
 NM_HD uint32_t nm_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
@@ -684,6 +691,118 @@ NM_HD uint64_t nm_pair_seed_slot(uint64_t core_slot, uint32_t m, uint32_t e) {
     if (e < 4) return (uint64_t)(e & 1u) | (ylo << 1) | ((uint64_t)(e >> 1) << s) | (yhi << (s + 1));
     const uint32_t b = e - 4;
     return ylo | ((uint64_t)(b & 1u) << m) | (yhi << s) | ((uint64_t)(b >> 1) << (s + m));
+}
+
+// ---- quad table: ONE 32-byte entry settles FOUR neighbouring positions ---------------------------
+// Range mode only asks "which is the least length with one occurrence", and when the window of
+// w = m + 3 bases at a position already occurs once and w <= kmin the answer is kmin -- one BIT per
+// w-mer is enough.  Positions p .. p+3 share the m-mer core Y = S[p+3 .. p+3+m): the window of
+// position p+i is  L.Y.R  with the 3-i bases L before the core and the i bases R after it, so the
+// 4 x 4^3 = 256 bits "L.Y.R occurs exactly once (both strands)" of one core fill one 32-byte entry
+// and a lane that owns four positions reads one 128-byte line for all of them (the pair table needs
+// two lines, a plain seed table four).  Word i of an entry belongs to position p+i; bit index:
+//      i = 0:  l0 | l1<<2 | l2<<4        i = 1:  l0 | l1<<2 | r0<<4
+//      i = 2:  r0 | r1<<2 | l0<<4        i = 3:  r0 | r1<<2 | r2<<4         (bases in text order)
+// The table is derived from the seed table of length m without atomics: the lane of m-mer Z walks the
+// (pruned) tree of its 64 three-base extensions; the leaves are word 3 of entry Z, and -- the index
+// holds both strands, so a string and its reverse complement have the same count -- also word 0 of
+// entry rc(Z).  The same leaves, read as Z[0] . (Z[1..m) b1) . b2 b3, are a 16-bit piece of word 2 of
+// four entries and, mirrored, of word 1 of four more.  Every 16-bit piece of the table is written once.
+#define NM_QUAD_EXT 3u
+
+NM_HD uint64_t nm_bit_reverse64(uint64_t x) {
+    x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+    return (x >> 32) | (x << 32);
+}
+
+// slot of the reverse complement of the m-mer a slot spells (reverse each plane, flip both)
+NM_HD uint64_t nm_slot_revcomp(uint64_t slot, uint32_t m) {
+    const uint64_t mask = (1ULL << m) - 1ULL;
+    const uint64_t lo = nm_bit_reverse64(~(slot & mask)) >> (64 - m);
+    const uint64_t hi = nm_bit_reverse64(~((slot >> m) & mask)) >> (64 - m);
+    return (lo & mask) | ((hi & mask) << m);
+}
+
+// one extension step of the table walk: children of an interval; a one-row interval has exactly one
+// child, named by its BWT symbol, which saves three of the four LF steps
+template <bool BIG>
+NM_HD void nm_quad_children(const nm_view &ix, uint64_t lo, uint64_t hi, uint64_t clo[4], uint64_t chi[4]) {
+    for (uint32_t b = 0; b < 4; b++) { clo[b] = 0; chi[b] = 0; }
+    if (hi <= lo) return;
+    if (hi - lo == 1) {
+        uint32_t c;
+        if (!nm_bwt_code(ix, lo, c)) return;               // preceded by a separator: no extension
+        const uint64_t r = nm_lf<BIG>(ix, c, lo);
+        clo[3u - c] = r; chi[3u - c] = r + 1;              // appending base b = prepending its complement
+        return;
+    }
+    for (uint32_t b = 0; b < 4; b++) {
+        uint64_t l = lo, h = hi;
+        nm_lf_interval<BIG>(ix, 3u - b, l, h);
+        if (h > l) { clo[b] = l; chi[b] = h; }
+    }
+}
+
+// all pieces of the quad table that the m-mer Z determines (ix.seed = seed table of length m)
+template <bool BIG>
+NM_HD void nm_quad_build_one(const nm_view &ix, uint64_t Z, uint32_t m, uint64_t *quad) {
+    uint64_t lo = 0, hi = 0;
+    if (!nm_seed_decode(ix.seed[Z], lo, hi)) {             // saturated size: walk the m bases
+        lo = 0; hi = ix.n;
+        for (uint32_t j = 0; j < m && lo < hi; j++) nm_lf_interval<BIG>(ix, 3u - nm_seed_slot_code(Z, m, j), lo, hi);
+    }
+    uint64_t w3 = 0, w0 = 0;
+    uint32_t piece2[4] = {0, 0, 0, 0}, piece1[4] = {0, 0, 0, 0};
+    uint64_t l1[4], h1[4], l2[4], h2[4], l3[4], h3[4];
+    nm_quad_children<BIG>(ix, lo, hi, l1, h1);
+    for (uint32_t b1 = 0; b1 < 4; b1++) {
+        if (h1[b1] <= l1[b1]) continue;
+        nm_quad_children<BIG>(ix, l1[b1], h1[b1], l2, h2);
+        for (uint32_t b2 = 0; b2 < 4; b2++) {
+            if (h2[b2] <= l2[b2]) continue;
+            nm_quad_children<BIG>(ix, l2[b2], h2[b2], l3, h3);
+            for (uint32_t b3 = 0; b3 < 4; b3++) {
+                if (h3[b3] - l3[b3] != 1) continue;        // Z b1 b2 b3 occurs exactly once
+                w3 |= 1ULL << (b1 | (b2 << 2) | (b3 << 4));
+                w0 |= 1ULL << ((3u - b3) | ((3u - b2) << 2) | ((3u - b1) << 4));
+                piece2[b1] |= 1u << (b2 | (b3 << 2));
+                piece1[b1] |= 1u << ((3u - b3) | ((3u - b2) << 2));
+            }
+        }
+    }
+    const uint64_t mask = (1ULL << m) - 1ULL;
+    const uint64_t zlo = Z & mask, zhi = (Z >> m) & mask;
+    const uint32_t first = (uint32_t)(zlo & 1ULL) | ((uint32_t)(zhi & 1ULL) << 1);          // Z[0]
+    quad[Z * 4 + 3] = w3;
+    quad[nm_slot_revcomp(Z, m) * 4 + 0] = w0;
+    for (uint32_t b1 = 0; b1 < 4; b1++) {
+        const uint64_t core = (zlo >> 1) | ((uint64_t)(b1 & 1u) << (m - 1)) |
+                              (((zhi >> 1) | ((uint64_t)(b1 >> 1) << (m - 1))) << m);      // Z[1..m) b1
+        ((uint16_t *)(quad + core * 4 + 2))[first] = (uint16_t)piece2[b1];
+        ((uint16_t *)(quad + nm_slot_revcomp(core, m) * 4 + 1))[3u - first] = (uint16_t)piece1[b1];
+    }
+}
+
+// core slot of the four positions whose first window is `w`
+NM_HD uint64_t nm_quad_slot(const nm_window &w, uint32_t m) {
+    const uint64_t mask = (1ULL << m) - 1ULL;
+    return ((w.lo >> NM_QUAD_EXT) & mask) | (((w.hi >> NM_QUAD_EXT) & mask) << m);
+}
+
+// bit i of the result: the (m+3)-mer at position i of the four occurs exactly once
+NM_HD uint32_t nm_quad_bits(const nm_window &w, uint32_t m, const uint64_t e[4]) {
+    const uint32_t c0 = nm_window_code(w, 0), c1 = nm_window_code(w, 1), c2 = nm_window_code(w, 2);
+    const uint32_t r0 = nm_window_code(w, 3 + m), r1 = nm_window_code(w, 4 + m), r2 = nm_window_code(w, 5 + m);
+    const uint32_t i0 = c0 | (c1 << 2) | (c2 << 4);
+    const uint32_t i1 = c1 | (c2 << 2) | (r0 << 4);
+    const uint32_t i2 = r0 | (r1 << 2) | (c2 << 4);
+    const uint32_t i3 = r0 | (r1 << 2) | (r2 << 4);
+    return (uint32_t)((e[0] >> i0) & 1ULL) | ((uint32_t)((e[1] >> i1) & 1ULL) << 1) |
+           ((uint32_t)((e[2] >> i2) & 1ULL) << 2) | ((uint32_t)((e[3] >> i3) & 1ULL) << 3);
 }
 
 #endif

@@ -40,8 +40,19 @@ static __device__ __forceinline__ uint64_t nm_seed_load_policy(const nm_view &ix
 
 // ------------------------------------------------------------------------------ kernels ----
 
+#define NM_WORK_WORDS 8             /* handle-owned counters: [0] chunk counter of k_min_unique_v2, [1..4] probe tally */
+
+// the status words of a launch (and the handle's counters) start from zero; folded into the encode
+// pass so that a segment costs one launch less (k_reset_status does the same on its own)
+__device__ __forceinline__ void nm_reset_words(uint64_t *__restrict__ status, unsigned long long *__restrict__ work) {
+    if (blockIdx.x == 0 && threadIdx.x < NM_STATUS_WORDS && status) status[threadIdx.x] = threadIdx.x == 2 ? ~0ULL : 0ULL;
+    if (blockIdx.x == 0 && threadIdx.x < NM_WORK_WORDS && work) work[threadIdx.x] = 0ULL;
+}
+
 __global__ __launch_bounds__(NM_BLOCK) void k_encode(const uint8_t *__restrict__ seq, uint64_t seq_len,
-                                                     nm_enc_word *__restrict__ enc, uint64_t n_words) {
+                                                     nm_enc_word *__restrict__ enc, uint64_t n_words,
+                                                     uint64_t *__restrict__ status, unsigned long long *__restrict__ work) {
+    nm_reset_words(status, work);
     // one wave per 64-base word: three ballots give the three planes
     const uint64_t wave = (blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
@@ -62,7 +73,9 @@ __global__ __launch_bounds__(NM_BLOCK) void k_encode(const uint8_t *__restrict__
 // 16 bases per lane (one 16-byte load), four lanes OR their 16-bit pieces into one 64-base word:
 // 1 KiB per wave-instruction instead of the 64 B of k_encode.  Needs a 16-byte aligned `seq`.
 __global__ __launch_bounds__(NM_BLOCK) void k_encode16(const uint8_t *__restrict__ seq, uint64_t seq_len,
-                                                       nm_enc_word *__restrict__ enc, uint64_t n_words) {
+                                                       nm_enc_word *__restrict__ enc, uint64_t n_words,
+                                                       uint64_t *__restrict__ status, unsigned long long *__restrict__ work) {
+    nm_reset_words(status, work);
     const uint64_t t = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     if (t >= n_words * 4) return;                       // groups of 4 lanes stay whole
     const uint64_t base = t * 16;
@@ -312,7 +325,12 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
     const bool amb0 = (win0.amb & 1ULL) != 0, amb1 = (win0.amb & 2ULL) != 0;
     const bool core_ok = ((win0.amb >> 1) & core_mask) == 0;
     // positions a repeat probe has settled store 0 and read nothing (p0, p1 share a probe stride)
-    const uint32_t n_settled = (settled && in0) ? settled[p0 / NM_PROBE_STRIDE] : 0u;
+    uint32_t n_settled = 0;                               // two strides per wave: wave-uniform addresses -> scalar loads
+    if (settled && wave_base < num_kmers) {
+        const uint32_t c_first = settled[w0];
+        const uint32_t c_second = wave_base + NM_PROBE_STRIDE < num_kmers ? settled[w0 + 1] : 0u;
+        n_settled = q < NM_PROBE_STRIDE ? c_first : c_second;
+    }
     const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
     const bool go0 = in0 && !amb0 && core_ok && off0 >= n_settled;               // bases 0..m unambiguous
     const bool go1 = in1 && core_ok && !((win0.amb >> s) & 1ULL) && off0 + 1 >= n_settled;   // bases 1..m+1 unambiguous
@@ -390,6 +408,145 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
             atomicAdd((unsigned long long *)&status[7], (unsigned long long)f);
         }
     }
+}
+
+
+// ---- k_min_unique_quad: one 128-byte line serves FOUR positions ---------------------------------
+// The pair kernel is bound by the table lines it fetches (one per two positions).  When kmin is at
+// least w = m + 3, all a position needs from the table is ONE BIT -- "the w-mer here occurs once" --
+// because the element stored is then kmin itself.  The quad table (nm_core.h) packs those bits for the
+// four positions that share an m-mer core into one 32-byte entry: a lane owns positions 4i .. 4i+3,
+// reads one entry, and only the positions whose w-mer is repeated (or absent) go on to the seed table
+// and the walk (stage 2, compacted through LDS like the pair kernel's).
+template <bool BIG, bool STATS>
+__global__ __launch_bounds__(NM_BLOCK) void k_min_unique_quad(nm_view ix, const nm_enc_word *__restrict__ enc,
+                                                              uint64_t n_enc_words, uint64_t num_kmers,
+                                                              uint32_t kmin, uint32_t kmax, void *__restrict__ out,
+                                                              int elem_bytes, uint64_t *__restrict__ status,
+                                                              const uint8_t *__restrict__ settled) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * 256ull;
+    const uint32_t m = ix.quad_m, w = m + NM_QUAD_EXT;
+
+    nm_enc_word W[5];                                     // wave-uniform -> scalar loads
+    const uint64_t w0 = wave_base >> 6;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        uint64_t wi = w0 + j;
+        if (wi >= n_enc_words) wi = n_enc_words - 1;
+        W[j] = enc[wi];
+    }
+    const uint32_t q = 4 * lane;                          // offset of the lane's first position in the wave's 256
+    const uint32_t qw = q >> 6;
+    // value selects, field by field: indexing W[] with a lane-varying index would put the array in scratch memory
+    nm_enc_word Wa, Wb;
+#define NM_SEL4(f, base) (qw == 0 ? W[base].f : (qw == 1 ? W[base + 1].f : (qw == 2 ? W[base + 2].f : W[base + 3].f)))
+    Wa.lo = NM_SEL4(lo, 0); Wa.hi = NM_SEL4(hi, 0); Wa.amb = NM_SEL4(amb, 0); Wa.pad = 0;
+    Wb.lo = NM_SEL4(lo, 1); Wb.hi = NM_SEL4(hi, 1); Wb.amb = NM_SEL4(amb, 1); Wb.pad = 0;
+#undef NM_SEL4
+    const nm_window win = nm_window_from(Wa, Wb, q & 63);            // bases p0 .. p0+63
+    const uint64_t p0 = wave_base + q;
+    const uint32_t n_settled = (settled && p0 < num_kmers) ? settled[p0 / NM_PROBE_STRIDE] : 0u;   // four positions, one stride
+    const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
+    // go: the position takes part in the lookup.  With kmin <= 60 the lane's 64-base window shows whether the
+    // first kmin bases are free of ambiguity (if not: U_p < kmin, element 0, search.py:437) and stage 1 is
+    // branch-free; longer kmin checks the w bases here and the rest with nm_all_valid.
+    const bool short_kmin = kmin <= 60;                    // wave-uniform
+    const uint64_t vmask = (1ULL << (short_kmin ? kmin : w)) - 1ULL;
+    bool in[4], go[4];
+    bool any_go = false;
+    uint32_t n_amb = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        in[i] = p0 + i < num_kmers;
+        n_amb += (uint32_t)(in[i] && ((win.amb >> i) & 1ULL));
+        go[i] = in[i] && ((win.amb >> i) & vmask) == 0 && off0 + i >= n_settled;
+        any_go |= go[i];
+    }
+    uint64_t e[4] = {0, 0, 0, 0};
+    if (any_go && !(ix.seed_policy & 0x200u)) {            // the core lies inside every window that is free of ambiguity
+        const ulonglong2 *ep = reinterpret_cast<const ulonglong2 *>(ix.quad + nm_quad_slot(win, m) * 4);
+        const ulonglong2 a = ep[0], b = ep[1];
+        e[0] = a.x; e[1] = a.y; e[2] = b.x; e[3] = b.y;
+    }
+    const uint32_t once = nm_quad_bits(win, m, e);
+    nm_tally t = {0, 0, 0, 0};
+    bool any_err = false;
+    uint64_t err_pos = ~0ULL;
+    __shared__ uint64_t q_p[NM_BLOCK * 4];
+    __shared__ uint32_t q_n;
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+    // ---- stage 1: what the entry alone decides.  once: least unique length <= w <= kmin, the element is kmin
+    // (if within U_p); otherwise the w-mer is repeated or absent: seed table + walk in stage 2
+    uint32_t r[4] = {0, 0, 0, 0};
+    uint32_t walk = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        const bool is_once = ((once >> i) & 1u) != 0;
+        if (short_kmin) {
+            r[i] = (go[i] && is_once) ? kmin : 0u;
+        } else if (go[i] && is_once) {
+            nm_window wi = nm_window_from(Wa, Wb, (q & 63) + i);
+            uint32_t kbase = 0;
+            r[i] = nm_all_valid(enc, p0 + i, wi, kbase, w, kmin) ? kmin : 0u;
+        }
+        walk |= (uint32_t)(go[i] && !is_once) << i;
+    }
+    if (walk) {
+        const uint32_t n = (uint32_t)__builtin_popcount(walk);
+        uint32_t at = atomicAdd(&q_n, n);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++)
+            if ((walk >> i) & 1u) q_p[at++] = p0 + i;
+    }
+    if (elem_bytes == 1 && in[3] && (((uintptr_t)out) & 3u) == 0) {
+        reinterpret_cast<uint32_t *>(out)[p0 >> 2] = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++)
+            if (in[i]) nm_store(out, elem_bytes, p0 + i, r[i]);
+    }
+    __syncthreads();                                       // stage 2 overwrites the placeholders of queued positions
+    // ---- stage 2: dense walks
+    const uint32_t n_walk = (ix.seed_policy & 0x100u) ? 0u : q_n;     // (0x100 / 0x200: timing experiments, wrong results)
+    for (uint32_t i = threadIdx.x; i < n_walk; i += NM_BLOCK) {
+        const uint64_t p = q_p[i];
+        bool amb0 = false, err = false;
+        const uint32_t v = nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
+        if (err) { any_err = true; if (p < err_pos) err_pos = p; }
+        nm_store(out, elem_bytes, p, v);
+    }
+
+    const uint32_t amb_sum = wave_sum(n_amb);
+    if (lane == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
+    if (__ballot(any_err)) {
+        if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
+        if (lane == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
+    }
+    if (STATS) {
+        uint32_t searched = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) searched += (uint32_t)(in[i] && !((win.amb >> i) & 1ULL));
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks),
+                       c = wave_sum((any_go ? 4u : 0u) + t.seeds),                 // 8-byte table words read
+                       f = wave_sum(searched);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)f);
+        }
+    }
+}
+
+// quad table from the seed table of the same length (nm_core.h: nm_quad_build_one)
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_quad_build(nm_view ix, uint64_t *__restrict__ quad, uint64_t first_slot,
+                                                         uint64_t n_slots, uint32_t m) {
+    const uint64_t slot = first_slot + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (slot < n_slots) nm_quad_build_one<BIG>(ix, slot, m, quad);
 }
 
 // level s of the seed table from level s-1 (one LF step per entry instead of s)
@@ -680,10 +837,9 @@ __global__ __launch_bounds__(NM_BLOCK) void k_multi(nm_multi_args a, uint64_t se
     nm_epilogue<false>(inb, amb0, err, p, t, status);
 }
 
-#define NM_WORK_WORDS 8
 __global__ void k_reset_status(uint64_t *__restrict__ status, unsigned long long *__restrict__ work) {
     if (threadIdx.x < NM_STATUS_WORDS) status[threadIdx.x] = threadIdx.x == 2 ? ~0ULL : 0ULL;
-    if (threadIdx.x < NM_WORK_WORDS && work) work[threadIdx.x] = 0ULL;   // [0] chunk counter of k_min_unique_v2, [1..4] probe tally
+    if (threadIdx.x < NM_WORK_WORDS && work) work[threadIdx.x] = 0ULL;
 }
 
 // ------------------------------------------------------------------------------ host side ---
@@ -711,6 +867,7 @@ struct nm_index {
     void *d_rank = nullptr, *d_strand = nullptr, *d_sep = nullptr, *d_seed = nullptr, *d_super = nullptr;
     void *d_seed2 = nullptr;              // small secondary seed table (nm_view_for)
     uint32_t seed2_len = 0;
+    void *d_quad = nullptr;               // quad table (k_min_unique_quad)
     void *d_pair = nullptr;               // pair table (k_min_unique_pair)
     void *d_rank2 = nullptr, *d_super2 = nullptr;   // two-step rank blocks + their superblock table
     void *d_lfb = nullptr;                // LF blocks
@@ -783,7 +940,33 @@ static int nm_seed_launch(nm_index *ix, const nm_view &v, const uint64_t *parent
 
 // build the 4^s table on the device: level 8 entry by entry, every further level from the one
 // below it (launches sliced so that grid * block stays below 2^32)
-static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table) {
+// quad table for cores of m bases, from the seed table of that length (a level of the seed-table build):
+// 4^m entries x 32 bytes
+static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m) {
+    ix->view.quad = nullptr;
+    ix->view.quad_m = 0;
+    if (!level_table || m < 3 || m > 16 || ix->h.n < 2) return NM_OK;
+    const uint64_t n_cores = 1ULL << (2 * m);
+    HIP_TRY(hipMalloc(&ix->d_quad, n_cores * 32));
+    ix->device_bytes += n_cores * 32;
+    nm_view v = ix->view;
+    v.seed = level_table;
+    v.seed_len = m;
+    const uint64_t slice = 1ULL << 30;
+    for (uint64_t first = 0; first < n_cores; first += slice) {
+        const uint64_t cnt = n_cores - first < slice ? n_cores - first : slice;
+        if (ix->big) hipLaunchKernelGGL(k_quad_build<true>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_quad, first, n_cores, m);
+        else         hipLaunchKernelGGL(k_quad_build<false>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_quad, first, n_cores, m);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->view.quad = (const uint64_t *)ix->d_quad;
+    ix->view.quad_m = m;
+    return NM_OK;
+}
+
+// quad_m: also derive the quad table from the level of that length (0 = none)
+static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table, uint32_t quad_m = 0) {
     const uint64_t n_slots = 1ULL << (2 * s);
     HIP_TRY(hipMalloc(d_table, n_slots * sizeof(uint64_t)));
     ix->device_bytes += n_slots * sizeof(uint64_t);
@@ -798,11 +981,23 @@ static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table) {
         if (level < s && hipMalloc(&dst, (8ULL << (2 * level))) != hipSuccess) { nm_set_error("hipMalloc failed for a seed level"); rc = NM_E_ALLOC; break; }
         rc = nm_seed_launch(ix, v, level == s0 ? nullptr : (const uint64_t *)cur, (uint64_t *)dst, level);
         if (rc == NM_OK && hipStreamSynchronize(ix->stream) != hipSuccess) { nm_set_error("seed table kernel failed"); rc = NM_E_DEVICE; }
+        if (rc == NM_OK && level == quad_m) rc = nm_build_quad(ix, (const uint64_t *)dst, level);
         if (cur) (void)hipFree(cur);
         cur = level < s ? dst : nullptr;
     }
     if (cur) (void)hipFree(cur);
     return rc;
+}
+
+// core length of the quad table: as long as the seed, at most a fifth of the free HBM (4^m x 32 bytes)
+static uint32_t nm_auto_quad_len(const nm_index *ix, uint32_t s) {
+    (void)ix;
+    uint32_t m = s;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    free_b -= free_b < (8ULL << (2 * s)) ? free_b : (8ULL << (2 * s));      // the seed table comes first
+    while (m >= 8 && (32ULL << (2 * m)) > free_b / 5) m--;
+    return m >= 8 ? m : 0;
 }
 
 // seed length that makes nearly all positions resolve in the table: two more bases than log4(n)
@@ -901,11 +1096,11 @@ static int nm_build_pair(nm_index *ix, uint32_t m) {
     return NM_OK;
 }
 
-static int nm_build_seed(nm_index *ix, uint32_t s) {
+static int nm_build_seed(nm_index *ix, uint32_t s, uint32_t quad_m = 0) {
     ix->view.seed = nullptr;
     ix->view.seed_len = 0;
     if (s == 0 || ix->h.n < 2) return NM_OK;
-    int rc = nm_build_seed_table(ix, s, &ix->d_seed);
+    int rc = nm_build_seed_table(ix, s, &ix->d_seed, quad_m);
     if (rc != NM_OK) return rc;
     ix->view.seed = (const uint64_t *)ix->d_seed;
     ix->view.seed_len = s;
@@ -1025,6 +1220,8 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.rank2 = nullptr;
     v.superC2 = nullptr;
     v.lfb = nullptr;
+    v.quad = nullptr;
+    v.quad_m = 0;
 
     if (seed_len_override < -1 && h.n >= 2) {
         const char *off = getenv("NEWMAP_AMD_LF_BLOCKS");
@@ -1036,10 +1233,21 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     uint32_t s = seed_len_override == -1 ? h.seed_len
                : (seed_len_override < -1 ? nm_auto_seed_len(ix) : (uint32_t)seed_len_override);
     if (s > 16) s = 16;
-    rc = nm_build_seed(ix, s);
+    // automatic sizing: the quad table, cut from the seed-table level of its core length.  Core length:
+    // NEWMAP_AMD_QUAD_M (0 = none), else nm_auto_quad_len.
+    uint32_t quad_m = 0;
+    if (seed_len_override < -1 && s >= 8) {
+        quad_m = nm_auto_quad_len(ix, s);
+        if (const char *q = getenv("NEWMAP_AMD_QUAD_M")) quad_m = (uint32_t)atoi(q);
+        if (quad_m > s) quad_m = s;
+        if (quad_m && quad_m < 8) quad_m = 8;              // the level-wise build starts at length 8
+    }
+    rc = nm_build_seed(ix, s, quad_m);
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
-    if (seed_len_override < -1 && s >= 5) {
-        // automatic sizing also builds the pair table (cores of s-1 bases, same resolution as the
+    const bool have_quad = ix->view.quad != nullptr;
+    const char *force_pair = getenv("NEWMAP_AMD_PAIR");
+    if (seed_len_override < -1 && s >= 5 && (!have_quad || (force_pair && force_pair[0] == '1'))) {
+        // without a quad table: the pair table (cores of s-1 bases, same resolution as the
         // seed table, twice its bytes) unless it would take more than 40 % of the free HBM
         uint32_t m = s - 1 > 15 ? 15 : s - 1;
         size_t free_b = 0, total_b = 0;
@@ -1073,7 +1281,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_rank2, ix->d_super2, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_quad, ix->d_rank2, ix->d_super2, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
                     ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p, ix->settled.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1099,6 +1307,7 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 11: return ix->view.lfb ? 1 : 0;
         case 12: return ix->view.rank2 ? 1 : 0;
         case 13: return ix->repeat_probes ? 1 : 0;
+        case 18: return ix->view.quad_m;
         case 14: case 15: case 16: case 17: {              // probe tally of the last range-mode launch
             unsigned long long v = 0;
             if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
@@ -1123,7 +1332,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_SEED_POLICY) {
-        if (value < 0 || value > 2) { nm_set_error("seed policy must be 0, 1 or 2"); return NM_E_ARGUMENT; }
+        if (value < 0 || (value & 0xFF) > 2 || value > 0x3FF) { nm_set_error("seed policy must be 0, 1 or 2 (+ 0x100 / 0x200 timing experiments)"); return NM_E_ARGUMENT; }
         ix->view.seed_policy = (uint32_t)value;
         return NM_OK;
     }
@@ -1136,7 +1345,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_KERNEL) {
-        if (value < 0 || value > 4) { nm_set_error("kernel version must be 0..4"); return NM_E_ARGUMENT; }
+        if (value < 0 || value > 5) { nm_set_error("kernel version must be 0..5"); return NM_E_ARGUMENT; }
         ix->kernel_version = (int)value;
         return NM_OK;
     }
@@ -1169,17 +1378,19 @@ extern "C" int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_
 
 // -------------------------------------------------------------------------- launch helpers --
 
-static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStream_t st) {
+// d_status != nullptr: the pass also resets the launch's status words and the handle's counters
+static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStream_t st, uint64_t *d_status = nullptr) {
+    unsigned long long *work = d_status ? (unsigned long long *)ix->work.p : nullptr;
     const uint64_t n_words = seq_len / 64 + 3;
     int rc = nm_grow(ix->enc, n_words * sizeof(nm_enc_word));
     if (rc != NM_OK) return rc;
     ix->enc_words = n_words;
     if (((uintptr_t)d_seq & 15) == 0)
         hipLaunchKernelGGL(k_encode16, dim3(nm_grid(n_words * 4)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
-                           (nm_enc_word *)ix->enc.p, n_words);
+                           (nm_enc_word *)ix->enc.p, n_words, d_status, work);
     else
         hipLaunchKernelGGL(k_encode, dim3(nm_grid(n_words * 64)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
-                           (nm_enc_word *)ix->enc.p, n_words);
+                           (nm_enc_word *)ix->enc.p, n_words, d_status, work);
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }
@@ -1202,10 +1413,11 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kme
                               int elem_bytes, uint64_t *d_status, hipStream_t st) {
     const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
-    const bool pair_kernel = RC && (ix->kernel_version == 4 || ix->kernel_version == 0) && view.pair && kmin >= view.pair_m + 1;
+    const bool quad_kernel = RC && (ix->kernel_version == 5 || ix->kernel_version == 0) && view.quad && kmin >= view.quad_m + NM_QUAD_EXT;
+    const bool pair_kernel = !quad_kernel && RC && (ix->kernel_version == 4 || ix->kernel_version == 0) && view.pair && kmin >= view.pair_m + 1;
     // repeat probes feed the two kernels that take a `settled` array: the pair kernel and k_min_unique
     const uint8_t *settled = nullptr;
-    if (RC && ix->repeat_probes && ix->kernel_version != 2 && ix->kernel_version != 3) {
+    if (RC && ix->repeat_probes && ix->kernel_version != 2 && ix->kernel_version != 3) {   // (versions 4 and 5 fall back to 1 without their table)
         const uint64_t n_probes = (num_kmers + NM_PROBE_STRIDE - 1) / NM_PROBE_STRIDE;
         const int rc = nm_grow(ix->settled, n_probes);
         if (rc != NM_OK) return rc;
@@ -1225,6 +1437,14 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kme
         unsigned long long *work = (unsigned long long *)ix->work.p;
         if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_v2<BIG, true>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
         else                 hipLaunchKernelGGL((k_min_unique_v2<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
+        return NM_OK;
+    }
+    if (quad_kernel) {
+        const uint64_t per_block = (uint64_t)NM_BLOCK * 4;
+        const dim3 qgrid((unsigned)((num_kmers + per_block - 1) / per_block));
+        ix->last_kernel = 5;
+        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_quad<BIG, true>), qgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+        else                 hipLaunchKernelGGL((k_min_unique_quad<BIG, false>), qgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
         return NM_OK;
     }
     if (pair_kernel) {
@@ -1260,9 +1480,8 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
     if (!d_status) { nm_set_error("d_status is required"); return NM_E_ARGUMENT; }
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
-    if ((rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
-    if (num_kmers == 0) return NM_OK;
-    if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
+    if (num_kmers == 0) return nm_reset_status(ix, d_status, st);
+    if ((rc = nm_encode(ix, d_seq, seq_len, st, d_status)) != NM_OK) return rc;
     nm_view view;
     if ((rc = nm_view_for(ix, kmin, &view)) != NM_OK) return rc;
     if (ix->big) rc = use_revcomp ? launch_min_unique<true, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st)
@@ -1476,7 +1695,7 @@ extern "C" int nm_search_segment_multi(nm_index *const *indexes, uint32_t n_inde
         tmp.push_back(d_enc);
         a.enc[i] = (const nm_enc_word *)d_enc;
         if (hipMemcpyAsync(d_seq, seqs[i], seq_len, hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); nm_set_error("copy to device failed"); return NM_E_DEVICE; }
-        hipLaunchKernelGGL(k_encode16, dim3(nm_grid(n_words * 4)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len, (nm_enc_word *)d_enc, n_words);
+        hipLaunchKernelGGL(k_encode16, dim3(nm_grid(n_words * 4)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len, (nm_enc_word *)d_enc, n_words, (uint64_t *)nullptr, (unsigned long long *)nullptr);
     }
     const uint64_t out_bytes = num_kmers * (uint64_t)elem_bytes;
     if ((rc = nm_grow(ix0->out, out_bytes + 64)) != NM_OK || (rc = nm_grow(ix0->ks, (uint64_t)nk * 4)) != NM_OK) { cleanup(); return rc; }

@@ -59,7 +59,7 @@ class Index:
             self.set_repeat_probes(os.environ["NEWMAP_AMD_REPEAT_PROBES"] != "0")
         if os.environ.get("NEWMAP_AMD_SEED_POLICY"):
             _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SEED_POLICY,
-                                                 int(os.environ["NEWMAP_AMD_SEED_POLICY"])))
+                                                 int(os.environ["NEWMAP_AMD_SEED_POLICY"], 0)))
 
     # lifetime -----------------------------------------------------------------------------
     def close(self):
@@ -89,7 +89,9 @@ class Index:
         names = ["bwt_length", "forward_text_length", "separators", "records", "raw_bases",
                  "seed_length", "device_bytes", "sa_ratio", "last_range_kernel", "pair_core_length", "device",
                  "lf_blocks", "two_step_blocks", "repeat_probes"]
-        return {n: int(self._L.nm_index_info(self.handle, i)) for i, n in enumerate(names)}
+        d = {n: int(self._L.nm_index_info(self.handle, i)) for i, n in enumerate(names)}
+        d["quad_core_length"] = int(self._L.nm_index_info(self.handle, 18))
+        return d
 
     def probe_tally(self) -> dict:
         """Repeat probes of the last range-mode launch: positions settled without a search and (with
@@ -101,7 +103,8 @@ class Index:
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_COUNT_STEPS, int(bool(on))))
 
     def set_kernel(self, version: int):
-        """1 = one lane per position, 2 = persistent lanes, 3 = several positions per lane"""
+        """0 = automatic, 1 = one lane per position, 2 = persistent lanes, 3 = several positions per lane,
+        4 = position pairs on the pair table, 5 = position quads on the quad table"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_KERNEL, int(version)))
 
     def set_persistent_blocks(self, blocks: int):

@@ -34,6 +34,8 @@ def lib():
     L.hs_check_rank2.argtypes = [vp, u64]
     L.hs_check_levels.restype = u64
     L.hs_check_levels.argtypes = [vp, u32]
+    L.hs_check_quad.restype = u64
+    L.hs_check_quad.argtypes = [vp]
     L.hs_check_pair.restype = u64
     L.hs_check_pair.argtypes = [vp, u32]
     L.hs_info.restype = u64
@@ -78,6 +80,11 @@ class HostSim:
 
     def check_levels(self, s):
         return int(self.L.hs_check_levels(self.h, s))
+
+    def check_quad(self):
+        """build the quad table from the simulated seed table (core length = seed length <= 8) and compare every
+        bit four neighbouring positions can read with a direct count; returns the number of wrong bits"""
+        return int(self.L.hs_check_quad(self.h))
 
     def check_pair(self, m):
         return int(self.L.hs_check_pair(self.h, m))

@@ -19,6 +19,7 @@ struct hs_index {
     std::vector<uint64_t> sep, seed, superC, superC2;
     std::vector<nm_rank2_block> rank2;
     std::vector<nm_lf_entry> lfb;
+    std::vector<uint64_t> quad;
     nm_view v;
     bool big;
 };
@@ -103,7 +104,7 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
     v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
     v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
-    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pair_m = 0; v.pair = nullptr; v.rank2 = nullptr; v.superC2 = nullptr; v.lfb = nullptr;
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pair_m = 0; v.pair = nullptr; v.rank2 = nullptr; v.superC2 = nullptr; v.lfb = nullptr; v.quad = nullptr; v.quad_m = 0;
     uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
     if (s > 12) s = 12;                     // keep the simulated table small
     if (s && h.n >= 2) {
@@ -183,6 +184,45 @@ uint64_t hs_check_pair(hs_index *ix, uint32_t m) {
             // an empty interval may sit anywhere: compare sizes, and starts only when non-empty
             const uint64_t wc = want >> NM_SEED_LO_BITS, gc = got >> NM_SEED_LO_BITS;
             if (wc != gc || (wc && want != got)) bad++;
+        }
+    }
+    return bad;
+}
+// quad table (nm_core.h: nm_quad_build_one, the body of k_quad_build) from the simulated seed table; then
+// every bit a group of four positions can read is compared with a direct count of its (m+3)-mer.
+// Returns the number of wrong bits (+ 2^32 per 16-bit piece no lane wrote).
+uint64_t hs_check_quad(hs_index *ix) {
+    const uint32_t m = ix->v.seed_len, w = m + 3;
+    if (!m || m > 8) return ~0ULL;
+    const uint64_t cores = 1ULL << (2 * m);
+    ix->quad.assign(cores * 4, 0x5A5A5A5A5A5A5A5AULL);
+    std::vector<uint64_t> ref(cores * 4, 0x5A5A5A5A5A5A5A5AULL), other(cores * 4, 0xA5A5A5A5A5A5A5A5ULL);
+    for (uint64_t Z = 0; Z < cores; Z++) {
+        if (ix->big) { nm_quad_build_one<true>(ix->v, Z, m, ix->quad.data()); nm_quad_build_one<true>(ix->v, Z, m, other.data()); }
+        else { nm_quad_build_one<false>(ix->v, Z, m, ix->quad.data()); nm_quad_build_one<false>(ix->v, Z, m, other.data()); }
+    }
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < cores * 4; i++)                // a piece nobody wrote keeps its (different) fill pattern
+        for (int h = 0; h < 4; h++)
+            if (((ix->quad[i] >> (16 * h)) & 0xFFFF) != ((other[i] >> (16 * h)) & 0xFFFF)) bad += 1ULL << 32;
+    ix->v.quad = ix->quad.data();
+    ix->v.quad_m = m;
+    // windows of m + 6 bases: L (3) . core (m) . R (3); position i of the group reads word i
+    const uint64_t n_win = 1ULL << (2 * (m + 6));
+    for (uint64_t x = 0; x < n_win; x++) {
+        nm_window win{0, 0, 0};
+        for (uint32_t j = 0; j < m + 6; j++) {
+            const uint32_t c = (uint32_t)(x >> (2 * j)) & 3u;
+            win.lo |= (uint64_t)(c & 1u) << j;
+            win.hi |= (uint64_t)(c >> 1) << j;
+        }
+        const uint64_t slot = nm_quad_slot(win, m);
+        const uint32_t got = nm_quad_bits(win, m, ix->quad.data() + slot * 4);
+        for (uint32_t i = 0; i < 4; i++) {
+            nm_window wi{win.lo >> i, win.hi >> i, 0};
+            const uint64_t e = ix->big ? nm_seed_entry<true>(ix->v, nm_seed_slot(wi, w), w) : nm_seed_entry<false>(ix->v, nm_seed_slot(wi, w), w);
+            const uint32_t want = (e >> NM_SEED_LO_BITS) == 1 ? 1u : 0u;
+            if (((got >> i) & 1u) != want) bad++;
         }
     }
     return bad;

@@ -260,6 +260,14 @@ def test_device_pointer_api_matches_host_api(mixed_genome, eng):
         got_sub = np.zeros(len(sub), np.uint8)
         assert L.nm_dev_download(0, got_sub.ctypes.data, d_out, got_sub.size) == 0
         assert np.array_equal(got_sub, want_sub)
+        # an output buffer at an odd address: the quad kernel falls back from 4-byte to element-wise stores
+        sub = rec[:len(rec) - 3]
+        want_sub, _ = ix.min_unique_segment(sub, len(sub), 20, 200)
+        ix.min_unique_segment_dev(d_seq.value, len(sub), len(sub), 20, 200, True, 1, d_out.value + 3, d_st.value)
+        assert L.nm_dev_sync(0) == 0
+        got_sub = np.zeros(len(sub), np.uint8)
+        assert L.nm_dev_download(0, got_sub.ctypes.data, ctypes.c_void_p(d_out.value + 3), got_sub.size) == 0
+        assert np.array_equal(got_sub, want_sub)
         for p in (d_seq, d_out, d_st):
             L.nm_dev_free(0, p)
 
@@ -292,9 +300,9 @@ def test_large_random_genome_properties(tmp_path, eng):
     rec = synth.config_genome("c2")[0][1].tobytes()
     fa, idx = _build_index(tmp_path, b">chr1\n" + rec + b"\n", "big")
     kmin, kmax = 20, 200
-    with eng.Index(idx, 0) as ix:                         # automatic tables: the pair kernel, as in bench.py
+    with eng.Index(idx, 0) as ix:                         # automatic tables: the quad kernel, as in bench.py
         whole, amb = ix.min_unique_segment(rec, len(rec), kmin, kmax)
-        assert amb == 0 and ix.info()["last_range_kernel"] == 4
+        assert amb == 0 and ix.info()["last_range_kernel"] == 5
         parts = [ix.min_unique_segment(s.data, rd.num_kmers_of(s, kmax), kmin, kmax)[0]
                  for s in rd.record_segments(b"c", rec, 10_000_000 + kmax - 1, kmax - 1)]
         assert np.array_equal(np.concatenate(parts), whole)
@@ -445,31 +453,48 @@ def test_config4_fixed_k(tmp_path, eng, k):
             assert np.array_equal(got, want), (name, k)
 
 
-def test_both_range_kernels_agree(mixed_genome, eng):
-    """the persistent-lane kernel (default) and the one-lane-per-position kernel are two schedules
-    of the same arithmetic"""
+def test_both_range_kernels_agree(mixed_genome, eng, monkeypatch):
+    """the range kernels (one lane per position, persistent lanes, several positions per lane, position pairs
+    on the pair table, position quads on the quad table) are schedules of the same arithmetic"""
     g = mixed_genome
+    monkeypatch.setenv("NEWMAP_AMD_PAIR", "1")                      # both tables (the default builds only the quad table)
     with eng.Index(g["idx"], 0) as ix:
+        info = ix.info()
+        assert 8 <= info["quad_core_length"] <= info["seed_length"] and info["pair_core_length"] == info["seed_length"] - 1
+        w = info["quad_core_length"] + 3
         for rec in (g["r1"], g["r2"]):
-            for kmin, kmax in ((20, 200), (8, 30), (20, 1000)):
+            for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (70, 90)):
                 ix.set_kernel(2)
                 a, amb_a = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                 ix.set_kernel(1)
                 b, amb_b = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                 assert np.array_equal(a, b) and amb_a == amb_b
                 # walks on the one-step rank blocks instead of the two-step ones
-                for kernel in (0, 1, 3):
+                for kernel in (0, 1, 3, 4, 5):
                     ix.set_kernel(kernel)
                     ix.set_two_step(False)
-                    c, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                    c, amb_c = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                    used = ix.info()["last_range_kernel"]
+                    pair_ok = kmin >= info["pair_core_length"] + 1
+                    if kernel in (0, 5):
+                        assert used == (5 if kmin >= w else (4 if kernel == 0 and pair_ok else 1)), (kernel, kmin, used)
+                    if kernel == 4:
+                        assert used == (4 if pair_ok else 1), (kmin, used)
                     ix.set_two_step(True)
                     d, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
-                    assert np.array_equal(a, c) and np.array_equal(a, d), (kernel, kmin, kmax)
+                    assert np.array_equal(a, c) and np.array_equal(a, d) and amb_c == amb_a, (kernel, kmin, kmax)
                 ix.set_kernel(0)
                 ix.set_lf_blocks(False)                           # packed 32-byte rank blocks instead of LF entries
                 e, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                 ix.set_lf_blocks(True)
                 assert np.array_equal(a, e)
+        # unaligned output pointer and 2-byte elements take the quad kernel's element-wise stores
+        rec = g["r1"][:70_001]
+        ix.set_kernel(5)
+        a16, _ = ix.min_unique_segment(rec, len(rec), 20, 300)
+        ix.set_kernel(1)
+        b16, _ = ix.min_unique_segment(rec, len(rec), 20, 300)
+        assert a16.dtype == np.uint16 and np.array_equal(a16, b16)
 
 
 def test_big_index_code_path(mixed_genome, eng):

@@ -295,3 +295,25 @@ def test_repeat_probes_settle_only_zero_positions(tmp_path):
         # the reverse-complement copy is seen through the both-strand index
         settled, _ = sim.repeat_probes(r2, len(r2), 200, 64)
         assert settled[5000 // 64 + 1:].sum() > 400
+
+
+@pytest.mark.parametrize("m,force_big", [(4, False), (6, False), (5, True)])
+def test_quad_table_bits_equal_direct_counts(tmp_path, m, force_big):
+    """nm_quad_build_one / nm_quad_slot / nm_quad_bits (the quad table of k_quad_build and
+    k_min_unique_quad): every 16-bit piece is written exactly once, and for every window of m + 6 bases
+    the four bits read are 'the (m+3)-mer at this position occurs once over both strands'."""
+    rng = np.random.default_rng(5 + m)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    n = {4: 3000, 5: 12000, 6: 60000}[m]                   # about as many positions as (m+3)-mers: a mix of 0 / 1 / many
+    r1 = bytearray(bytes(alpha[rng.integers(0, 4, n)]))
+    r1[100:400] = (b"ACGGT" * 60)                          # repeats, a palindrome-rich stretch, N runs
+    r1[500:560] = b"ACGT" * 15
+    r1[700:705] = b"NNNNN"
+    r2 = bytes(alpha[rng.integers(0, 4, n // 3)]) + bytes(r1[50:90])
+    fa = _write(tmp_path, b">a\n" + bytes(r1) + b"\n>b\n" + r2 + b"\n")
+    idx = tmp_path / "q.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    sim = HostSim(idx, m, force_big)
+    assert sim.check_quad() == 0
+    sim.enable_lfb(True)                                   # the table walk on LF entries instead of the packed blocks
+    assert sim.check_quad() == 0

@@ -418,6 +418,12 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
 // four positions that share an m-mer core into one 32-byte entry: a lane owns positions 4i .. 4i+3,
 // reads one entry, and only the positions whose w-mer is repeated (or absent) go on to the seed table
 // and the walk (stage 2, compacted through LDS like the pair kernel's).
+// A lane owns NM_QUAD_GROUPS groups of four positions (group g of lane l: wave base + 256 g + 4 l) and issues
+// the entry loads of all its groups before it looks at any: with 32 waves per CU the requests in flight,
+// not the lines per position, were what kept the kernel below the HBM's random-line rate.
+#define NM_QUAD_GROUPS 2
+#define NM_QUAD_MAX_KMIN 60u      /* kmin bases from any of a lane's four positions lie inside its 64-base window */
+#define NM_QUAD_PER_WAVE (256u * NM_QUAD_GROUPS)
 template <bool BIG, bool STATS>
 __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_quad(nm_view ix, const nm_enc_word *__restrict__ enc,
                                                               uint64_t n_enc_words, uint64_t num_kmers,
@@ -426,87 +432,94 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_quad(nm_view ix, const 
                                                               const uint8_t *__restrict__ settled) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * 256ull;
-    const uint32_t m = ix.quad_m, w = m + NM_QUAD_EXT;
+    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * NM_QUAD_PER_WAVE;
+    const uint32_t m = ix.quad_m;
 
-    nm_enc_word W[5];                                     // wave-uniform -> scalar loads
+    // the 4 * NM_QUAD_GROUPS + 1 encoded words of the wave: wave-uniform -> scalar loads.  Separate variables,
+    // not an array: a lane picks its words by (lane >> 4), and selects over array elements are turned into an
+    // indexed load from scratch memory
     const uint64_t w0 = wave_base >> 6;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        uint64_t wi = w0 + j;
-        if (wi >= n_enc_words) wi = n_enc_words - 1;
-        W[j] = enc[wi];
-    }
-    const uint32_t q = 4 * lane;                          // offset of the lane's first position in the wave's 256
+#define NM_LOAD_WORD(j) const nm_enc_word W##j = enc[w0 + j < n_enc_words ? w0 + j : n_enc_words - 1];
+    NM_LOAD_WORD(0) NM_LOAD_WORD(1) NM_LOAD_WORD(2) NM_LOAD_WORD(3) NM_LOAD_WORD(4)
+    NM_LOAD_WORD(5) NM_LOAD_WORD(6) NM_LOAD_WORD(7) NM_LOAD_WORD(8)
+#undef NM_LOAD_WORD
+    static_assert(NM_QUAD_GROUPS == 2, "the word variables above are written out for two groups");
+    const uint32_t q = 4 * lane;                          // offset of the lane's first position in a group's 256
     const uint32_t qw = q >> 6;
-    // value selects, field by field: indexing W[] with a lane-varying index would put the array in scratch memory
-    nm_enc_word Wa, Wb;
-#define NM_SEL4(f, base) (qw == 0 ? W[base].f : (qw == 1 ? W[base + 1].f : (qw == 2 ? W[base + 2].f : W[base + 3].f)))
-    Wa.lo = NM_SEL4(lo, 0); Wa.hi = NM_SEL4(hi, 0); Wa.amb = NM_SEL4(amb, 0); Wa.pad = 0;
-    Wb.lo = NM_SEL4(lo, 1); Wb.hi = NM_SEL4(hi, 1); Wb.amb = NM_SEL4(amb, 1); Wb.pad = 0;
-#undef NM_SEL4
-    const nm_window win = nm_window_from(Wa, Wb, q & 63);            // bases p0 .. p0+63
-    const uint64_t p0 = wave_base + q;
-    const uint32_t n_settled = (settled && p0 < num_kmers) ? settled[p0 / NM_PROBE_STRIDE] : 0u;   // four positions, one stride
-    const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
-    // go: the position takes part in the lookup.  With kmin <= 60 the lane's 64-base window shows whether the
-    // first kmin bases are free of ambiguity (if not: U_p < kmin, element 0, search.py:437) and stage 1 is
-    // branch-free; longer kmin checks the w bases here and the rest with nm_all_valid.
-    const bool short_kmin = kmin <= 60;                    // wave-uniform
-    const uint64_t vmask = (1ULL << (short_kmin ? kmin : w)) - 1ULL;
-    bool in[4], go[4];
-    bool any_go = false;
-    uint32_t n_amb = 0;
+    // go: the position takes part in the lookup.  kmin <= NM_QUAD_MAX_KMIN (the launcher sees to it), so the
+    // lane's 64-base window shows whether the first kmin bases are free of ambiguity (if not: U_p < kmin,
+    // element 0, search.py:437) and stage 1 is branch-free.
+    const uint64_t vmask = (1ULL << kmin) - 1ULL;
+    nm_window win[NM_QUAD_GROUPS];
+#define NM_SEL4(f, a, b, c, d) (qw == 0 ? a.f : (qw == 1 ? b.f : (qw == 2 ? c.f : d.f)))
+    uint64_t e[NM_QUAD_GROUPS][4];
+    uint32_t go[NM_QUAD_GROUPS], inb[NM_QUAD_GROUPS];     // bit i: position i of the group
+    uint32_t n_amb = 0, n_searched = 0, n_entries = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-        in[i] = p0 + i < num_kmers;
-        n_amb += (uint32_t)(in[i] && ((win.amb >> i) & 1ULL));
-        go[i] = in[i] && ((win.amb >> i) & vmask) == 0 && off0 + i >= n_settled;
-        any_go |= go[i];
+    for (int g = 0; g < NM_QUAD_GROUPS; g++) {
+        {
+            nm_enc_word Wa, Wb;
+            Wa.pad = Wb.pad = 0;
+            if (g == 0) {
+                Wa.lo = NM_SEL4(lo, W0, W1, W2, W3); Wa.hi = NM_SEL4(hi, W0, W1, W2, W3); Wa.amb = NM_SEL4(amb, W0, W1, W2, W3);
+                Wb.lo = NM_SEL4(lo, W1, W2, W3, W4); Wb.hi = NM_SEL4(hi, W1, W2, W3, W4); Wb.amb = NM_SEL4(amb, W1, W2, W3, W4);
+            } else {
+                Wa.lo = NM_SEL4(lo, W4, W5, W6, W7); Wa.hi = NM_SEL4(hi, W4, W5, W6, W7); Wa.amb = NM_SEL4(amb, W4, W5, W6, W7);
+                Wb.lo = NM_SEL4(lo, W5, W6, W7, W8); Wb.hi = NM_SEL4(hi, W5, W6, W7, W8); Wb.amb = NM_SEL4(amb, W5, W6, W7, W8);
+            }
+            win[g] = nm_window_from(Wa, Wb, q & 63);      // bases p0 .. p0+63
+        }
+        const uint64_t p0 = wave_base + 256u * g + q;
+        const uint32_t n_settled = (settled && p0 < num_kmers) ? settled[p0 / NM_PROBE_STRIDE] : 0u;   // four positions, one stride
+        const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
+        go[g] = 0; inb[g] = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const bool in = p0 + i < num_kmers;
+            const bool amb = ((win[g].amb >> i) & 1ULL) != 0;
+            inb[g] |= (uint32_t)in << i;
+            n_amb += (uint32_t)(in && amb);
+            n_searched += (uint32_t)(in && !amb);
+            go[g] |= (uint32_t)(in && ((win[g].amb >> i) & vmask) == 0 && off0 + i >= n_settled) << i;
+        }
+        e[g][0] = e[g][1] = e[g][2] = e[g][3] = 0;
+        if (go[g] && !(ix.seed_policy & 0x200u)) {        // the core lies inside every window that is free of ambiguity
+            const ulonglong2 *ep = reinterpret_cast<const ulonglong2 *>(ix.quad + nm_quad_slot(win[g], m) * 4);
+            const ulonglong2 a = ep[0], b = ep[1];
+            e[g][0] = a.x; e[g][1] = a.y; e[g][2] = b.x; e[g][3] = b.y;
+            n_entries += 4;
+        }
     }
-    uint64_t e[4] = {0, 0, 0, 0};
-    if (any_go && !(ix.seed_policy & 0x200u)) {            // the core lies inside every window that is free of ambiguity
-        const ulonglong2 *ep = reinterpret_cast<const ulonglong2 *>(ix.quad + nm_quad_slot(win, m) * 4);
-        const ulonglong2 a = ep[0], b = ep[1];
-        e[0] = a.x; e[1] = a.y; e[2] = b.x; e[3] = b.y;
-    }
-    const uint32_t once = nm_quad_bits(win, m, e);
     nm_tally t = {0, 0, 0, 0};
     bool any_err = false;
     uint64_t err_pos = ~0ULL;
-    __shared__ uint64_t q_p[NM_BLOCK * 4];
+    __shared__ uint64_t q_p[NM_BLOCK * 4 * NM_QUAD_GROUPS];
     __shared__ uint32_t q_n;
     if (threadIdx.x == 0) q_n = 0;
     __syncthreads();
     // ---- stage 1: what the entry alone decides.  once: least unique length <= w <= kmin, the element is kmin
     // (if within U_p); otherwise the w-mer is repeated or absent: seed table + walk in stage 2
-    uint32_t r[4] = {0, 0, 0, 0};
-    uint32_t walk = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-        const bool is_once = ((once >> i) & 1u) != 0;
-        if (short_kmin) {
-            r[i] = (go[i] && is_once) ? kmin : 0u;
-        } else if (go[i] && is_once) {
-            nm_window wi = nm_window_from(Wa, Wb, (q & 63) + i);
-            uint32_t kbase = 0;
-            r[i] = nm_all_valid(enc, p0 + i, wi, kbase, w, kmin) ? kmin : 0u;
+    for (int g = 0; g < NM_QUAD_GROUPS; g++) {
+        const uint64_t p0 = wave_base + 256u * g + q;
+        const uint32_t once = nm_quad_bits(win[g], m, e[g]);
+        uint32_t r[4] = {0, 0, 0, 0};
+        const uint32_t hit = go[g] & once, walk = go[g] & ~once;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) r[i] = ((hit >> i) & 1u) ? kmin : 0u;
+        if (walk) {
+            uint32_t at = atomicAdd(&q_n, (uint32_t)__builtin_popcount(walk));
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if ((walk >> i) & 1u) q_p[at++] = p0 + i;
         }
-        walk |= (uint32_t)(go[i] && !is_once) << i;
-    }
-    if (walk) {
-        const uint32_t n = (uint32_t)__builtin_popcount(walk);
-        uint32_t at = atomicAdd(&q_n, n);
+        if (elem_bytes == 1 && inb[g] == 0xFu && (((uintptr_t)out) & 3u) == 0) {
+            reinterpret_cast<uint32_t *>(out)[p0 >> 2] = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        } else {
 #pragma unroll
-        for (uint32_t i = 0; i < 4; i++)
-            if ((walk >> i) & 1u) q_p[at++] = p0 + i;
-    }
-    if (elem_bytes == 1 && in[3] && (((uintptr_t)out) & 3u) == 0) {
-        reinterpret_cast<uint32_t *>(out)[p0 >> 2] = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
-    } else {
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++)
-            if (in[i]) nm_store(out, elem_bytes, p0 + i, r[i]);
+            for (uint32_t i = 0; i < 4; i++)
+                if ((inb[g] >> i) & 1u) nm_store(out, elem_bytes, p0 + i, r[i]);
+        }
     }
     __syncthreads();                                       // stage 2 overwrites the placeholders of queued positions
     // ---- stage 2: dense walks
@@ -526,12 +539,9 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_quad(nm_view ix, const 
         if (lane == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
     }
     if (STATS) {
-        uint32_t searched = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) searched += (uint32_t)(in[i] && !((win.amb >> i) & 1ULL));
         const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks),
-                       c = wave_sum((any_go ? 4u : 0u) + t.seeds),                 // 8-byte table words read
-                       f = wave_sum(searched);
+                       c = wave_sum(n_entries + t.seeds),                            // 8-byte table words read
+                       f = wave_sum(n_searched);
         if (lane == 0) {
             atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
             atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
@@ -539,6 +549,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_quad(nm_view ix, const 
             atomicAdd((unsigned long long *)&status[7], (unsigned long long)f);
         }
     }
+#undef NM_SEL4
 }
 
 // quad table from the seed table of the same length (nm_core.h: nm_quad_build_one)
@@ -989,14 +1000,15 @@ static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table, uint32_
     return rc;
 }
 
-// core length of the quad table: as long as the seed, at most a fifth of the free HBM (4^m x 32 bytes)
+// core length of the quad table: as long as the seed, at most 60 % of the HBM still free once the seed table is
+// in place (4^m x 32 bytes: 137 GB for m = 16; the pair table is not built next to it)
 static uint32_t nm_auto_quad_len(const nm_index *ix, uint32_t s) {
     (void)ix;
     uint32_t m = s;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
     free_b -= free_b < (8ULL << (2 * s)) ? free_b : (8ULL << (2 * s));      // the seed table comes first
-    while (m >= 8 && (32ULL << (2 * m)) > free_b / 5) m--;
+    while (m >= 8 && (32ULL << (2 * m)) > free_b / 5 * 3) m--;
     return m >= 8 ? m : 0;
 }
 
@@ -1413,7 +1425,8 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kme
                               int elem_bytes, uint64_t *d_status, hipStream_t st) {
     const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
-    const bool quad_kernel = RC && (ix->kernel_version == 5 || ix->kernel_version == 0) && view.quad && kmin >= view.quad_m + NM_QUAD_EXT;
+    const bool quad_kernel = RC && (ix->kernel_version == 5 || ix->kernel_version == 0) && view.quad && kmin >= view.quad_m + NM_QUAD_EXT &&
+                             kmin <= NM_QUAD_MAX_KMIN;
     const bool pair_kernel = !quad_kernel && RC && (ix->kernel_version == 4 || ix->kernel_version == 0) && view.pair && kmin >= view.pair_m + 1;
     // repeat probes feed the two kernels that take a `settled` array: the pair kernel and k_min_unique
     const uint8_t *settled = nullptr;
@@ -1440,7 +1453,7 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kme
         return NM_OK;
     }
     if (quad_kernel) {
-        const uint64_t per_block = (uint64_t)NM_BLOCK * 4;
+        const uint64_t per_block = (uint64_t)(NM_BLOCK / NM_WAVE) * NM_QUAD_PER_WAVE;
         const dim3 qgrid((unsigned)((num_kmers + per_block - 1) / per_block));
         ix->last_kernel = 5;
         if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_quad<BIG, true>), qgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);

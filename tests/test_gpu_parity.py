@@ -463,7 +463,7 @@ def test_both_range_kernels_agree(mixed_genome, eng, monkeypatch):
         assert 8 <= info["quad_core_length"] <= info["seed_length"] and info["pair_core_length"] == info["seed_length"] - 1
         w = info["quad_core_length"] + 3
         for rec in (g["r1"], g["r2"]):
-            for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (70, 90)):
+            for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (60, 90), (61, 90)):
                 ix.set_kernel(2)
                 a, amb_a = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                 ix.set_kernel(1)
@@ -476,8 +476,9 @@ def test_both_range_kernels_agree(mixed_genome, eng, monkeypatch):
                     c, amb_c = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                     used = ix.info()["last_range_kernel"]
                     pair_ok = kmin >= info["pair_core_length"] + 1
+                    quad_ok = w <= kmin <= 60                     # NM_QUAD_MAX_KMIN
                     if kernel in (0, 5):
-                        assert used == (5 if kmin >= w else (4 if kernel == 0 and pair_ok else 1)), (kernel, kmin, used)
+                        assert used == (5 if quad_ok else (4 if kernel == 0 and pair_ok else 1)), (kernel, kmin, used)
                     if kernel == 4:
                         assert used == (4 if pair_ok else 1), (kmin, used)
                     ix.set_two_step(True)

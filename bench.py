@@ -97,12 +97,14 @@ def prepare_workload(args, rank, world, barrier):
 def measured_traffic(kernel: str, config: str, positions_per_launch: float):
     """HBM-side read+write bytes per launch of the dominant kernel, from the PMC passes committed under
     profiles/ (rocprofv3 --pmc cannot run inside this process).  Reads: TCC_EA0_RDREQ x 128 B -- on
-    gfx950 every read request of this kernel is a 128-byte one (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ),
-    which is the guide's "FETCH_SIZE reports half" correction stated exactly; writes: WRITE_SIZE (KB).
+    gfx950 every read request of these kernels is a 128-byte one (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ
+    within 3 %), which is the guide's "FETCH_SIZE reports half" correction stated exactly; writes:
+    TCC_EA0_WRREQ x 64 B (WRITE_SIZE in KB for the older pair-kernel pass).
     The counts are per 10 M-position launch of configs[1]; other workloads report null."""
-    if config != "c2" or kernel != "k_min_unique_pair":
+    files = {"k_min_unique_quad": "pmc_quad_kernel_summary.csv", "k_min_unique_pair": "pmc_pair_kernel_summary.csv"}
+    if config != "c2" or kernel not in files:
         return None, None
-    f = ROOT / "profiles" / "round1" / "pmc_pair_kernel_summary.csv"
+    f = ROOT / "profiles" / "round1" / files[kernel]
     if not f.exists():
         return None, None
     vals = {}
@@ -113,7 +115,10 @@ def measured_traffic(kernel: str, config: str, positions_per_launch: float):
         return None, None
     scale = positions_per_launch / 10_000_000
     read_b = vals["TCC_EA0_RDREQ_sum"] * 128.0
-    write_b = vals.get("WRITE_SIZE", 0.0) * 1024.0     # rocprofv3 reports WRITE_SIZE in KB (exact for stores)
+    if "TCC_EA0_WRREQ_sum" in vals:
+        write_b = vals["TCC_EA0_WRREQ_sum"] * 64.0
+    else:
+        write_b = vals.get("WRITE_SIZE", 0.0) * 1024.0  # rocprofv3 reports WRITE_SIZE in KB (exact for stores)
     return (read_b + write_b) * scale, str(f.relative_to(ROOT))
 
 

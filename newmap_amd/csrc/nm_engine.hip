@@ -424,15 +424,18 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
 #define NM_QUAD_GROUPS 2
 #define NM_QUAD_MAX_KMIN 60u      /* kmin bases from any of a lane's four positions lie inside its 64-base window */
 #define NM_QUAD_PER_WAVE (256u * NM_QUAD_GROUPS)
+// one wave per workgroup: the two barriers then cost nothing and no wave waits for the slowest line of three
+// others, so the load / compute / store phases of the 32 resident waves of a CU drift apart and overlap
+#define NM_QUAD_BLOCK 64
 template <bool BIG, bool STATS>
-__global__ __launch_bounds__(NM_BLOCK) void k_min_unique_quad(nm_view ix, const nm_enc_word *__restrict__ enc,
+__global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, const nm_enc_word *__restrict__ enc,
                                                               uint64_t n_enc_words, uint64_t num_kmers,
                                                               uint32_t kmin, uint32_t kmax, void *__restrict__ out,
                                                               int elem_bytes, uint64_t *__restrict__ status,
                                                               const uint8_t *__restrict__ settled) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * NM_QUAD_PER_WAVE;
+    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_QUAD_BLOCK / NM_WAVE) + wave_in_block) * NM_QUAD_PER_WAVE;
     const uint32_t m = ix.quad_m;
 
     // the 4 * NM_QUAD_GROUPS + 1 encoded words of the wave: wave-uniform -> scalar loads.  Separate variables,
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_quad(nm_view ix, const 
     nm_tally t = {0, 0, 0, 0};
     bool any_err = false;
     uint64_t err_pos = ~0ULL;
-    __shared__ uint64_t q_p[NM_BLOCK * 4 * NM_QUAD_GROUPS];
+    __shared__ uint64_t q_p[NM_QUAD_BLOCK * 4 * NM_QUAD_GROUPS];
     __shared__ uint32_t q_n;
     if (threadIdx.x == 0) q_n = 0;
     __syncthreads();
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_quad(nm_view ix, const 
     __syncthreads();                                       // stage 2 overwrites the placeholders of queued positions
     // ---- stage 2: dense walks
     const uint32_t n_walk = (ix.seed_policy & 0x100u) ? 0u : q_n;     // (0x100 / 0x200: timing experiments, wrong results)
-    for (uint32_t i = threadIdx.x; i < n_walk; i += NM_BLOCK) {
+    for (uint32_t i = threadIdx.x; i < n_walk; i += NM_QUAD_BLOCK) {
         const uint64_t p = q_p[i];
         bool amb0 = false, err = false;
         const uint32_t v = nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
@@ -1453,11 +1456,11 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kme
         return NM_OK;
     }
     if (quad_kernel) {
-        const uint64_t per_block = (uint64_t)(NM_BLOCK / NM_WAVE) * NM_QUAD_PER_WAVE;
-        const dim3 qgrid((unsigned)((num_kmers + per_block - 1) / per_block));
+        const uint64_t per_block = (uint64_t)(NM_QUAD_BLOCK / NM_WAVE) * NM_QUAD_PER_WAVE;
+        const dim3 qgrid((unsigned)((num_kmers + per_block - 1) / per_block)), qblock(NM_QUAD_BLOCK);
         ix->last_kernel = 5;
-        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_quad<BIG, true>), qgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
-        else                 hipLaunchKernelGGL((k_min_unique_quad<BIG, false>), qgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_quad<BIG, true>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+        else                 hipLaunchKernelGGL((k_min_unique_quad<BIG, false>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
         return NM_OK;
     }
     if (pair_kernel) {

@@ -370,14 +370,22 @@ NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint
     return nm_min_unique_walk_any<BIG, RC>(ix, enc, p, w, lo, hi, k, kmin, kmax, err, t);
 }
 
-// Repeat probe (both-strand range mode).  A k-mer that is a substring of a string occurring twice
-// occurs twice itself, so ONE walk from P that is still not unique at length L settles every
-// position q in [P, P + L - kmax]: its kmax-mer lies inside S[P .. P+L), has no unique prefix of any
-// length <= kmax, and the element stored for it is 0 whatever kmin is (U_q = kmax: the span is free
-// of ambiguous bytes).  The probe extends to at most kmax + stride - 1 bases and returns how many
-// positions from P on are settled that way (0 .. stride); inside long repeats this replaces `stride`
-// walks of kmax steps by one walk of kmax + stride steps.  Never changes a result -- positions it does
-// not settle take the ordinary path.
+// Repeat probe (both-strand range mode): one walk from every stride-th position P that knows two things
+// the positions after it can use.
+//  (1) A k-mer that is a substring of a string occurring twice occurs twice itself.  If S[P .. P+L) is still
+//      not unique, every position q in [P, P + L - kmax] has its kmax-mer inside it: no unique prefix of any
+//      length <= kmax, element 0 whatever kmin is (U_q = kmax: the span is free of ambiguous bytes).  If the
+//      walk ends at an ambiguous byte (or the end of the data) with S[P .. P+k) not unique, every q in
+//      [P, P+k) is 0: all its k-mers up to U_q = P + k - q lie inside the repeated string.
+//  (2) e(q) = q + (least unique length at q) never decreases with q (same substring argument).  When the
+//      probes of two neighbouring strides report the same end, e(P) = e(P + stride), every position between
+//      them has that end too, so its least unique length is e - q -- exact, without a table lookup or a walk.
+//      Inside any repeat longer than a stride that is the rule: all its positions become unique at the
+//      first base after the repeat.
+// The probe extends to at most kmax + stride - 1 bases.  It returns a word: bits 0..7 the number of positions
+// from P on that (1) settles (0 .. stride), bits 8..31 the exact least unique length at P when the walk found
+// it (0 = not known).  Never changes a result -- positions the probes do not decide take the ordinary path.
+#define NM_PROBE_OPEN 0xFFFFFFFFu
 template <bool BIG>
 NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64_t P, uint32_t kmax,
                                uint32_t stride, nm_tally &t) {
@@ -390,28 +398,48 @@ NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64
     if (ix.seed && s && s <= kmax && (w.amb & ((1ULL << s) - 1ULL)) == 0) {
         t.seeds++;
         if (nm_seed_decode(NM_SEED_LOAD(ix, nm_seed_slot(w, s)), lo, hi)) {
-            if (hi - lo <= 1) return 0;                   // unique (or absent) within the seed: nothing to skip
+            if (hi - lo <= 1) return 0;                   // unique (or absent) within the seed: nothing to tell
             k = s;
         } else { lo = 0; hi = ix.n; }
     }
-    uint32_t first_unique;                                // a lower bound of the least unique length at P
+    uint32_t first_unique, exact = 0, settled;            // first_unique: a lower bound of the least unique length at P
     for (;;) {
         const uint64_t cnt = hi - lo;
         if (cnt == 0) return 0;                           // absent k-mer: the ordinary path reports it
-        if (cnt == 1) { first_unique = k; break; }        // every shorter prefix occurs twice
+        if (cnt == 1) { first_unique = exact = k; break; }   // every shorter prefix occurs twice
         if (k >= cap) { first_unique = cap + 1; break; }
         uint32_t j = k - kbase;
         if (j >= 64) { w = nm_load_window(enc, P + k); kbase = k; j = 0; }
-        if ((w.amb >> j) & 1ULL) { first_unique = k + 1; break; }   // S[P .. P+k) occurs twice and ends the run
+        if ((w.amb >> j) & 1ULL) {                        // S[P .. P+k) occurs twice and ends the run: all of it is 0
+            return k < stride ? k : stride;
+        }
         const uint32_t c = 3u - nm_window_code(w, j);
         t.steps++;
         t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u;
         nm_lf_interval<BIG>(ix, c, lo, hi);
         k++;
     }
-    if (first_unique <= kmax) return 0;
-    const uint32_t settled = first_unique - kmax;         // q - P < first_unique - kmax
-    return settled < stride ? settled : stride;
+    settled = first_unique > kmax ? first_unique - kmax : 0u;            // q - P < first_unique - kmax
+    if (settled > stride) settled = stride;
+    if (exact >= (1u << 24)) exact = 0;
+    return settled | (exact << 8);
+}
+
+// What the probe words of a position's stride (wj) and of the next stride (wj1) say about the position at
+// offset o of the stride: its least unique length (kmax + 1 standing for "none up to kmax"), or NM_PROBE_OPEN.
+NM_HD uint32_t nm_probe_kstar(uint32_t wj, uint32_t wj1, uint32_t o, uint32_t stride, uint32_t kmax) {
+    if (o < (wj & 0xFFu)) return kmax + 1;
+    const uint32_t kj = wj >> 8, kj1 = wj1 >> 8;
+    if (kj1 && kj == kj1 + stride) return kj - o;          // same end on both sides
+    return NM_PROBE_OPEN;
+}
+
+// element stored for a least unique length decided by the probes; kmin_valid: the first kmin bases of the
+// position are unambiguous (only asked when kstar < kmin; the kstar bases themselves were walked over)
+NM_HD uint32_t nm_probe_element(uint32_t kstar, uint32_t kmin, uint32_t kmax, bool kmin_valid) {
+    if (kstar > kmax) return 0;
+    if (kstar >= kmin) return kstar;
+    return kmin_valid ? kmin : 0u;
 }
 
 // One position of list mode.

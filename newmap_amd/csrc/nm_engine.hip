@@ -152,21 +152,24 @@ __device__ __forceinline__ void nm_store(void *out, int elem_bytes, uint64_t p, 
 }
 
 // ---- k_repeat_probe: one lane per NM_PROBE_STRIDE positions (nm_core.h: nm_repeat_probe) -------
-// Runs before the range kernel.  settled[j] = how many positions from j * NM_PROBE_STRIDE on lie
-// inside a stretch that occurs twice over at least kmax bases; the range kernel stores 0 for them and
-// neither reads a table line nor walks.  Lanes of a wave probe neighbouring strides, so inside a long
-// repeat they walk in step.  probe_tally (counter builds): LF steps, blocks, seed entries, settled.
+// Runs before the range kernel.  probe[j] = the word of nm_repeat_probe for stride j: how many positions from
+// j * NM_PROBE_STRIDE on lie inside a stretch that occurs twice over at least kmax bases (the range kernel
+// stores 0 for them) and the exact least unique length at the probe position (two neighbouring strides with the
+// same end decide every position between them); such positions neither read a table line nor walk.  Lanes of
+// a wave probe neighbouring strides, so inside a long repeat they walk in step.  probe[n_probes] = 0 (the
+// consumers read strides j and j+1).  probe_tally (counter builds): LF steps, blocks, seed entries, settled.
 #define NM_PROBE_STRIDE 64u
 template <bool BIG, bool STATS>
 __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_probes,
-                                                           uint32_t kmax, uint8_t *__restrict__ settled,
+                                                           uint32_t kmax, uint32_t *__restrict__ probe,
                                                            unsigned long long *__restrict__ probe_tally) {
     const uint64_t j = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     nm_tally t = {0, 0, 0, 0};
     uint32_t c = 0;
-    if (j < n_probes) {
-        c = nm_repeat_probe<BIG>(ix, enc, j * NM_PROBE_STRIDE, kmax, NM_PROBE_STRIDE, t);
-        settled[j] = (uint8_t)c;
+    if (j <= n_probes) {
+        const uint32_t word = j < n_probes ? nm_repeat_probe<BIG>(ix, enc, j * NM_PROBE_STRIDE, kmax, NM_PROBE_STRIDE, t) : 0u;
+        probe[j] = word;
+        c = word & 0xFFu;
     }
     if (STATS) {
         const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), d = wave_sum(t.seeds), e = wave_sum(c);
@@ -184,16 +187,23 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique(nm_view ix, const nm_en
                                                          uint64_t num_kmers, uint32_t kmin, uint32_t kmax,
                                                          void *__restrict__ out, int elem_bytes,
                                                          uint64_t *__restrict__ status,
-                                                         const uint8_t *__restrict__ settled) {
+                                                         const uint32_t *__restrict__ probe) {
     const uint64_t p = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     const bool inb = p < num_kmers;
     bool amb0 = false, err = false;
     nm_tally t = {0, 0, 0, 0};
     uint32_t r = 0;
     if (inb) {
-        // positions a repeat probe has settled (k_repeat_probe) store 0 without touching the index
-        if (!(settled && (uint32_t)(p & (NM_PROBE_STRIDE - 1)) < settled[p / NM_PROBE_STRIDE]))
+        // positions the repeat probes decide (k_repeat_probe) are stored without touching the index
+        uint32_t ks = NM_PROBE_OPEN;
+        if (probe) ks = nm_probe_kstar(probe[p / NM_PROBE_STRIDE], probe[p / NM_PROBE_STRIDE + 1], (uint32_t)(p & (NM_PROBE_STRIDE - 1)), NM_PROBE_STRIDE, kmax);
+        if (ks == NM_PROBE_OPEN) {
             r = nm_min_unique_one<BIG, RC>(ix, enc, p, kmin, kmax, amb0, err, t);
+        } else {
+            nm_window w = nm_load_window(enc, p);
+            uint32_t kbase = 0;
+            r = nm_probe_element(ks, kmin, kmax, ks < kmin && nm_all_valid(enc, p, w, kbase, 0, kmin));
+        }
         nm_store(out, elem_bytes, p, r);
     }
     nm_epilogue<STATS>(inb, amb0, err, p, t, status);
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
                                                               uint64_t n_enc_words, uint64_t num_kmers,
                                                               uint32_t kmin, uint32_t kmax, void *__restrict__ out,
                                                               int elem_bytes, uint64_t *__restrict__ status,
-                                                              const uint8_t *__restrict__ settled) {
+                                                              const uint32_t *__restrict__ probe) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * 128ull;
@@ -324,16 +334,16 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
     const bool in0 = p0 < num_kmers, in1 = p1 < num_kmers;
     const bool amb0 = (win0.amb & 1ULL) != 0, amb1 = (win0.amb & 2ULL) != 0;
     const bool core_ok = ((win0.amb >> 1) & core_mask) == 0;
-    // positions a repeat probe has settled store 0 and read nothing (p0, p1 share a probe stride)
-    uint32_t n_settled = 0;                               // two strides per wave: wave-uniform addresses -> scalar loads
-    if (settled && wave_base < num_kmers) {
-        const uint32_t c_first = settled[w0];
-        const uint32_t c_second = wave_base + NM_PROBE_STRIDE < num_kmers ? settled[w0 + 1] : 0u;
-        n_settled = q < NM_PROBE_STRIDE ? c_first : c_second;
+    // positions the repeat probes decide store their element and read nothing (p0, p1 share a probe stride)
+    uint32_t ks0 = NM_PROBE_OPEN, ks1 = NM_PROBE_OPEN;
+    if (probe && in0) {
+        const uint32_t wj = probe[p0 / NM_PROBE_STRIDE], wj1 = probe[p0 / NM_PROBE_STRIDE + 1];
+        const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
+        ks0 = nm_probe_kstar(wj, wj1, off0, NM_PROBE_STRIDE, kmax);
+        ks1 = nm_probe_kstar(wj, wj1, off0 + 1, NM_PROBE_STRIDE, kmax);
     }
-    const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
-    const bool go0 = in0 && !amb0 && core_ok && off0 >= n_settled;               // bases 0..m unambiguous
-    const bool go1 = in1 && core_ok && !((win0.amb >> s) & 1ULL) && off0 + 1 >= n_settled;   // bases 1..m+1 unambiguous
+    const bool go0 = in0 && !amb0 && core_ok && ks0 == NM_PROBE_OPEN;                        // bases 0..m unambiguous
+    const bool go1 = in1 && core_ok && !((win0.amb >> s) & 1ULL) && ks1 == NM_PROBE_OPEN;     // bases 1..m+1 unambiguous
     const uint64_t slot = ((win0.lo >> 1) & core_mask) | (((win0.hi >> 1) & core_mask) << m);
     const uint64_t *blk = ix.pair + slot * 8;
     uint64_t e0 = 0, e1 = 0;
@@ -349,10 +359,14 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
     __shared__ uint32_t q_n;
     if (threadIdx.x == 0) q_n = 0;
     __syncthreads();
-    auto stage1 = [&](bool go, bool in_range, uint64_t p, const nm_window &win, uint64_t e) {
+    auto stage1 = [&](bool go, bool in_range, uint64_t p, const nm_window &win, uint64_t e, uint32_t ks) {
         if (!in_range) return;
         uint32_t r = 0;
-        if (go) {
+        if (ks != NM_PROBE_OPEN) {                         // decided by the probes
+            nm_window w = win;
+            uint32_t kbase = 0;
+            r = nm_probe_element(ks, kmin, kmax, ks < kmin && nm_all_valid(enc, p, w, kbase, 0, kmin));
+        } else if (go) {
             uint64_t lo = 0, hi = ix.n;
             const bool have = nm_seed_decode(e, lo, hi);
             const uint64_t cnt = hi - lo;
@@ -374,8 +388,8 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
         }
         nm_store(out, elem_bytes, p, r);
     };
-    stage1(go0, in0, p0, win0, e0);
-    stage1(go1, in1, p1, win1, e1);
+    stage1(go0, in0, p0, win0, e0, ks0);
+    stage1(go1, in1, p1, win1, e1, ks1);
     __syncthreads();
     // ---- stage 2: dense walks; waves beyond the queue length leave and free their slots
     const uint32_t n_walk = q_n;
@@ -424,15 +438,15 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
 #define NM_QUAD_GROUPS 2
 #define NM_QUAD_MAX_KMIN 60u      /* kmin bases from any of a lane's four positions lie inside its 64-base window */
 #define NM_QUAD_PER_WAVE (256u * NM_QUAD_GROUPS)
-// one wave per workgroup: the two barriers then cost nothing and no wave waits for the slowest line of three
-// others, so the load / compute / store phases of the 32 resident waves of a CU drift apart and overlap
-#define NM_QUAD_BLOCK 64
-template <bool BIG, bool STATS>
+// Workgroup size (template argument QB): 256 lanes share one walk queue, so the walks of a stretch of repeated
+// positions (the last kmax positions of every repeat) spread over four waves instead of running as four passes
+// of one; 64 saves the barriers' waiting on unique input (2 % there, measured) -- NEWMAP_AMD_QUAD_BLOCK.
+template <bool BIG, bool STATS, int NM_QUAD_BLOCK>
 __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, const nm_enc_word *__restrict__ enc,
                                                               uint64_t n_enc_words, uint64_t num_kmers,
                                                               uint32_t kmin, uint32_t kmax, void *__restrict__ out,
                                                               int elem_bytes, uint64_t *__restrict__ status,
-                                                              const uint8_t *__restrict__ settled) {
+                                                              const uint32_t *__restrict__ probe) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_QUAD_BLOCK / NM_WAVE) + wave_in_block) * NM_QUAD_PER_WAVE;
@@ -457,6 +471,7 @@ __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, c
 #define NM_SEL4(f, a, b, c, d) (qw == 0 ? a.f : (qw == 1 ? b.f : (qw == 2 ? c.f : d.f)))
     uint64_t e[NM_QUAD_GROUPS][4];
     uint32_t go[NM_QUAD_GROUPS], inb[NM_QUAD_GROUPS];     // bit i: position i of the group
+    uint32_t pw[NM_QUAD_GROUPS][2];                       // probe words of the group's stride and of the next one
     uint32_t n_amb = 0, n_searched = 0, n_entries = 0;
 #pragma unroll
     for (int g = 0; g < NM_QUAD_GROUPS; g++) {
@@ -473,17 +488,21 @@ __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, c
             win[g] = nm_window_from(Wa, Wb, q & 63);      // bases p0 .. p0+63
         }
         const uint64_t p0 = wave_base + 256u * g + q;
-        const uint32_t n_settled = (settled && p0 < num_kmers) ? settled[p0 / NM_PROBE_STRIDE] : 0u;   // four positions, one stride
+        uint32_t wj = 0, wj1 = 0;                          // four positions, one probe stride (words 0, 0: nothing decided)
+        if (probe && p0 < num_kmers) { wj = probe[p0 / NM_PROBE_STRIDE]; wj1 = probe[p0 / NM_PROBE_STRIDE + 1]; }
+        pw[g][0] = wj; pw[g][1] = wj1;
         const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
         go[g] = 0; inb[g] = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
             const bool in = p0 + i < num_kmers;
             const bool amb = ((win[g].amb >> i) & 1ULL) != 0;
+            const bool kmin_valid = ((win[g].amb >> i) & vmask) == 0;
+            const uint32_t ks = nm_probe_kstar(wj, wj1, off0 + i, NM_PROBE_STRIDE, kmax);
             inb[g] |= (uint32_t)in << i;
             n_amb += (uint32_t)(in && amb);
             n_searched += (uint32_t)(in && !amb);
-            go[g] |= (uint32_t)(in && ((win[g].amb >> i) & vmask) == 0 && off0 + i >= n_settled) << i;
+            go[g] |= (uint32_t)(in && kmin_valid && ks == NM_PROBE_OPEN) << i;
         }
         e[g][0] = e[g][1] = e[g][2] = e[g][3] = 0;
         if (go[g] && !(ix.seed_policy & 0x200u)) {        // the core lies inside every window that is free of ambiguity
@@ -508,8 +527,13 @@ __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, c
         const uint32_t once = nm_quad_bits(win[g], m, e[g]);
         uint32_t r[4] = {0, 0, 0, 0};
         const uint32_t hit = go[g] & once, walk = go[g] & ~once;
+        const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
 #pragma unroll
-        for (uint32_t i = 0; i < 4; i++) r[i] = ((hit >> i) & 1u) ? kmin : 0u;
+        for (uint32_t i = 0; i < 4; i++) {
+            r[i] = ((hit >> i) & 1u) ? kmin : 0u;
+            const uint32_t ks = nm_probe_kstar(pw[g][0], pw[g][1], off0 + i, NM_PROBE_STRIDE, kmax);
+            if (ks != NM_PROBE_OPEN) r[i] = nm_probe_element(ks, kmin, kmax, ((win[g].amb >> i) & vmask) == 0);   // decided by the probes
+        }
         if (walk) {
             uint32_t at = atomicAdd(&q_n, (uint32_t)__builtin_popcount(walk));
 #pragma unroll
@@ -889,6 +913,7 @@ struct nm_index {
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
     nm_buffer enc, seq, out, status, ks, starts, lens, work, settled;
+    int quad_block = 256;                 // workgroup size of k_min_unique_quad (64 or 256, NEWMAP_AMD_QUAD_BLOCK)
     bool repeat_probes = true;            // k_repeat_probe before the both-strand range kernels (NM_OPT_REPEAT_PROBES)
     uint64_t enc_words = 0;               // words written by the last nm_encode
     int kernel_version = 0;               // 0 = automatic (pair kernel when its table exists, else 1); 1..4 force a kernel
@@ -1260,6 +1285,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     rc = nm_build_seed(ix, s, quad_m);
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     const bool have_quad = ix->view.quad != nullptr;
+    if (const char *qb = getenv("NEWMAP_AMD_QUAD_BLOCK")) ix->quad_block = atoi(qb) == 64 ? 64 : 256;
     const char *force_pair = getenv("NEWMAP_AMD_PAIR");
     if (seed_len_override < -1 && s >= 5 && (!have_quad || (force_pair && force_pair[0] == '1'))) {
         // without a quad table: the pair table (cores of s-1 bases, same resolution as the
@@ -1431,16 +1457,16 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kme
     const bool quad_kernel = RC && (ix->kernel_version == 5 || ix->kernel_version == 0) && view.quad && kmin >= view.quad_m + NM_QUAD_EXT &&
                              kmin <= NM_QUAD_MAX_KMIN;
     const bool pair_kernel = !quad_kernel && RC && (ix->kernel_version == 4 || ix->kernel_version == 0) && view.pair && kmin >= view.pair_m + 1;
-    // repeat probes feed the two kernels that take a `settled` array: the pair kernel and k_min_unique
-    const uint8_t *settled = nullptr;
+    // repeat probes feed the kernels that take the probe words: the quad and pair kernels and k_min_unique
+    const uint32_t *settled = nullptr;
     if (RC && ix->repeat_probes && ix->kernel_version != 2 && ix->kernel_version != 3) {   // (versions 4 and 5 fall back to 1 without their table)
         const uint64_t n_probes = (num_kmers + NM_PROBE_STRIDE - 1) / NM_PROBE_STRIDE;
-        const int rc = nm_grow(ix->settled, n_probes);
+        const int rc = nm_grow(ix->settled, (n_probes + 1) * sizeof(uint32_t));
         if (rc != NM_OK) return rc;
         unsigned long long *tally = (unsigned long long *)ix->work.p + 1;
-        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes)), block, 0, st, view, enc, n_probes, kmax, (uint8_t *)ix->settled.p, tally);
-        else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes)), block, 0, st, view, enc, n_probes, kmax, (uint8_t *)ix->settled.p, tally);
-        settled = (const uint8_t *)ix->settled.p;
+        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally);
+        else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally);
+        settled = (const uint32_t *)ix->settled.p;
     }
     nm_timed timed(ix, st);
     if (RC && ix->kernel_version == 2) {
@@ -1456,11 +1482,17 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kme
         return NM_OK;
     }
     if (quad_kernel) {
-        const uint64_t per_block = (uint64_t)(NM_QUAD_BLOCK / NM_WAVE) * NM_QUAD_PER_WAVE;
-        const dim3 qgrid((unsigned)((num_kmers + per_block - 1) / per_block)), qblock(NM_QUAD_BLOCK);
+        const unsigned qb = ix->quad_block == 64 ? 64u : 256u;
+        const uint64_t per_block = (uint64_t)(qb / NM_WAVE) * NM_QUAD_PER_WAVE;
+        const dim3 qgrid((unsigned)((num_kmers + per_block - 1) / per_block)), qblock(qb);
         ix->last_kernel = 5;
-        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_quad<BIG, true>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
-        else                 hipLaunchKernelGGL((k_min_unique_quad<BIG, false>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+        if (qb == 64) {
+            if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_quad<BIG, true, 64>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+            else                 hipLaunchKernelGGL((k_min_unique_quad<BIG, false, 64>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+        } else {
+            if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_quad<BIG, true, 256>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+            else                 hipLaunchKernelGGL((k_min_unique_quad<BIG, false, 256>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+        }
         return NM_OK;
     }
     if (pair_kernel) {

@@ -274,18 +274,28 @@ int hs_min_unique(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t n
     return status[1] ? 8 : 0;
 }
 
-// the repeat probes of one segment (k_repeat_probe): settled[j] for every stride; returns the LF steps spent
-uint64_t hs_repeat_probes(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmax,
-                          uint32_t stride, uint8_t *settled) {
+// the repeat probes of one segment (k_repeat_probe): the probe word of every stride, and what the consumers
+// make of them: decided[p] = the element nm_probe_kstar / nm_probe_element give position p, 0xFFFFFFFF where the
+// probes leave it open.  Returns the LF steps spent.
+uint64_t hs_repeat_probes(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin,
+                          uint32_t kmax, uint32_t stride, uint32_t *words, uint32_t *decided) {
     std::vector<nm_enc_word> enc;
     hs_encode(seq, seq_len, enc);
     uint64_t steps = 0;
     const uint64_t n_probes = (num_kmers + stride - 1) / stride;
     for (uint64_t j = 0; j < n_probes; j++) {
         nm_tally t = {0, 0, 0, 0};
-        settled[j] = (uint8_t)(ix->big ? nm_repeat_probe<true>(ix->v, enc.data(), j * stride, kmax, stride, t)
-                                       : nm_repeat_probe<false>(ix->v, enc.data(), j * stride, kmax, stride, t));
+        words[j] = ix->big ? nm_repeat_probe<true>(ix->v, enc.data(), j * stride, kmax, stride, t)
+                           : nm_repeat_probe<false>(ix->v, enc.data(), j * stride, kmax, stride, t);
         steps += t.steps;
+    }
+    words[n_probes] = 0;
+    for (uint64_t p = 0; p < num_kmers; p++) {
+        const uint32_t ks = nm_probe_kstar(words[p / stride], words[p / stride + 1], (uint32_t)(p % stride), stride, kmax);
+        if (ks == NM_PROBE_OPEN) { decided[p] = 0xFFFFFFFFu; continue; }
+        nm_window w = nm_load_window(enc.data(), p);
+        uint32_t kbase = 0;
+        decided[p] = nm_probe_element(ks, kmin, kmax, ks < kmin && nm_all_valid(enc.data(), p, w, kbase, 0, kmin));
     }
     return steps;
 }

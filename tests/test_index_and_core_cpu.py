@@ -255,10 +255,11 @@ def test_two_step_rank_blocks(tmp_path, golden_search):
                 assert got[rid.encode()].tolist() == exp["values"], (c["name"], rid, seed)
 
 
-def test_repeat_probes_settle_only_zero_positions(tmp_path):
-    """nm_repeat_probe (the logic of k_repeat_probe): every position a probe settles has no unique
-    k-mer up to kmax according to the oracle, long repeats ARE settled, and the probes cost far fewer
-    LF steps than the walks they replace."""
+def test_repeat_probes_decide_only_what_the_oracle_confirms(tmp_path):
+    """nm_repeat_probe / nm_probe_kstar / nm_probe_element (the logic of k_repeat_probe and of its consumers):
+    every element the probes decide -- zeros inside long repeats, exact lengths where two neighbouring probes
+    see the same end -- equals the oracle's, long repeats ARE decided, and the probes cost far fewer LF steps
+    than the walks they replace."""
     rng = np.random.default_rng(2027)
     alpha = np.frombuffer(b"ACGT", np.uint8)
     r1 = bytearray(bytes(alpha[rng.integers(0, 4, 24000)]))
@@ -266,6 +267,7 @@ def test_repeat_probes_settle_only_zero_positions(tmp_path):
     r1[3000:9000] = (unit * 600)[:6000]                    # tandem array
     r1[15000:16200] = r1[1000:2200]                        # dispersed 1.2 kb copy
     r1[15500:15503] = b"NNN"                               # ... broken by ambiguous bytes
+    r1[18000:18400] = r1[11000:11400]                      # 400-base copy: exact lengths through the sandwich
     rc_src = bytes(r1[20000:20900])[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
     r2 = bytes(alpha[rng.integers(0, 4, 5000)]) + rc_src    # reverse-complement copy in another record
     text = b">one\n" + bytes(r1) + b"\n>two\n" + r2 + b"\n"
@@ -276,25 +278,26 @@ def test_repeat_probes_settle_only_zero_positions(tmp_path):
     for seed in (0, 6):
         sim = HostSim(idx, seed)
         for rec in (bytes(r1), r2):
-            for kmax, stride in ((60, 64), (200, 64), (255, 64), (30, 16), (5, 64)):
-                dtype, _ = rd.output_dtype(kmax)
+            for kmin, kmax, stride in ((20, 60, 64), (20, 200, 64), (20, 255, 64), (100, 255, 64), (8, 30, 16), (3, 5, 64),
+                                       (20, 1000, 64)):
                 n = len(rec)
-                want = rd.closed_form_min_unique(rec, oracle, min(20, kmax), kmax, True)
-                settled, steps = sim.repeat_probes(rec, n, kmax, stride)
-                total = 0
-                for j, c in enumerate(settled):
-                    assert c <= stride
-                    lo = j * stride
-                    assert not want[lo:lo + int(c)].any(), (seed, kmax, stride, j)
-                    # a settled position's kmax-mer lies inside the record and has no ambiguous byte
-                    assert lo + int(c) + kmax - 1 <= n or c == 0
-                    total += int(c)
+                want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True).astype(np.int64)
+                words, decided, steps = sim.repeat_probes(rec, n, kmin, kmax, stride)
+                assert ((words & 0xFF) <= stride).all()
+                closed = decided != 0xFFFFFFFF
+                assert np.array_equal(decided[closed].astype(np.int64), want[closed]), (seed, kmin, kmax, stride)
                 if rec is not r2 and kmax <= 255:
                     zeros_in_array = int((want[3000:9000 - kmax] == 0).sum())
-                    assert total >= 0.9 * zeros_in_array, (total, zeros_in_array)
+                    assert int((closed[3000:9000] & (want[3000:9000] == 0)).sum()) >= 0.9 * zeros_in_array
+                    # the walk-heavy tail of the array (lengths kmin .. kmax) is decided exactly, not walked
+                    tail = slice(9000 - kmax + stride, 9000 - 2 * stride)
+                    if tail.stop > tail.start and kmax >= 200:
+                        assert closed[tail].mean() > 0.9 and (want[tail] > 0).all()
+                if rec is not r2 and kmax == 1000:
+                    assert closed[18000:18250].mean() > 0.7 and (want[18000:18250] > 100).all()
         # the reverse-complement copy is seen through the both-strand index
-        settled, _ = sim.repeat_probes(r2, len(r2), 200, 64)
-        assert settled[5000 // 64 + 1:].sum() > 400
+        words, decided, _ = sim.repeat_probes(r2, len(r2), 20, 200, 64)
+        assert (decided[5100:5600] != 0xFFFFFFFF).sum() > 400
 
 
 @pytest.mark.parametrize("m,force_big", [(4, False), (6, False), (5, True)])

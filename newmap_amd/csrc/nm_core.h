@@ -386,6 +386,18 @@ NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint
 // from P on that (1) settles (0 .. stride), bits 8..31 the exact least unique length at P when the walk found
 // it (0 = not known).  Never changes a result -- positions the probes do not decide take the ordinary path.
 #define NM_PROBE_OPEN 0xFFFFFFFFu
+
+// quad-table bit of the FIRST position of a group (word 0 of the entry of the core three bases on, see the
+// quad table below): true when the (quad_m + 3)-mer at the start of `w` occurs exactly once
+NM_HD bool nm_quad_once_first(const nm_view &ix, const nm_window &w, uint32_t kmax) {
+    const uint32_t m = ix.quad_m, len = m + 3;
+    if (len > kmax || (w.amb & ((1ULL << len) - 1ULL)) != 0) return false;
+    const uint64_t mask = (1ULL << m) - 1ULL;
+    const uint64_t slot = ((w.lo >> 3) & mask) | (((w.hi >> 3) & mask) << m);
+    const uint32_t i0 = nm_window_code(w, 0) | (nm_window_code(w, 1) << 2) | (nm_window_code(w, 2) << 4);
+    return ((ix.quad[slot * 4] >> i0) & 1ULL) != 0;
+}
+
 template <bool BIG>
 NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64_t P, uint32_t kmax,
                                uint32_t stride, nm_tally &t) {
@@ -395,6 +407,7 @@ NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64
     const uint32_t s = ix.seed_len;
     uint64_t lo = 0, hi = ix.n;
     uint32_t k = 0, kbase = 0;
+    if (ix.quad && nm_quad_once_first(ix, w, kmax)) return 0;   // unique within the quad table's window: nothing to tell
     if (ix.seed && s && s <= kmax && (w.amb & ((1ULL << s) - 1ULL)) == 0) {
         t.seeds++;
         if (nm_seed_decode(NM_SEED_LOAD(ix, nm_seed_slot(w, s)), lo, hi)) {

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -52,13 +53,23 @@ static inline int pd_threads() {
 template <class T>
 class PdBuf {
 public:
-    explicit PdBuf(uint64_t n) : p_((T *)malloc((size_t)(n ? n : 1) * sizeof(T))) { if (!p_) throw std::bad_alloc(); }
-    ~PdBuf() { free(p_); }
+    explicit PdBuf(uint64_t n) : p_((T *)malloc((size_t)(n ? n : 1) * sizeof(T))), bytes_((size_t)(n ? n : 1) * sizeof(T)) { if (!p_) throw std::bad_alloc(); }
+    ~PdBuf() { release(); }
     PdBuf(const PdBuf &) = delete;
     PdBuf &operator=(const PdBuf &) = delete;
     T *data() { return p_; }
     T &operator[](uint64_t i) { return p_[i]; }
-    void release() { free(p_); p_ = nullptr; }
+    // unmapping 100 GB of touched pages takes ~10 s: big buffers are handed to a detached thread so that the
+    // sorter goes on while the kernel takes the pages back
+    void release() {
+        if (p_ && bytes_ >= ((size_t)1 << 30)) {
+            T *p = p_;
+            try { std::thread([p] { free(p); }).detach(); } catch (...) { free(p); }
+        } else {
+            free(p_);
+        }
+        p_ = nullptr;
+    }
     // first touch by all threads, each on its own contiguous slice: page faults are then taken in
     // parallel and sequentially instead of inside a random scatter
     void touch(uint64_t n) {
@@ -76,6 +87,7 @@ public:
     }
 private:
     T *p_;
+    size_t bytes_;
 };
 
 // (key, position) pair of the initial sort
@@ -181,11 +193,14 @@ void pd_suffix_array(const uint8_t *s, uint64_t n, I *SA) {
         if (verbose) { fprintf(stderr, "[pdsa] initial sort %.2fs\n", pd_now() - t0); t0 = pd_now(); }
 #pragma omp parallel for schedule(static) num_threads(nt)
         for (int64_t j = 0; j < (int64_t)n; j++) { K[j] = A[j].k; SA[j] = A[j].i; }
+        if (verbose) { fprintf(stderr, "[pdsa]   keys and positions apart %.2fs\n", pd_now() - t0); }
     }
+    if (verbose) { fprintf(stderr, "[pdsa]   sort buffers released %.2fs\n", pd_now() - t0); }
 
     // ---- 2. group heads and ranks
     PdBuf<I> R(n);                                           // R[i] = index of the head of i's group
     R.touch(n);
+    if (verbose) { fprintf(stderr, "[pdsa]   rank array touched %.2fs\n", pd_now() - t0); }
     PdBuf<I> &H = V2;                                        // H[j] = head index of sorted position j
     std::vector<std::vector<PdGroup<I>>> tg((size_t)nt);
     {
@@ -208,6 +223,7 @@ void pd_suffix_array(const uint8_t *s, uint64_t n, I *SA) {
             last_head[t] = head;
             has_head[t] = seen;
         }
+        if (verbose) { fprintf(stderr, "[pdsa]   heads %.2fs\n", pd_now() - t0); }
         // groups that cross chunk starts: carry the head from the left
         std::vector<uint64_t> carry((size_t)nt, 0);
         for (int t = 1; t < nt; t++) carry[t] = has_head[t - 1] ? last_head[t - 1] : carry[t - 1];

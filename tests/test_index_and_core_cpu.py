@@ -320,3 +320,11 @@ def test_quad_table_bits_equal_direct_counts(tmp_path, m, force_big):
     assert sim.check_quad() == 0
     sim.enable_lfb(True)                                   # the table walk on LF entries instead of the packed blocks
     assert sim.check_quad() == 0
+    # repeat probes that consult the quad table first decide nothing the oracle contradicts
+    oracle = rd.OracleIndex([bytes(r1), r2])
+    rec = bytes(r1)
+    for kmin, kmax in ((m + 3, 40), (4, 12)):
+        want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True).astype(np.int64)
+        words, decided, _ = sim.repeat_probes(rec, len(rec), kmin, kmax, 16)
+        closed = decided != 0xFFFFFFFF
+        assert closed.any() and np.array_equal(decided[closed].astype(np.int64), want[closed])

@@ -8,6 +8,7 @@ non-counting build of the kernel (template argument STATS = false) are averaged.
 import collections
 import csv
 import glob
+import re
 import sys
 
 
@@ -20,7 +21,7 @@ def main():
             with open(f) as fh:
                 for row in csv.DictReader(fh):
                     name = row["Kernel_Name"]
-                    if kernel not in name or ", true>" in name:
+                    if kernel not in name or re.search(r"<(true|false), true[,>]", name):    # STATS builds
                         continue
                     per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
             for c, by_dispatch in per.items():

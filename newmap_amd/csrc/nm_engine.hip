@@ -1,12 +1,17 @@
 // nm_engine.hip -- the MI355X (gfx950 / CDNA4) engine behind the C-ABI of include/newmap_amd.h.
 //
 // Kernels (all integer / bit work, HBM-gather bound, no MFMA):
-//   k_encode        sequence bytes -> 2 bit-planes + ambiguity plane (wave ballots), 32 B / 64 bases
-//   k_seed          device-side construction of the 4^s seed table from the rank blocks
-//   k_min_unique    range mode, one lane per genome position (newmap/search.py:383-548)
-//   k_fixed_k       list mode,  one lane per genome position (newmap/search.py:551-644)
-//   k_count         forward-strand counts of (start, len) k-mers (src/newmap-count.c:91-206)
-//   k_upper         per-position upper search length (newmap/search.py:744-882)
+//   k_encode16 / k_encode   sequence bytes -> 2 bit-planes + ambiguity plane, 32 B / 64 bases
+//   k_repeat_probe          one walk per 64 positions: settles long repeats, fixes lengths between equal ends
+//   k_min_unique_quad       range mode, four positions per 32-byte quad-table entry (default, newmap/search.py:383-548)
+//   k_min_unique_pair       range mode, two positions per pair-table block
+//   k_min_unique            range mode, one lane per genome position (also --norc and short kmin)
+//   k_min_unique_v2, _mp    earlier schedules of the same arithmetic, kept for A/B
+//   k_fixed_k               list mode,  one lane per genome position (newmap/search.py:551-644)
+//   k_multi                 several FASTA files x several index files (newmap/search.py:461, 656-697)
+//   k_count                 forward-strand counts of (start, len) k-mers (src/newmap-count.c:91-206)
+//   k_upper                 per-position upper search length (newmap/search.py:744-882)
+//   k_seed, k_seed_level, k_quad_build, k_pair_gather, k_pair, k_lf_blocks, k_rank2_*   tables built at open
 // The per-position logic lives in nm_core.h.
 #include <hip/hip_runtime.h>
 

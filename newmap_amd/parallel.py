@@ -9,8 +9,11 @@ index, so positions shard with no data-path collective:
     lookahead taken from the same record (the reference's own segment rule,
     newmap/search.py:229-235, newmap/fasta.py:109-150);
   * each rank runs its units on its GPU and keeps the uintN results of its slice;
-  * ONE collective at the end: the per-rank slices (padded to equal length) are gathered on rank 0,
-    which cuts them back into per-record `<id>.unique.<dtype>` files.
+  * output: every rank writes its slice straight into the per-record `<id>.unique.<dtype>` files at the
+    slice's byte offsets (rank 0 creates the files at full length first) -- each GPU drains over its own PCIe
+    link and nothing crosses xGMI.  For jobs whose ranks do not share a file system
+    (NEWMAP_AMD_GATHER=1) ONE collective at the end gathers the padded per-rank slices on rank 0 (RCCL),
+    which writes the files.
 
 The same code runs on CPU tensors with the "gloo" backend (tests/test_parallel_gloo.py), with the
 per-unit compute injected.
@@ -93,6 +96,39 @@ def gather_to_root(local: np.ndarray, total: int, world: int, rank: int, device=
     return None
 
 
+def write_slice_direct(records: Sequence[tuple[bytes, bytes]], local: np.ndarray, lo: int, hi: int,
+                       path_of: Callable[[bytes], Path], rank: int, barrier: Callable[[], None]) -> None:
+    """No collective: rank 0 creates every output file at its full length, then each rank writes the part of
+    its slice [lo, hi) (global positions, records laid end to end) that falls into each record at that
+    record's byte offset.  Duplicate ids: the later record wins, like the reference's truncate-on-new-id
+    (search.py:304-305)."""
+    import os
+    item = local.dtype.itemsize
+    last = {rid: i for i, (rid, _) in enumerate(records)}             # the record that owns each file
+    if rank == 0:
+        for i, (rid, data) in enumerate(records):
+            if last[rid] == i:
+                with open(path_of(rid), "wb") as fh:
+                    fh.truncate(len(data) * item)
+    barrier()
+    base = 0
+    for i, (rid, data) in enumerate(records):
+        n = len(data)
+        a, b = max(lo, base), min(hi, base + n)
+        if a < b and last[rid] == i:
+            fd = os.open(path_of(rid), os.O_WRONLY)
+            try:
+                buf = memoryview(np.ascontiguousarray(local[a - lo:b - lo])).cast("B")
+                off = (a - base) * item
+                while len(buf):
+                    w = os.pwrite(fd, buf, off)
+                    buf, off = buf[w:], off + w
+            finally:
+                os.close(fd)
+        base += n
+    barrier()
+
+
 def search_records_sharded(records: Sequence[tuple[bytes, bytes]], compute: Callable[[bytes, int], np.ndarray],
                            kmax: int, batch: int, dtype, world: int, rank: int, device=None):
     """Returns {record id: array} on rank 0 (None elsewhere)."""
@@ -152,12 +188,23 @@ def write_unique_counts_distributed(config) -> None:
             return index.min_unique_segment(seg, count, kmin, kmax, config.use_reverse_complement, dtype)[0]
         return index.fixed_k_segment(seg, count, config.kmer_lengths, config.use_reverse_complement, dtype)[0]
 
-    result = search_records_sharded(records, compute, kmax, config.kmer_batch_size, dtype, world, rank, device)
-    if result is not None:
-        for rid, arr in result.items():
-            path = Path(config.output_directory) / S.UNIQUE_COUNT_FILENAME_FORMAT.format(rid.decode(), suffix)
-            with open(path, "wb") as fh:
-                arr.tofile(fh)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
+    def path_of(rid: bytes) -> Path:
+        return Path(config.output_directory) / S.UNIQUE_COUNT_FILENAME_FORMAT.format(rid.decode(), suffix)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    if world > 1 and os.environ.get("NEWMAP_AMD_GATHER", "0") == "1":   # ranks without a shared file system
+        result = search_records_sharded(records, compute, kmax, config.kmer_batch_size, dtype, world, rank, device)
+        if result is not None:
+            for rid, arr in result.items():
+                with open(path_of(rid), "wb") as fh:
+                    arr.tofile(fh)
+        barrier()
+        return
+    lengths = [len(d) for _, d in records]
+    lo, hi = shard_bounds(int(sum(lengths)), world)[rank]
+    local = run_slice(records, units_for_slice(lengths, lo, hi, config.kmer_batch_size, kmax), compute, dtype)
+    write_slice_direct(records, local, lo, hi, path_of, rank, barrier)

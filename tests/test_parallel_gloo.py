@@ -50,6 +50,15 @@ def _worker(rank, world, port, outdir):
     else:
         assert res is None
     dist.barrier()
+    # the default output path: no collective, every rank writes its slice into the shared files (uint16 here, so
+    # that byte offsets differ from positions); records "a" twice: the later one owns the file
+    records2 = records + [(b"a", records[1][1][:900])]
+    lengths = [len(d) for _, d in records2]
+    lo, hi = parallel.shard_bounds(sum(lengths), world)[rank]
+    local = parallel.run_slice(records2, parallel.units_for_slice(lengths, lo, hi, batch, kmax),
+                               lambda seg, count: rd.closed_form_min_unique(seg, oracle, kmin, kmax)[:count], np.uint16)
+    parallel.write_slice_direct(records2, local, lo, hi, lambda rid: Path(outdir) / f"w{world}.{rid.decode()}.uint16",
+                                rank, dist.barrier)
     dist.destroy_process_group()
 
 
@@ -65,6 +74,9 @@ def test_sharded_search_equals_single_process(tmp_path, world):
     for rid, data in records:
         want = rd.closed_form_min_unique(data, oracle, 8, 40)
         assert np.array_equal(got[rid.decode()], want), rid
+    for rid, data in [records[1], records[2], (b"a", records[1][1][:900])]:        # files written without a collective
+        want = rd.closed_form_min_unique(data, oracle, 8, 40).astype(np.uint16)
+        assert np.array_equal(np.fromfile(tmp_path / f"w{world}.{rid.decode()}.uint16", dtype=np.uint16), want), rid
 
 
 def test_plan_covers_every_position_once():

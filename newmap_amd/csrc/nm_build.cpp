@@ -122,7 +122,7 @@ int read_fasta(const char *path, FastaText &ft) {
 
 template <class I>
 int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_ratio, uint8_t seed_len,
-                    nm_sa32_provider provider = nullptr, void *provider_ctx = nullptr) {
+                    nm_sa32_provider provider = nullptr, void *provider_ctx = nullptr, nm_bwt_provider bwt_provider = nullptr) {
     const uint64_t nf = ft.f.size();
     const uint64_t n = 2 * nf + 1;
     // T = F . RC . '#'
@@ -142,8 +142,23 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
     // (NEWMAP_AMD_SA=sais|pd forces one; both give the same array, tests/test_index_and_core_cpu.py)
     const bool verbose = nm::pd_verbose();
     double tv = nm::pd_now();
-    nm::PdBuf<I> SA(n);
-    {
+    const int nt = nm::pd_threads();
+    nm::PdBuf<uint8_t> bw(n);                                  // BWT symbol (low bits) | "suffix starts in the RC half" (bit 7)
+    bool have_bw = false;
+    if (bwt_provider) {
+        // suffix sort AND the gather of the BWT on the device (nm_build_device.hip): only n bytes come back
+        const int rc = bwt_provider(T.data(), n, nf, bw.data(), provider_ctx);
+        if (rc == NM_OK) {
+            have_bw = true;
+            if (verbose) { fprintf(stderr, "[build] suffix array + BWT on the device: %.2fs\n", nm::pd_now() - tv); tv = nm::pd_now(); }
+        } else if (rc != NM_E_ALLOC && rc != NM_E_TOO_LARGE) {
+            return rc;
+        } else if (verbose) {
+            fprintf(stderr, "[build] device suffix sort declined (%s): host sorter\n", nm_last_error());
+        }
+    }
+    nm::PdBuf<I> SA(have_bw ? 1 : n);
+    if (!have_bw) {
         const char *want = getenv("NEWMAP_AMD_SA");
         const bool use_pd = want ? strcmp(want, "pd") == 0 : (nm::pd_threads() > 1 && n > (1u << 16));
         if (provider && sizeof(I) == 4) {
@@ -175,9 +190,7 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
     if (h.n_super > NM_MAX_SUPER) { nm_set_error("text of %llu symbols is too large", (unsigned long long)n); return NM_E_TOO_LARGE; }
 
     // ---- BWT symbol (low bits) and "suffix starts in the RC half" (bit 7) per suffix-array position
-    const int nt = nm::pd_threads();
     const uint64_t nblk = h.n_rank_blocks;
-    nm::PdBuf<uint8_t> bw(n);
     std::vector<uint64_t> part((size_t)(nt + 1) * 5, 0);          // per block range: A,C,G,T,rc-half
 #pragma omp parallel num_threads(nt)
     {
@@ -190,12 +203,14 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
         const uint64_t i1 = std::min<uint64_t>(nblk * (uint64_t)(t + 1) / nt * 64, n);
         uint64_t cnt[5] = {0, 0, 0, 0, 0};
         for (uint64_t i = i0; i < i1; i++) {
-            const uint64_t p = (uint64_t)SA[i];
-            const uint8_t ch = T[p ? p - 1 : n - 1];
-            const bool rc_half = p >= nf && p < 2 * nf;
-            bw[i] = (uint8_t)(ch | (rc_half ? 0x80 : 0));
+            if (!have_bw) {
+                const uint64_t p = (uint64_t)SA[i];
+                const uint8_t c0 = T[p ? p - 1 : n - 1];
+                bw[i] = (uint8_t)(c0 | ((p >= nf && p < 2 * nf) ? 0x80 : 0));
+            }
+            const uint8_t ch = bw[i] & 0x7F;
             if (ch >= SYM_A) cnt[ch - SYM_A]++;
-            cnt[4] += rc_half;
+            cnt[4] += (bw[i] >> 7);
         }
         for (int c = 0; c < 5; c++) part[(size_t)(t + 1) * 5 + c] = cnt[c];
     }
@@ -278,7 +293,7 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
 }  // namespace
 
 int nm_index_build_impl(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len,
-                        nm_sa32_provider provider, void *provider_ctx) {
+                        nm_sa32_provider provider, void *provider_ctx, nm_bwt_provider big_provider) {
     if (!fasta_path || !index_path) { nm_set_error("null path"); return NM_E_ARGUMENT; }
     if (seed_len > 16) { nm_set_error("seed length %d is larger than the supported maximum 16", (int)seed_len); return NM_E_ARGUMENT; }
     try {
@@ -291,8 +306,12 @@ int nm_index_build_impl(const char *fasta_path, const char *index_path, uint8_t 
         int rc = read_fasta(fasta_path, ft);
         if (rc != NM_OK) return rc;
         const uint64_t n = 2 * (uint64_t)ft.f.size() + 1;
-        if (n < (1ULL << 31) - 8) return build_and_write<int32_t>(ft, index_path, sa_ratio, seed_len, provider, provider_ctx);
-        return build_and_write<int64_t>(ft, index_path, sa_ratio, seed_len);   // beyond 2^31 symbols: host sorter
+        // NEWMAP_AMD_DEVICE_SA=large (tests): the large-text device path on a small text
+        const char *force = getenv("NEWMAP_AMD_DEVICE_SA");
+        const bool force_large = big_provider && force && strcmp(force, "large") == 0;
+        if (n < (1ULL << 31) - 8 && !force_large) return build_and_write<int32_t>(ft, index_path, sa_ratio, seed_len, provider, provider_ctx);
+        if (n < (1ULL << 31) - 8) return build_and_write<int32_t>(ft, index_path, sa_ratio, seed_len, nullptr, provider_ctx, big_provider);
+        return build_and_write<int64_t>(ft, index_path, sa_ratio, seed_len, nullptr, provider_ctx, big_provider);   // host sorter unless the device takes it
     } catch (const std::bad_alloc &) {
         nm_set_error("Could not allocate enough memory to create index");
         return NM_E_ALLOC;

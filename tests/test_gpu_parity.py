@@ -628,7 +628,7 @@ def test_multi_fasta_multi_index_mode(tmp_path, eng):
     eng.close_all()
 
 
-def test_device_index_builder_writes_the_same_file(tmp_path, eng):
+def test_device_index_builder_writes_the_same_file(tmp_path, eng, monkeypatch):
     """suffix array by prefix doubling on the GPU (rocPRIM radix sorts) -> index file
     byte-identical to the host builder's, on uniform, repeat-heavy and multi-record inputs"""
     from newmap_amd import synth
@@ -644,10 +644,16 @@ def test_device_index_builder_writes_the_same_file(tmp_path, eng):
     for name, text in inputs.items():
         fa = tmp_path / f"{name}.fa"
         fa.write_bytes(text)
-        host, dev = tmp_path / f"{name}.host.awfmi", tmp_path / f"{name}.dev.awfmi"
+        host, dev, big = tmp_path / f"{name}.host.awfmi", tmp_path / f"{name}.dev.awfmi", tmp_path / f"{name}.big.awfmi"
         generate_fm_index(str(fa), str(host), 8, 12)
         generate_fm_index(str(fa), str(dev), 8, 12, device=0)
         assert host.read_bytes() == dev.read_bytes(), name
+        # the path for texts of 2^31 symbols and more (64-bit, bucketed initial sort, refinement of the tied
+        # groups only, BWT gathered on the device), forced onto the small text
+        monkeypatch.setenv("NEWMAP_AMD_DEVICE_SA", "large")
+        generate_fm_index(str(fa), str(big), 8, 12, device=0)
+        monkeypatch.delenv("NEWMAP_AMD_DEVICE_SA")
+        assert host.read_bytes() == big.read_bytes(), name
 
 
 def test_cli_end_to_end(tmp_path):

@@ -12,7 +12,8 @@
 // Every pass is a full-width radix sort of n (key, position) pairs at HBM speed; uniform DNA needs
 // one refinement pass, 50 kb tandem arrays about a dozen.  The result is the true lexicographic
 // suffix array, so the index file is byte-identical to the host builder's (tests/test_gpu_parity.py).
-// Limit: texts below 2^31 symbols (genomes up to ~1.07 Gbp); larger inputs use the host sorter.
+// This full-width variant takes texts below 2^31 symbols (genomes up to ~1.07 Gbp); larger ones go through
+// device_bwt_large further down (64-bit, bucketed, refinement of the tied groups only).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -192,9 +193,10 @@ __global__ __launch_bounds__(SA_BLOCK) void k_big_hist(const uint8_t *__restrict
 }
 
 // positions whose leading symbols spell bucket b, in any order (they are sorted next)
-__global__ __launch_bounds__(SA_BLOCK) void k_big_collect(const uint8_t *__restrict__ T, u64 n, unsigned bits, u64 bucket,
+// (kernels over all n positions are launched in slices of 2^31: a grid may not exceed 2^32 work-items)
+__global__ __launch_bounds__(SA_BLOCK) void k_big_collect(const uint8_t *__restrict__ T, u64 first, u64 n, unsigned bits, u64 bucket,
                                                           u64 *__restrict__ idx, u64 *__restrict__ key, u64 *__restrict__ counter) {
-    const u64 i = blockIdx.x * (u64)SA_BLOCK + threadIdx.x;
+    const u64 i = first + blockIdx.x * (u64)SA_BLOCK + threadIdx.x;
     bool mine = false;
     if (i < n) {
         u64 b = 0;
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(SA_BLOCK) void k_big_place(const u64 *__restrict__ 
 }
 
 // 1 where sorted position j belongs to a group of more than one suffix
-__global__ __launch_bounds__(SA_BLOCK) void k_big_tied(const u64 *__restrict__ SA, const u64 *__restrict__ rank, u64 n, uint8_t *__restrict__ flag) {
-    const u64 j = blockIdx.x * (u64)SA_BLOCK + threadIdx.x;
+__global__ __launch_bounds__(SA_BLOCK) void k_big_tied(const u64 *__restrict__ SA, const u64 *__restrict__ rank, u64 first, u64 n, uint8_t *__restrict__ flag) {
+    const u64 j = first + blockIdx.x * (u64)SA_BLOCK + threadIdx.x;
     if (j >= n) return;
     const bool head = rank[SA[j]] == j;
     const bool next_head = j + 1 >= n || rank[SA[j + 1]] == j + 1;
@@ -281,8 +283,8 @@ __global__ __launch_bounds__(SA_BLOCK) void k_big_write(const uint32_t *__restri
     keep[k] = (head && next_head) ? 0 : 1;                 // singletons leave the list
 }
 
-__global__ __launch_bounds__(SA_BLOCK) void k_big_bwt(const uint8_t *__restrict__ T, const u64 *__restrict__ SA, u64 n, u64 nf, uint8_t *__restrict__ bw) {
-    const u64 j = blockIdx.x * (u64)SA_BLOCK + threadIdx.x;
+__global__ __launch_bounds__(SA_BLOCK) void k_big_bwt(const uint8_t *__restrict__ T, const u64 *__restrict__ SA, u64 first, u64 n, u64 nf, uint8_t *__restrict__ bw) {
+    const u64 j = first + blockIdx.x * (u64)SA_BLOCK + threadIdx.x;
     if (j >= n) return;
     const u64 p = SA[j];
     bw[j] = (uint8_t)(T[p ? p - 1 : n - 1] | ((p >= nf && p < 2 * nf) ? 0x80 : 0));
@@ -301,13 +303,17 @@ int device_bwt_large(const uint8_t *T, uint64_t n, uint64_t nf, uint8_t *bw, voi
     auto fail = [&](int code) { (void)hipStreamDestroy(st); return code; };
 #define TRYB(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { nm_set_error("HIP error %d (%s): %s", (int)e__, hipGetErrorString(e__), #expr); return fail(e__ == hipErrorOutOfMemory ? NM_E_ALLOC : NM_E_DEVICE); } } while (0)
     auto grid = [](u64 m) { return dim3((unsigned)((m + SA_BLOCK - 1) / SA_BLOCK)); };
+    const u64 slice = 1ULL << 31;                            // positions per launch of the kernels that sweep the text
     DBuf dT, dSA, dRank, dHist, dCount;
     int rc;
     if ((rc = dev_alloc(dT, n)) || (rc = dev_alloc(dSA, n * 8)) || (rc = dev_alloc(dRank, n * 8)) || (rc = dev_alloc(dCount, 64))) {
         nm_set_error("not enough device memory for a text of %llu symbols", (unsigned long long)n);
         return fail(NM_E_ALLOC);
     }
-    TRYB(hipMemcpyAsync(dT.p, T, n, hipMemcpyHostToDevice, st));
+    for (u64 a = 0; a < n; a += 1ULL << 30) {                 // copies of at most 1 GiB
+        const u64 len = n - a < (1ULL << 30) ? n - a : (1ULL << 30);
+        TRYB(hipMemcpyAsync((uint8_t *)dT.p + a, T + a, len, hipMemcpyHostToDevice, st));
+    }
     const uint8_t *d_T = (const uint8_t *)dT.p;
     u64 *SA = (u64 *)dSA.p, *rank = (u64 *)dRank.p, *count = (u64 *)dCount.p;
 
@@ -351,7 +357,15 @@ int device_bwt_large(const uint8_t *T, uint64_t n, uint64_t nf, uint8_t *bw, voi
             if (!m) continue;
             rocprim::double_buffer<u64> kb((u64 *)dK0.p, (u64 *)dK1.p), vb((u64 *)dI0.p, (u64 *)dI1.p);
             TRYB(hipMemsetAsync(count, 0, 8, st));
-            hipLaunchKernelGGL(k_big_collect, grid(n), dim3(SA_BLOCK), 0, st, d_T, (u64)n, bits, b, vb.current(), kb.current(), count);
+            for (u64 first = 0; first < n; first += slice)
+                hipLaunchKernelGGL(k_big_collect, grid(n - first < slice ? n - first : slice), dim3(SA_BLOCK), 0, st, d_T, first, (u64)n, bits, b,
+                                   vb.current(), kb.current(), count);
+            if (verbose) {
+                u64 got = 0;
+                TRYB(hipMemcpyAsync(&got, count, 8, hipMemcpyDeviceToHost, st));
+                TRYB(hipStreamSynchronize(st));
+                if (got != m) { nm_set_error("device suffix sort: bucket %llu collected %llu of %llu", b, got, m); return fail(NM_E_DEVICE); }
+            }
             size_t tb = t_bytes;
             TRYB(rocprim::radix_sort_pairs(dTmp.p, tb, kb, vb, m, 0, 63, st));
             hipLaunchKernelGGL(k_big_starts, grid(m), dim3(SA_BLOCK), 0, st, (const u64 *)kb.current(), m, offset, (u64 *)dStart.p);
@@ -371,7 +385,9 @@ int device_bwt_large(const uint8_t *T, uint64_t n, uint64_t nf, uint8_t *bw, voi
     {
         DBuf dFlag, dTmp;
         if ((rc = dev_alloc(dFlag, n)) != NM_OK) return fail(NM_E_ALLOC);
-        hipLaunchKernelGGL(k_big_tied, grid(n), dim3(SA_BLOCK), 0, st, (const u64 *)SA, (const u64 *)rank, (u64)n, (uint8_t *)dFlag.p);
+        for (u64 first = 0; first < n; first += slice)
+            hipLaunchKernelGGL(k_big_tied, grid(n - first < slice ? n - first : slice), dim3(SA_BLOCK), 0, st, (const u64 *)SA, (const u64 *)rank,
+                               first, (u64)n, (uint8_t *)dFlag.p);
         // count first, so that the list gets exactly the room it needs; the primitives run over chunks of 2^30
         const u64 chunk = 1ULL << 30;
         size_t t_red = 0, t_sel = 0;
@@ -406,7 +422,7 @@ int device_bwt_large(const uint8_t *T, uint64_t n, uint64_t nf, uint8_t *bw, voi
     }
     int rounds = 0;
     for (u64 h = SA_H0; m; h *= 2) {
-        if (++rounds > 48) { nm_set_error("device suffix sort did not converge"); return fail(NM_E_DEVICE); }
+        if (++rounds > 48 || h > 2 * (u64)n) { nm_set_error("device suffix sort did not converge"); return fail(NM_E_DEVICE); }
         DBuf dSa, dHead, dKey2, dKa, dKb, dPa, dPb, dStart, dKeep, dNew, dTmp;
         if ((rc = dev_alloc(dSa, m * 8)) || (rc = dev_alloc(dHead, m * 8)) || (rc = dev_alloc(dKey2, m * 8)) || (rc = dev_alloc(dKa, m * 8)) ||
             (rc = dev_alloc(dKb, m * 8)) || (rc = dev_alloc(dPa, m * 4)) || (rc = dev_alloc(dPb, m * 4)) || (rc = dev_alloc(dStart, m * 8)) ||
@@ -454,8 +470,13 @@ int device_bwt_large(const uint8_t *T, uint64_t n, uint64_t nf, uint8_t *bw, voi
     dRank.reset();
     DBuf dBw;
     if ((rc = dev_alloc(dBw, n)) != NM_OK) return fail(NM_E_ALLOC);
-    hipLaunchKernelGGL(k_big_bwt, grid(n), dim3(SA_BLOCK), 0, st, d_T, (const u64 *)SA, (u64)n, (u64)nf, (uint8_t *)dBw.p);
-    TRYB(hipMemcpyAsync(bw, dBw.p, n, hipMemcpyDeviceToHost, st));
+    for (u64 first = 0; first < n; first += slice)
+        hipLaunchKernelGGL(k_big_bwt, grid(n - first < slice ? n - first : slice), dim3(SA_BLOCK), 0, st, d_T, (const u64 *)SA, first, (u64)n, (u64)nf,
+                           (uint8_t *)dBw.p);
+    for (u64 a = 0; a < n; a += 1ULL << 30) {
+        const u64 len = n - a < (1ULL << 30) ? n - a : (1ULL << 30);
+        TRYB(hipMemcpyAsync(bw + a, (const uint8_t *)dBw.p + a, len, hipMemcpyDeviceToHost, st));
+    }
     TRYB(hipStreamSynchronize(st));
     TRYB(hipGetLastError());
     (void)hipStreamDestroy(st);

@@ -55,7 +55,8 @@ def parse():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json workload (default c2 = configs[1])")
     ap.add_argument("--mbp", type=float, default=None, help="genome size in Mbp (default: the config's own size)")
     ap.add_argument("--seed-length", default="auto",
-                    help="device seed table length: auto (default, ceil(log4 n)+1), file (the index's, 12), or 0..16")
+                    help="device tables: auto (default: sized for throughput), auto-small (<= 17 GB, what the one-shot CLI uses), "
+                         "file (the index's seed length, 12), or a seed length 0..16")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--index-builder", choices=["host", "device"], default="host",
                     help="suffix sort on the host cores (default) or on the GPU (same index file; not timed in `value`)")
@@ -217,7 +218,7 @@ def main():
     rec_off = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
     n = int(rec_off[-1])
     t0 = time.time()
-    ix = Index(idx_path, dev_index, args.seed_length if args.seed_length in ("auto", "file") else int(args.seed_length))
+    ix = Index(idx_path, dev_index, args.seed_length if args.seed_length in ("auto", "auto-small", "file") else int(args.seed_length))
     t_open = time.time() - t0
     info = ix.info()
     if rank == 0:

@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -984,6 +985,11 @@ static int nm_seed_launch(nm_index *ix, const nm_view &v, const uint64_t *parent
 
 // build the 4^s table on the device: level 8 entry by entry, every further level from the one
 // below it (launches sliced so that grid * block stays below 2^32)
+// NEWMAP_AMD_VERBOSE=1: phase timings of nm_index_open on stderr
+static bool nm_verbose() { const char *v = getenv("NEWMAP_AMD_VERBOSE"); return v && *v && *v != '0'; }
+static double nm_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define NM_PHASE(t0, what) do { if (nm_verbose()) { fprintf(stderr, "[open] %s: %.3fs\n", what, nm_now() - (t0)); (t0) = nm_now(); } } while (0)
+
 // quad table for cores of m bases, from the seed table of that length (a level of the seed-table build):
 // 4^m entries x 32 bytes
 static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m) {
@@ -991,7 +997,9 @@ static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m) 
     ix->view.quad_m = 0;
     if (!level_table || m < 3 || m > 16 || ix->h.n < 2) return NM_OK;
     const uint64_t n_cores = 1ULL << (2 * m);
+    double tq = nm_now();
     HIP_TRY(hipMalloc(&ix->d_quad, n_cores * 32));
+    NM_PHASE(tq, "quad table hipMalloc");
     ix->device_bytes += n_cores * 32;
     nm_view v = ix->view;
     v.seed = level_table;
@@ -1004,6 +1012,7 @@ static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m) 
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ix->stream));
+    NM_PHASE(tq, "quad table kernels");
     ix->view.quad = (const uint64_t *)ix->d_quad;
     ix->view.quad_m = m;
     return NM_OK;
@@ -1012,7 +1021,9 @@ static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m) 
 // quad_m: also derive the quad table from the level of that length (0 = none)
 static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table, uint32_t quad_m = 0) {
     const uint64_t n_slots = 1ULL << (2 * s);
+    double ts = nm_now();
     HIP_TRY(hipMalloc(d_table, n_slots * sizeof(uint64_t)));
+    NM_PHASE(ts, "seed table hipMalloc");
     ix->device_bytes += n_slots * sizeof(uint64_t);
     nm_view v = ix->view;
     v.seed = nullptr;
@@ -1030,6 +1041,7 @@ static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table, uint32_
         cur = level < s ? dst : nullptr;
     }
     if (cur) (void)hipFree(cur);
+    NM_PHASE(ts, "seed table levels (incl. the quad table)");
     return rc;
 }
 
@@ -1180,6 +1192,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         nm_set_error("device %d: this engine has no CPU path; a MI355X device index (>= 0) is required", device);
         return NM_E_DEVICE;
     }
+    double t_open = nm_now();
     FILE *fp = fopen(index_path, "rb");
     if (!fp) { nm_set_error("Could not load reference index from file %s", index_path); return NM_E_FILE_OPEN; }
     nm_file_header h;
@@ -1247,6 +1260,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     }
     fclose(fp);
     fp = nullptr;
+    NM_PHASE(t_open, "device init + index file read + upload");
 
     nm_view &v = ix->view;
     v.rank = (const nm_rank_block *)ix->d_rank;
@@ -1273,16 +1287,23 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         if (!(off && off[0] == '0')) {
             rc = nm_build_lf_blocks(ix);
             if (rc != NM_OK) { nm_index_close(ix); return rc; }
+            NM_PHASE(t_open, "LF blocks");
         }
     }
     uint32_t s = seed_len_override == -1 ? h.seed_len
                : (seed_len_override < -1 ? nm_auto_seed_len(ix) : (uint32_t)seed_len_override);
     if (s > 16) s = 16;
+    // -3: automatic with small tables (seed <= 15, quad cores <= 14: 17 GB at most).  A one-shot run never earns
+    // back what the large tables cost to allocate: hipMalloc of more than ~40 GB waits 3 - 5 s for the driver to
+    // clear the memory (measured), the large tables save ~1.5 ps per position.
+    const bool small_tables = seed_len_override == -3;
+    if (small_tables && s > 15) s = 15;
     // automatic sizing: the quad table, cut from the seed-table level of its core length.  Core length:
     // NEWMAP_AMD_QUAD_M (0 = none), else nm_auto_quad_len.
     uint32_t quad_m = 0;
     if (seed_len_override < -1 && s >= 8) {
         quad_m = nm_auto_quad_len(ix, s);
+        if (small_tables && quad_m > 14) quad_m = 14;
         if (const char *q = getenv("NEWMAP_AMD_QUAD_M")) quad_m = (uint32_t)atoi(q);
         if (quad_m > s) quad_m = s;
         if (quad_m && quad_m < 8) quad_m = 8;              // the level-wise build starts at length 8

@@ -40,14 +40,18 @@ class Index:
     """Device-resident index.  Replaces the per-call load of src/newmap-count.c:9-17,135-136."""
 
     def __init__(self, index_path, device: int | None = None, seed_length: int | str | None = None):
-        """seed_length: None / "auto" = sized for the device (ceil(log4 n)+1, <= 16), "file" = the
-        --seed-length recorded by `newmap index`, 0 = no seed table, 1..16 = that length."""
+        """seed_length: None / "auto" = tables sized for throughput (seed ceil(log4 n)+2 <= 16 bases, quad table of
+        the same core length: up to 172 GB, 3 - 5 s to allocate), "auto-small" = the same kernels on tables of at
+        most 17 GB (what the one-shot CLI uses), "file" = the --seed-length recorded by `newmap index`,
+        0 = no seed table, 1..16 = that length."""
         self._L = _lib.lib()
         self.path = Path(index_path)
         self.device = default_device() if device is None else int(device)
         if seed_length is None:
             seed_length = os.environ.get("NEWMAP_AMD_SEED_LENGTH", "auto")
-        code = -2 if seed_length == "auto" else (-1 if seed_length == "file" else int(seed_length))
+        code = {"auto": -2, "auto-small": -3, "file": -1}.get(seed_length)
+        if code is None:
+            code = int(seed_length)
         h = ctypes.c_void_p()
         rc = self._L.nm_index_open(os.fsencode(self.path), self.device, code, ctypes.byref(h))
         _lib.raise_for(rc)

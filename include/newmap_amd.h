@@ -151,8 +151,10 @@ enum {
     NM_OPT_SEED_POLICY = 7,        /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */
     NM_OPT_TWO_STEP = 8,           /* walks on the two-step rank blocks (built only with NEWMAP_AMD_TWO_STEP=1) */
     NM_OPT_LF_BLOCKS = 9,          /* LF steps on the 16-byte LF entries (default when built) or the packed rank blocks */
-    NM_OPT_REPEAT_PROBES = 10      /* both-strand range mode: one probe per 64 positions settles stretches that occur
+    NM_OPT_REPEAT_PROBES = 10,     /* both-strand range mode: one probe per 64 positions settles stretches that occur
                                       twice over more than kmax bases (default 1; 0 = every position searches for itself) */
+    NM_OPT_LIST_VIA_RANGE = 11     /* list mode with ONE length on both strands runs on the range kernels with
+                                      kmin = kmax = k (default 1; 0 = the list kernel, for A/B) */
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 

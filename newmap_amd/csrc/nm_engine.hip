@@ -442,12 +442,12 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
 // the entry loads of all its groups before it looks at any: with 32 waves per CU the requests in flight,
 // not the lines per position, were what kept the kernel below the HBM's random-line rate.
 #define NM_QUAD_GROUPS 2
-#define NM_QUAD_MAX_KMIN 60u      /* kmin bases from any of a lane's four positions lie inside its 64-base window */
+#define NM_QUAD_MAX_KMIN 124u     /* kmin bases from any of a lane's four positions lie inside its two 64-base windows */
 #define NM_QUAD_PER_WAVE (256u * NM_QUAD_GROUPS)
 // Workgroup size (template argument QB): 256 lanes share one walk queue, so the walks of a stretch of repeated
 // positions (the last kmax positions of every repeat) spread over four waves instead of running as four passes
 // of one; 64 saves the barriers' waiting on unique input (2 % there, measured) -- NEWMAP_AMD_QUAD_BLOCK.
-template <bool BIG, bool STATS, int NM_QUAD_BLOCK>
+template <bool BIG, bool STATS, int NM_QUAD_BLOCK, bool LONGK>
 __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, const nm_enc_word *__restrict__ enc,
                                                               uint64_t n_enc_words, uint64_t num_kmers,
                                                               uint32_t kmin, uint32_t kmax, void *__restrict__ out,
@@ -464,16 +464,24 @@ __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, c
     const uint64_t w0 = wave_base >> 6;
 #define NM_LOAD_WORD(j) const nm_enc_word W##j = enc[w0 + j < n_enc_words ? w0 + j : n_enc_words - 1];
     NM_LOAD_WORD(0) NM_LOAD_WORD(1) NM_LOAD_WORD(2) NM_LOAD_WORD(3) NM_LOAD_WORD(4)
-    NM_LOAD_WORD(5) NM_LOAD_WORD(6) NM_LOAD_WORD(7) NM_LOAD_WORD(8)
+    NM_LOAD_WORD(5) NM_LOAD_WORD(6) NM_LOAD_WORD(7) NM_LOAD_WORD(8) NM_LOAD_WORD(9)
 #undef NM_LOAD_WORD
     static_assert(NM_QUAD_GROUPS == 2, "the word variables above are written out for two groups");
     const uint32_t q = 4 * lane;                          // offset of the lane's first position in a group's 256
     const uint32_t qw = q >> 6;
     // go: the position takes part in the lookup.  kmin <= NM_QUAD_MAX_KMIN (the launcher sees to it), so the
-    // lane's 64-base window shows whether the first kmin bases are free of ambiguity (if not: U_p < kmin,
-    // element 0, search.py:437) and stage 1 is branch-free.
-    const uint64_t vmask = (1ULL << kmin) - 1ULL;
+    // lane's 64-base window -- plus the ambiguity plane of the next 64 bases when kmin > 60 -- shows whether the
+    // first kmin bases are free of ambiguity (if not: U_p < kmin, element 0, search.py:437); stage 1 is branch-free.
+    constexpr bool long_kmin = LONGK;                      // kmin > 60: its own instantiation (6 more VGPRs cost a wave per SIMD)
     nm_window win[NM_QUAD_GROUPS];
+    uint64_t amb_next[NM_QUAD_GROUPS];                     // ambiguity plane of bases p0+64 .. p0+127 (long_kmin only)
+    auto kmin_bases_valid = [&](int g, uint32_t i) -> bool {
+        const uint64_t a = win[g].amb >> i;
+        if (!long_kmin) return (a & ((1ULL << kmin) - 1ULL)) == 0;
+        const uint32_t n_lo = kmin < 64u - i ? kmin : 64u - i, n_hi = kmin - n_lo;        // n_hi <= 63
+        const uint64_t lo_mask = n_lo == 64 ? ~0ULL : ((1ULL << n_lo) - 1ULL);
+        return (a & lo_mask) == 0 && (amb_next[g] & ((1ULL << n_hi) - 1ULL)) == 0;
+    };
 #define NM_SEL4(f, a, b, c, d) (qw == 0 ? a.f : (qw == 1 ? b.f : (qw == 2 ? c.f : d.f)))
     uint64_t e[NM_QUAD_GROUPS][4];
     uint32_t go[NM_QUAD_GROUPS], inb[NM_QUAD_GROUPS];     // bit i: position i of the group
@@ -492,6 +500,12 @@ __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, c
                 Wb.lo = NM_SEL4(lo, W5, W6, W7, W8); Wb.hi = NM_SEL4(hi, W5, W6, W7, W8); Wb.amb = NM_SEL4(amb, W5, W6, W7, W8);
             }
             win[g] = nm_window_from(Wa, Wb, q & 63);      // bases p0 .. p0+63
+            amb_next[g] = 0;
+            if (long_kmin) {
+                const uint64_t c = g == 0 ? NM_SEL4(amb, W2, W3, W4, W5) : NM_SEL4(amb, W6, W7, W8, W9);
+                const uint32_t sh = q & 63;
+                amb_next[g] = sh ? (Wb.amb >> sh) | (c << (64 - sh)) : Wb.amb;
+            }
         }
         const uint64_t p0 = wave_base + 256u * g + q;
         uint32_t wj = 0, wj1 = 0;                          // four positions, one probe stride (words 0, 0: nothing decided)
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, c
         for (uint32_t i = 0; i < 4; i++) {
             const bool in = p0 + i < num_kmers;
             const bool amb = ((win[g].amb >> i) & 1ULL) != 0;
-            const bool kmin_valid = ((win[g].amb >> i) & vmask) == 0;
+            const bool kmin_valid = kmin_bases_valid(g, i);
             const uint32_t ks = nm_probe_kstar(wj, wj1, off0 + i, NM_PROBE_STRIDE, kmax);
             inb[g] |= (uint32_t)in << i;
             n_amb += (uint32_t)(in && amb);
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, c
         for (uint32_t i = 0; i < 4; i++) {
             r[i] = ((hit >> i) & 1u) ? kmin : 0u;
             const uint32_t ks = nm_probe_kstar(pw[g][0], pw[g][1], off0 + i, NM_PROBE_STRIDE, kmax);
-            if (ks != NM_PROBE_OPEN) r[i] = nm_probe_element(ks, kmin, kmax, ((win[g].amb >> i) & vmask) == 0);   // decided by the probes
+            if (ks != NM_PROBE_OPEN) r[i] = nm_probe_element(ks, kmin, kmax, kmin_bases_valid(g, i));   // decided by the probes
         }
         if (walk) {
             uint32_t at = atomicAdd(&q_n, (uint32_t)__builtin_popcount(walk));
@@ -832,11 +846,11 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_v2(nm_view ix, const nm
 
 template <bool BIG, bool RC, bool STATS>
 __global__ __launch_bounds__(NM_BLOCK) void k_fixed_k(nm_view ix, const nm_enc_word *__restrict__ enc,
-                                                      uint64_t seq_len, uint64_t num_kmers,
+                                                      uint64_t seq_len, uint64_t first, uint64_t num_kmers,
                                                       const uint32_t *__restrict__ ks, uint32_t nk,
                                                       void *__restrict__ out, int elem_bytes,
                                                       uint64_t *__restrict__ status) {
-    const uint64_t p = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    const uint64_t p = first + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     const bool inb = p < num_kmers;
     bool amb0 = false, err = false;
     nm_tally t = {0, 0, 0, 0};
@@ -919,6 +933,7 @@ struct nm_index {
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
     nm_buffer enc, seq, out, status, ks, starts, lens, work, settled;
+    bool list_via_range = true;           // list mode with one length runs on the range kernels (NM_OPT_LIST_VIA_RANGE, A/B)
     int quad_block = 256;                 // workgroup size of k_min_unique_quad (64 or 256, NEWMAP_AMD_QUAD_BLOCK)
     bool repeat_probes = true;            // k_repeat_probe before the both-strand range kernels (NM_OPT_REPEAT_PROBES)
     uint64_t enc_words = 0;               // words written by the last nm_encode
@@ -1407,6 +1422,10 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         ix->big = value != 0 || ix->h.n_super > 1;
         return NM_OK;
     }
+    if (option == NM_OPT_LIST_VIA_RANGE) {
+        ix->list_via_range = value != 0;
+        return NM_OK;
+    }
     if (option == NM_OPT_REPEAT_PROBES) {
         ix->repeat_probes = value != 0;
         return NM_OK;
@@ -1512,13 +1531,17 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kme
         const uint64_t per_block = (uint64_t)(qb / NM_WAVE) * NM_QUAD_PER_WAVE;
         const dim3 qgrid((unsigned)((num_kmers + per_block - 1) / per_block)), qblock(qb);
         ix->last_kernel = 5;
+        const bool longk = kmin > 60;
+#define NM_LAUNCH_QUAD(STATS_, QB_, LONG_) hipLaunchKernelGGL((k_min_unique_quad<BIG, STATS_, QB_, LONG_>), qgrid, qblock, 0, st, view, enc, ix->enc_words, \
+                                                              num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled)
         if (qb == 64) {
-            if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_quad<BIG, true, 64>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
-            else                 hipLaunchKernelGGL((k_min_unique_quad<BIG, false, 64>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+            if (ix->count_steps) { if (longk) NM_LAUNCH_QUAD(true, 64, true); else NM_LAUNCH_QUAD(true, 64, false); }
+            else                 { if (longk) NM_LAUNCH_QUAD(false, 64, true); else NM_LAUNCH_QUAD(false, 64, false); }
         } else {
-            if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_quad<BIG, true, 256>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
-            else                 hipLaunchKernelGGL((k_min_unique_quad<BIG, false, 256>), qgrid, qblock, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
+            if (ix->count_steps) { if (longk) NM_LAUNCH_QUAD(true, 256, true); else NM_LAUNCH_QUAD(true, 256, false); }
+            else                 { if (longk) NM_LAUNCH_QUAD(false, 256, true); else NM_LAUNCH_QUAD(false, 256, false); }
         }
+#undef NM_LAUNCH_QUAD
         return NM_OK;
     }
     if (pair_kernel) {
@@ -1568,13 +1591,13 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
 }
 
 template <bool BIG, bool RC>
-static void launch_fixed_k(nm_index *ix, const nm_view &view, uint64_t seq_len, uint64_t num_kmers, const uint32_t *d_ks, uint32_t nk,
+static void launch_fixed_k(nm_index *ix, const nm_view &view, uint64_t seq_len, uint64_t first, uint64_t num_kmers, const uint32_t *d_ks, uint32_t nk,
                            void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st) {
-    const dim3 grid(nm_grid(num_kmers)), block(NM_BLOCK);
+    const dim3 grid(nm_grid(num_kmers - first)), block(NM_BLOCK);      // positions [first, num_kmers)
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
     nm_timed timed(ix, st);
-    if (ix->count_steps) hipLaunchKernelGGL((k_fixed_k<BIG, RC, true>), grid, block, 0, st, view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
-    else                 hipLaunchKernelGGL((k_fixed_k<BIG, RC, false>), grid, block, 0, st, view, enc, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
+    if (ix->count_steps) hipLaunchKernelGGL((k_fixed_k<BIG, RC, true>), grid, block, 0, st, view, enc, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
+    else                 hipLaunchKernelGGL((k_fixed_k<BIG, RC, false>), grid, block, 0, st, view, enc, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
 }
 
 extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
@@ -1602,8 +1625,24 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     for (uint32_t i = 1; i < nk; i++) if (ks[i] < kshort) kshort = ks[i];
     nm_view view;
     if ((rc = nm_view_for(ix, kshort, &view)) != NM_OK) return rc;
-    if (ix->big) { if (use_revcomp) launch_fixed_k<true, true>(ix, view, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<true, false>(ix, view, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
-    else         { if (use_revcomp) launch_fixed_k<false, true>(ix, view, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<false, false>(ix, view, seq_len, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
+    // ONE length K on both strands is range mode with kmin = kmax = K for every position whose K-mer lies inside
+    // the data (same walk, same early stop at one occurrence, same ambiguity rule): those positions take the
+    // range kernels with their tables and repeat probes; the up to K-1 positions at the end of the data, whose
+    // k-mer the reference truncates (search.py:590), keep the list kernel.
+    uint64_t first = 0;
+    if (nk == 1 && use_revcomp && ix->list_via_range && (view.quad || view.pair) && seq_len >= ks[0]) {
+        const uint64_t head = num_kmers < seq_len - ks[0] + 1 ? num_kmers : seq_len - ks[0] + 1;
+        if (head) {
+            rc = ix->big ? launch_min_unique<true, true>(ix, view, head, ks[0], ks[0], d_out, elem_bytes, d_status, st)
+                         : launch_min_unique<false, true>(ix, view, head, ks[0], ks[0], d_out, elem_bytes, d_status, st);
+            if (rc != NM_OK) return rc;
+            first = head;
+        }
+    }
+    if (first < num_kmers) {
+        if (ix->big) { if (use_revcomp) launch_fixed_k<true, true>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<true, false>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
+        else         { if (use_revcomp) launch_fixed_k<false, true>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<false, false>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
+    }
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }

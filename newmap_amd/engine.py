@@ -119,6 +119,10 @@ class Index:
         (default on); off = every position searches for itself.  Results are identical."""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_REPEAT_PROBES, int(bool(on))))
 
+    def set_list_via_range(self, on: bool):
+        """A/B: list mode with one length on the range kernels (default) or on the list kernel."""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LIST_VIA_RANGE, int(bool(on))))
+
     def set_lf_blocks(self, on: bool):
         """LF steps read one 16-byte LF entry (default) or the packed 32-byte rank block"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LF_BLOCKS, int(bool(on))))

@@ -157,7 +157,8 @@ def test_batch_independence_and_segment_api(mixed_genome, eng):
 
 
 @pytest.mark.parametrize("ks,rc", [([36], True), ([100], True), ([12, 20, 30], True), ([30, 12], True),
-                                   ([24], False), ([300, 20], True)])
+                                   ([24], False), ([300, 20], True), ([15], True), ([14], True), ([60], True), ([61], True),
+                                   ([124], True), ([125], True), ([1000], True)])
 def test_fixed_k_equals_oracle(mixed_genome, eng, ks, rc):
     g = mixed_genome
     kmax = max(ks)
@@ -171,9 +172,14 @@ def test_fixed_k_equals_oracle(mixed_genome, eng, ks, rc):
                 for seg in rd.record_segments(b"r", rec, batch + kmax - 1, kmax - 1):
                     n = rd.num_kmers_of(seg, kmax)
                     w, _ = rd.linear_search_segment(g["oracle"], seg, ks, kmax, dtype, rc)
-                    a, _ = ix.fixed_k_segment(seg.data, n, ks, rc)
+                    a, amb_a = ix.fixed_k_segment(seg.data, n, ks, rc)
                     got.append(a)
                     want.append(w)
+                    if len(ks) == 1 and rc:                # one length: the range kernels (default) vs the list kernel
+                        ix.set_list_via_range(False)
+                        b, amb_b = ix.fixed_k_segment(seg.data, n, ks, rc)
+                        ix.set_list_via_range(True)
+                        assert np.array_equal(a, b) and amb_a == amb_b, (ks, batch)
                 assert np.array_equal(np.concatenate(got), np.concatenate(want)), (ks, rc, batch)
 
 
@@ -321,6 +327,11 @@ def test_large_random_genome_properties(tmp_path, eng):
         tot2 = ix.count_from_sequence(rec, pos[longer], k[longer] - 1) + \
             ix.count_from_sequence(rcrec, len(rec) - pos[longer] - (k[longer] - 1), k[longer] - 1)
         assert (tot2 > 1).all()
+    with eng.Index(idx, 0, "auto-small") as small:          # the one-shot CLI's tables: same kernels, 17 GB
+        info = small.info()
+        assert info["seed_length"] == 15 and info["quad_core_length"] == 14 and info["device_bytes"] < 20e9
+        got, _ = small.min_unique_segment(rec[:20_000_199], 20_000_000, kmin, kmax)
+        assert small.info()["last_range_kernel"] == 5 and np.array_equal(got, whole[:20_000_000])
     with eng.Index(idx, 0, 12) as ix12:                   # the reference's default seed length, simple kernel
         seed12, _ = ix12.min_unique_segment(rec, len(rec), kmin, kmax)
         assert ix12.info()["last_range_kernel"] == 1 and np.array_equal(seed12, whole)
@@ -463,7 +474,8 @@ def test_both_range_kernels_agree(mixed_genome, eng, monkeypatch):
         assert 8 <= info["quad_core_length"] <= info["seed_length"] and info["pair_core_length"] == info["seed_length"] - 1
         w = info["quad_core_length"] + 3
         for rec in (g["r1"], g["r2"]):
-            for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (60, 90), (61, 90)):
+            for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (60, 90), (61, 90), (64, 64), (100, 300),
+                               (124, 200), (125, 200)):
                 ix.set_kernel(2)
                 a, amb_a = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                 ix.set_kernel(1)
@@ -476,7 +488,7 @@ def test_both_range_kernels_agree(mixed_genome, eng, monkeypatch):
                     c, amb_c = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                     used = ix.info()["last_range_kernel"]
                     pair_ok = kmin >= info["pair_core_length"] + 1
-                    quad_ok = w <= kmin <= 60                     # NM_QUAD_MAX_KMIN
+                    quad_ok = w <= kmin <= 124                    # NM_QUAD_MAX_KMIN
                     if kernel in (0, 5):
                         assert used == (5 if quad_ok else (4 if kernel == 0 and pair_ok else 1)), (kernel, kmin, used)
                     if kernel == 4:

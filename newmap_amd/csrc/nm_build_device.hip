@@ -192,30 +192,48 @@ __global__ __launch_bounds__(SA_BLOCK) void k_big_hist(const uint8_t *__restrict
         if (bins[b]) atomicAdd(&hist[b], (u64)bins[b]);
 }
 
-// positions whose leading symbols spell bucket b, in any order (they are sorted next)
-// (kernels over all n positions are launched in slices of 2^31: a grid may not exceed 2^32 work-items)
-__global__ __launch_bounds__(SA_BLOCK) void k_big_collect(const uint8_t *__restrict__ T, u64 first, u64 n, unsigned bits, u64 bucket,
+// positions whose leading symbols spell bucket b, in any order (they are sorted next).  A block owns a
+// contiguous chunk of the text: it counts its members, reserves their slots with ONE atomic and writes them on a
+// second sweep (one atomic per wave on a single counter made this kernel 90 % of the build at 6.2 G symbols).
+__global__ __launch_bounds__(SA_BLOCK) void k_big_collect(const uint8_t *__restrict__ T, u64 n, unsigned bits, u64 bucket,
                                                           u64 *__restrict__ idx, u64 *__restrict__ key, u64 *__restrict__ counter) {
-    const u64 i = first + blockIdx.x * (u64)SA_BLOCK + threadIdx.x;
-    bool mine = false;
-    if (i < n) {
+    __shared__ unsigned long long cursor;
+    __shared__ unsigned total;
+    const u64 per_block = (n + gridDim.x - 1) / gridDim.x;
+    const u64 a = blockIdx.x * per_block, e = a + per_block < n ? a + per_block : n;
+    const unsigned lane = threadIdx.x & 63;
+    auto member = [&](u64 i) -> bool {
+        if (i >= e) return false;
         u64 b = 0;
         for (unsigned j = 0; j < bits / 3; j++) b = (b << 3) | (u64)(i + j < n ? T[i + j] : 0);
-        mine = b == bucket;
-    }
-    const u64 mask = __ballot(mine);
-    if (!mask) return;
-    const unsigned lane = threadIdx.x & 63;
-    u64 base = 0;
-    if (lane == (unsigned)__ffsll((long long)mask) - 1) base = atomicAdd(counter, (u64)__popcll(mask));
-    base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-    if (mine) {
-        const u64 at = base + (u64)__popcll(mask & ((1ULL << lane) - 1ULL));
-        u64 k = 0;
+        return b == bucket;
+    };
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    unsigned mine = 0;
+    for (u64 i = a + threadIdx.x; i < e; i += SA_BLOCK) mine += member(i) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if (lane == 0 && mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) cursor = total ? atomicAdd(counter, (u64)total) : 0ULL;
+    __syncthreads();
+    if (!total) return;
+    for (u64 base_i = a; base_i < e; base_i += SA_BLOCK) {     // all lanes take every trip: the ballots need whole waves
+        const u64 i = base_i + threadIdx.x;
+        const bool m = member(i);
+        const u64 mask = __ballot(m);
+        if (!mask) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&cursor, (unsigned long long)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (m) {
+            const u64 at = base + (u64)__popcll(mask & ((1ULL << lane) - 1ULL));
+            u64 k = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < SA_H0; j++) k |= (u64)(i + j < n ? T[i + j] : 0) << (3 * (SA_H0 - 1 - j));
-        idx[at] = i;
-        key[at] = k;
+            for (uint32_t j = 0; j < SA_H0; j++) k |= (u64)(i + j < n ? T[i + j] : 0) << (3 * (SA_H0 - 1 - j));
+            idx[at] = i;
+            key[at] = k;
+        }
     }
 }
 
@@ -321,6 +339,7 @@ int device_bwt_large(const uint8_t *T, uint64_t n, uint64_t nf, uint8_t *bw, voi
     size_t free_b = 0, total_b = 0;
     TRYB(hipMemGetInfo(&free_b, &total_b));
     const u64 budget = (u64)(free_b / 10 * 8) / 48;          // 48 bytes of buffers per member of a bucket
+    const u64 hist_blocks = n / (16 * SA_BLOCK) + 1 < 16384 ? n / (16 * SA_BLOCK) + 1 : 16384;   // blocks of the text sweeps
     unsigned bits = 0;
     std::vector<u64> hist;
     for (unsigned try_bits : {6u, 9u, SA_MAX_BUCKET_BITS}) {
@@ -328,7 +347,6 @@ int device_bwt_large(const uint8_t *T, uint64_t n, uint64_t nf, uint8_t *bw, voi
         DBuf dH;
         if ((rc = dev_alloc(dH, nb * 8)) != NM_OK) return fail(rc);
         TRYB(hipMemsetAsync(dH.p, 0, nb * 8, st));
-        const u64 hist_blocks = n / (16 * SA_BLOCK) + 1 < 8192 ? n / (16 * SA_BLOCK) + 1 : 8192;      // per block < 2^32 elements
         hipLaunchKernelGGL(k_big_hist, dim3((unsigned)hist_blocks), dim3(SA_BLOCK), 0, st, d_T, (u64)n, try_bits, (u64 *)dH.p);
         hist.assign(nb, 0);
         TRYB(hipMemcpyAsync(hist.data(), dH.p, nb * 8, hipMemcpyDeviceToHost, st));
@@ -357,9 +375,8 @@ int device_bwt_large(const uint8_t *T, uint64_t n, uint64_t nf, uint8_t *bw, voi
             if (!m) continue;
             rocprim::double_buffer<u64> kb((u64 *)dK0.p, (u64 *)dK1.p), vb((u64 *)dI0.p, (u64 *)dI1.p);
             TRYB(hipMemsetAsync(count, 0, 8, st));
-            for (u64 first = 0; first < n; first += slice)
-                hipLaunchKernelGGL(k_big_collect, grid(n - first < slice ? n - first : slice), dim3(SA_BLOCK), 0, st, d_T, first, (u64)n, bits, b,
-                                   vb.current(), kb.current(), count);
+            hipLaunchKernelGGL(k_big_collect, dim3((unsigned)hist_blocks), dim3(SA_BLOCK), 0, st, d_T, (u64)n, bits, b,
+                               vb.current(), kb.current(), count);
             if (verbose) {
                 u64 got = 0;
                 TRYB(hipMemcpyAsync(&got, count, 8, hipMemcpyDeviceToHost, st));

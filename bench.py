@@ -32,7 +32,11 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-BATCH = 10_000_000
+BATCH = 100_000_000          # positions per launch.  The reference's --kmer-batch-size default (10 M) exists "to control
+#                              memory usage" on the host; with 288 GB of HBM a launch takes a whole 100 Mbp record.  The
+#                              throughput at the reference's 10 M is measured in the same run (`reference_batch`).
+REFERENCE_BATCH = 10_000_000
+PMC_POSITIONS_PER_DISPATCH = 100_000_000     # launch size of the runs behind profiles/round1/pmc_*_summary.csv
 # BASELINE.json configs: name -> (search range, description); configs[1] = c2 is the bench workload,
 # the others are parity / capability cases that the same harness can run on request
 CONFIGS = {
@@ -61,6 +65,8 @@ def parse():
     ap.add_argument("--index-builder", choices=["host", "device"], default="host",
                     help="suffix sort on the host cores (default) or on the GPU (same index file; not timed in `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-batch", action="store_true",
+                    help="skip the extra passes at the reference's 10 M batch (profiling runs: one launch size per kernel)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--workdir", default=os.environ.get("NEWMAP_AMD_BENCH_DIR", "/tmp/newmap_amd_bench"))
     args = ap.parse_args()
@@ -101,7 +107,8 @@ def measured_traffic(kernel: str, config: str, positions_per_launch: float):
     gfx950 every read request of these kernels is a 128-byte one (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ
     within 3 %), which is the guide's "FETCH_SIZE reports half" correction stated exactly; writes:
     TCC_EA0_WRREQ x 64 B (WRITE_SIZE in KB for the older pair-kernel pass).
-    The counts are per 10 M-position launch of configs[1]; other workloads report null."""
+    The counts are per launch of the default bench run (configs[1], one launch of 100 M positions); other
+    workloads report null."""
     files = {"k_min_unique_quad": "pmc_quad_kernel_summary.csv", "k_min_unique_pair": "pmc_pair_kernel_summary.csv"}
     if config != "c2" or kernel not in files:
         return None, None
@@ -114,7 +121,7 @@ def measured_traffic(kernel: str, config: str, positions_per_launch: float):
         vals[k] = float(v)
     if "TCC_EA0_RDREQ_sum" not in vals:
         return None, None
-    scale = positions_per_launch / 10_000_000
+    scale = positions_per_launch / PMC_POSITIONS_PER_DISPATCH
     read_b = vals["TCC_EA0_RDREQ_sum"] * 128.0
     if "TCC_EA0_WRREQ_sum" in vals:
         write_b = vals["TCC_EA0_WRREQ_sum"] * 64.0
@@ -246,8 +253,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     seq_ptr, out_ptr, st_ptr = d_seq.data_ptr(), d_out.data_ptr(), d_status.data_ptr()
 
-    def step():
-        for (p, seg_len, nk) in segs:
+    def step(work=None):
+        for (p, seg_len, nk) in (segs if work is None else work):
             ix.min_unique_segment_dev(seq_ptr + p, seg_len, nk, KMIN, KMAX, True, 1, out_ptr + p, st_ptr, stream)
 
     def finish_steps():
@@ -271,6 +278,26 @@ def main():
     if rank == 0:
         log(f"[bench] {args.steps} steps in {elapsed:.3f}s; {n_launch} search launches, "
             f"{kern_ms:.2f} ms in the kernel (max {kern_max:.3f} ms)")
+    # the same passes cut into the reference's default batch (10 M positions per launch), for comparison
+    ref_batch = None
+    if args.batch > REFERENCE_BATCH and not args.no_reference_batch:
+        ref_units = parallel.units_for_slice(lengths, lo, hi, REFERENCE_BATCH, KMAX)
+        ref_segs = [(int(rec_off[u.record]) + u.start, u.seg_len, u.count) for u in ref_units]
+        step(ref_segs)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(ref_segs)
+        torch.cuda.synchronize()
+        barrier()
+        ref_elapsed = time.perf_counter() - t1
+        if world > 1:
+            tr = torch.tensor([ref_elapsed], dtype=torch.float64, device=torch.device("cpu") if rehearse else dev)
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            ref_elapsed = float(tr.item())
+        ref_batch = {"batch": REFERENCE_BATCH, "value": n * args.steps / ref_elapsed, "unit": "positions/s",
+                     "ms_per_step": ref_elapsed / args.steps * 1e3, "launches_per_step": len(ref_segs)}
     final_gather_ms = None
     if world > 1:
         cdev = torch.device("cpu") if rehearse else dev    # gloo gathers CPU tensors only
@@ -349,6 +376,8 @@ def main():
                               "seed_lookups_per_position": probe["seed_lookups"] / max(my_pos, 1)},
             "host": {"index_build_s": t_build, "index_open_s": t_open},
         }
+        if ref_batch is not None:
+            result["reference_batch"] = ref_batch
         if final_gather_ms is not None:
             result["final_gather_ms"] = final_gather_ms     # one RCCL gather of all slices to rank 0, outside `value`
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":      # the oracle's comparison-based

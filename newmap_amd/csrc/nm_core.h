@@ -401,7 +401,13 @@ NM_HD bool nm_quad_once_first(const nm_view &ix, const nm_window &w, uint32_t km
 template <bool BIG>
 NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64_t P, uint32_t kmax,
                                uint32_t stride, nm_tally &t) {
-    nm_window w = nm_load_window(enc, P);
+    nm_window w;
+    if (P & 63) {
+        w = nm_load_window(enc, P);
+    } else {                                              // probe positions are word-aligned: one 32-byte word, no shift
+        const nm_enc_word &e0 = enc[P >> 6];
+        w.lo = e0.lo; w.hi = e0.hi; w.amb = e0.amb;
+    }
     if (w.amb & 1ULL) return 0;
     const uint32_t cap = kmax + stride - 1;
     const uint32_t s = ix.seed_len;

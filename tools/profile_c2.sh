@@ -4,7 +4,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/prof_c2
 mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --steps 5 --warmup 1"
+B="python3 bench.py --no-cpu-baseline --no-reference-batch --steps 20 --warmup 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $B > $O/trace.json 2> $O/trace.log || echo "trace failed"
 timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $O/pmc1 -o p -- $B > $O/pmc1.json 2> $O/pmc1.log || echo "pmc1 failed"
 timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc2 -o p -- $B > $O/pmc2.json 2> $O/pmc2.log || echo "pmc2 failed"

@@ -1013,7 +1013,13 @@ static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m) 
     if (!level_table || m < 3 || m > 16 || ix->h.n < 2) return NM_OK;
     const uint64_t n_cores = 1ULL << (2 * m);
     double tq = nm_now();
-    HIP_TRY(hipMalloc(&ix->d_quad, n_cores * 32));
+    if (hipMalloc(&ix->d_quad, n_cores * 32) != hipSuccess) {     // (someone else holds the memory: go on without the table)
+        (void)hipGetLastError();
+        ix->d_quad = nullptr;
+        if (nm_verbose()) fprintf(stderr, "[open] quad table of %llu GB does not fit: range mode runs on the seed table\n",
+                                  (unsigned long long)(n_cores * 32 >> 30));
+        return NM_OK;
+    }
     NM_PHASE(tq, "quad table hipMalloc");
     ix->device_bytes += n_cores * 32;
     nm_view v = ix->view;

@@ -447,12 +447,19 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const 
 // Workgroup size (template argument QB): 256 lanes share one walk queue, so the walks of a stretch of repeated
 // positions (the last kmax positions of every repeat) spread over four waves instead of running as four passes
 // of one; 64 saves the barriers' waiting on unique input (2 % there, measured) -- NEWMAP_AMD_QUAD_BLOCK.
-template <bool BIG, bool STATS, int NM_QUAD_BLOCK, bool LONGK>
+// LIST: list mode with several lengths, all of them >= m + 3 (newmap/search.py:551-644).  kmin = the FIRST listed
+// length, kmax = the longest: a position whose (m+3)-mer occurs once is unique at every listed length, so its
+// element is the first one (if its bases are unambiguous); positions the probes settle as repeated over more than
+// kmax bases are 0; everything else -- repeated windows and lengths fixed by the probes -- goes through
+// nm_fixed_k_one in stage 2.  The caller keeps the positions whose longest k-mer leaves the data out of this kernel.
+template <bool BIG, bool STATS, int NM_QUAD_BLOCK, bool LONGK, bool LIST = false>
 __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, const nm_enc_word *__restrict__ enc,
                                                               uint64_t n_enc_words, uint64_t num_kmers,
                                                               uint32_t kmin, uint32_t kmax, void *__restrict__ out,
                                                               int elem_bytes, uint64_t *__restrict__ status,
-                                                              const uint32_t *__restrict__ probe) {
+                                                              const uint32_t *__restrict__ probe,
+                                                              uint64_t seq_len = 0, const uint32_t *__restrict__ list = nullptr,
+                                                              uint32_t n_list = 0) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_QUAD_BLOCK / NM_WAVE) + wave_in_block) * NM_QUAD_PER_WAVE;
@@ -546,13 +553,16 @@ __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, c
         const uint64_t p0 = wave_base + 256u * g + q;
         const uint32_t once = nm_quad_bits(win[g], m, e[g]);
         uint32_t r[4] = {0, 0, 0, 0};
-        const uint32_t hit = go[g] & once, walk = go[g] & ~once;
+        const uint32_t hit = go[g] & once;
+        uint32_t walk = go[g] & ~once;
         const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
             r[i] = ((hit >> i) & 1u) ? kmin : 0u;
             const uint32_t ks = nm_probe_kstar(pw[g][0], pw[g][1], off0 + i, NM_PROBE_STRIDE, kmax);
-            if (ks != NM_PROBE_OPEN) r[i] = nm_probe_element(ks, kmin, kmax, kmin_bases_valid(g, i));   // decided by the probes
+            if (ks == NM_PROBE_OPEN) continue;
+            if (!LIST) r[i] = nm_probe_element(ks, kmin, kmax, kmin_bases_valid(g, i));   // decided by the probes
+            else if (ks <= kmax && ((inb[g] >> i) & 1u)) walk |= 1u << i;                  // (list mode: stage 2 picks the length)
         }
         if (walk) {
             uint32_t at = atomicAdd(&q_n, (uint32_t)__builtin_popcount(walk));
@@ -574,7 +584,8 @@ __global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, c
     for (uint32_t i = threadIdx.x; i < n_walk; i += NM_QUAD_BLOCK) {
         const uint64_t p = q_p[i];
         bool amb0 = false, err = false;
-        const uint32_t v = nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
+        const uint32_t v = LIST ? nm_fixed_k_one<BIG, true>(ix, enc, p, seq_len, list, n_list, amb0, err, t)
+                                : nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
         if (err) { any_err = true; if (p < err_pos) err_pos = p; }
         nm_store(out, elem_bytes, p, v);
     }
@@ -1596,6 +1607,35 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
     return NM_OK;
 }
 
+// list mode with several lengths on the quad kernel (LIST instantiation): positions [0, head), whose longest k-mer
+// lies inside the data.  The caller has checked: quad table, every length >= its window, first length <= 124.
+template <bool BIG>
+static int launch_list_quad(nm_index *ix, const nm_view &view, uint64_t seq_len, uint64_t head, uint32_t k_first, uint32_t k_longest,
+                            const uint32_t *d_ks, uint32_t nk, void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st) {
+    const dim3 block(NM_BLOCK);
+    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    const uint32_t *settled = nullptr;
+    if (ix->repeat_probes) {
+        const uint64_t n_probes = (head + NM_PROBE_STRIDE - 1) / NM_PROBE_STRIDE;
+        const int rc = nm_grow(ix->settled, (n_probes + 1) * sizeof(uint32_t));
+        if (rc != NM_OK) return rc;
+        unsigned long long *tally = (unsigned long long *)ix->work.p + 1;
+        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, k_longest, (uint32_t *)ix->settled.p, tally);
+        else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, k_longest, (uint32_t *)ix->settled.p, tally);
+        settled = (const uint32_t *)ix->settled.p;
+    }
+    nm_timed timed(ix, st);
+    const uint64_t per_block = (uint64_t)(256 / NM_WAVE) * NM_QUAD_PER_WAVE;
+    const dim3 qgrid((unsigned)((head + per_block - 1) / per_block)), qblock(256);
+    ix->last_kernel = 5;
+#define NM_LAUNCH_LIST(STATS_, LONG_) hipLaunchKernelGGL((k_min_unique_quad<BIG, STATS_, 256, LONG_, true>), qgrid, qblock, 0, st, view, enc, ix->enc_words, \
+                                                          head, k_first, k_longest, d_out, elem_bytes, d_status, settled, seq_len, d_ks, nk)
+    if (ix->count_steps) { if (k_first > 60) NM_LAUNCH_LIST(true, true); else NM_LAUNCH_LIST(true, false); }
+    else                 { if (k_first > 60) NM_LAUNCH_LIST(false, true); else NM_LAUNCH_LIST(false, false); }
+#undef NM_LAUNCH_LIST
+    return NM_OK;
+}
+
 template <bool BIG, bool RC>
 static void launch_fixed_k(nm_index *ix, const nm_view &view, uint64_t seq_len, uint64_t first, uint64_t num_kmers, const uint32_t *d_ks, uint32_t nk,
                            void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st) {
@@ -1641,6 +1681,17 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
         if (head) {
             rc = ix->big ? launch_min_unique<true, true>(ix, view, head, ks[0], ks[0], d_out, elem_bytes, d_status, st)
                          : launch_min_unique<false, true>(ix, view, head, ks[0], ks[0], d_out, elem_bytes, d_status, st);
+            if (rc != NM_OK) return rc;
+            first = head;
+        }
+    }
+    // several lengths, all at least as long as the quad table's window: the LIST instantiation of the quad kernel
+    if (nk > 1 && use_revcomp && ix->list_via_range && view.quad && (ix->kernel_version == 0 || ix->kernel_version == 5) &&
+        kshort >= view.quad_m + NM_QUAD_EXT && ks[0] <= NM_QUAD_MAX_KMIN && seq_len >= kmax) {
+        const uint64_t head = num_kmers < seq_len - kmax + 1 ? num_kmers : seq_len - kmax + 1;
+        if (head) {
+            rc = ix->big ? launch_list_quad<true>(ix, view, seq_len, head, ks[0], kmax, d_ks, nk, d_out, elem_bytes, d_status, st)
+                         : launch_list_quad<false>(ix, view, seq_len, head, ks[0], kmax, d_ks, nk, d_out, elem_bytes, d_status, st);
             if (rc != NM_OK) return rc;
             first = head;
         }

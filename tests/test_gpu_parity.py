@@ -158,7 +158,8 @@ def test_batch_independence_and_segment_api(mixed_genome, eng):
 
 @pytest.mark.parametrize("ks,rc", [([36], True), ([100], True), ([12, 20, 30], True), ([30, 12], True),
                                    ([24], False), ([300, 20], True), ([15], True), ([14], True), ([60], True), ([61], True),
-                                   ([124], True), ([125], True), ([1000], True)])
+                                   ([124], True), ([125], True), ([1000], True), ([20, 36, 100], True), ([36, 20, 50], True),
+                                   ([100, 24], True), ([15, 16], True), ([124, 300], True)])
 def test_fixed_k_equals_oracle(mixed_genome, eng, ks, rc):
     g = mixed_genome
     kmax = max(ks)
@@ -175,7 +176,7 @@ def test_fixed_k_equals_oracle(mixed_genome, eng, ks, rc):
                     a, amb_a = ix.fixed_k_segment(seg.data, n, ks, rc)
                     got.append(a)
                     want.append(w)
-                    if len(ks) == 1 and rc:                # one length: the range kernels (default) vs the list kernel
+                    if rc:                                 # the range / quad kernels (default where they apply) vs the list kernel
                         ix.set_list_via_range(False)
                         b, amb_b = ix.fixed_k_segment(seg.data, n, ks, rc)
                         ix.set_list_via_range(True)

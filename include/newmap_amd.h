@@ -59,7 +59,7 @@ int nm_index_build(const char *fasta_path, const char *index_path, uint8_t sa_ra
 /* The same build with the suffix array computed on `device` (prefix doubling over rocPRIM radix sorts,
  * csrc/nm_build_device.hip); the index file is byte-identical to nm_index_build's.  Texts of 2^31
  * symbols or more (genomes beyond ~1.07 Gbp) take a bucketed 64-bit variant that also gathers the BWT
- * on the device (3.09 Gbp: 14 s instead of 146 s); if the device cannot hold it the host sorter runs. */
+ * on the device (3.09 Gbp: 10 s instead of 146 s); if the device cannot hold it the host sorter runs. */
 int nm_index_build_device(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len, int device);
 
 /* Read an index file and upload it to HBM of `device` (>= 0).  seed_len_override: -1 keeps the

@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include "../../include/newmap_amd.h"
@@ -75,11 +76,22 @@ struct FastaText {
         if (!len) return;
         if (!record_has_data) { record_has_data = true; n_records++; }
         raw_bases += len;
+        // a line yields at most one symbol per byte: write through a raw pointer, trim afterwards
+        const size_t old = f.size();
+        f.resize(old + len);
+        uint8_t *out = f.data() + old;
+        uint64_t cnt[4] = {0, 0, 0, 0};
+        bool run = in_run;
+        uint64_t runs = 0;
         for (size_t i = 0; i < len; i++) {
-            uint8_t c = g_lut.code[p[i]];
-            if (c != 0xFF) { f.push_back((uint8_t)(SYM_A + c)); base_count[c]++; in_run = true; }
-            else end_run();
+            const uint8_t c = g_lut.code[p[i]];
+            if (c != 0xFF) { *out++ = (uint8_t)(SYM_A + c); cnt[c]++; run = true; }
+            else if (run) { *out++ = SYM_SEP; runs++; run = false; }
         }
+        f.resize((size_t)(out - f.data()));
+        in_run = run;
+        n_runs += runs;
+        for (int c = 0; c < 4; c++) base_count[c] += cnt[c];
     }
     void header() { end_run(); record_has_data = false; }
     void line(const unsigned char *p, size_t len) {
@@ -94,6 +106,10 @@ int read_fasta(const char *path, FastaText &ft) {
     gzFile gz = gzopen(path, "rb");          // transparent for plain files
     if (!gz) { nm_set_error("Could not open fasta file to create index: %s", path); return NM_E_FILE_OPEN; }
     gzbuffer(gz, 1 << 20);
+    {   // room for the whole text at once (a plain FASTA is a little larger than its bases)
+        struct stat sb;
+        if (stat(path, &sb) == 0 && sb.st_size > 0 && gzdirect(gz)) ft.f.reserve((size_t)sb.st_size);
+    }
     std::vector<unsigned char> buf(1 << 22);
     std::vector<unsigned char> carry;
     for (;;) {
@@ -101,8 +117,10 @@ int read_fasta(const char *path, FastaText &ft) {
         if (got < 0) { gzclose(gz); nm_set_error("read error in %s", path); return NM_E_FILE_OPEN; }
         if (got == 0) break;
         size_t start = 0;
-        for (size_t i = 0; i < (size_t)got; i++) {
-            if (buf[i] != '\n') continue;
+        for (;;) {
+            const unsigned char *nl = (const unsigned char *)memchr(buf.data() + start, '\n', (size_t)got - start);
+            if (!nl) break;
+            const size_t i = (size_t)(nl - buf.data());
             if (!carry.empty()) {
                 carry.insert(carry.end(), buf.begin() + start, buf.begin() + i);
                 ft.line(carry.data(), carry.size());
@@ -126,13 +144,16 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
     const uint64_t nf = ft.f.size();
     const uint64_t n = 2 * nf + 1;
     // T = F . RC . '#'
-    std::vector<uint8_t> T(n);
+    nm::PdBuf<uint8_t> T(n);                                   // (uninitialised: every byte is written below)
     if (nf) {
-        memcpy(T.data(), ft.f.data(), nf);
-        // reverse F without its trailing separator, complement the bases, close with a separator
-        for (uint64_t i = 0; i + 1 < nf; i++) {
-            uint8_t c = ft.f[nf - 2 - i];
-            T[nf + i] = c >= SYM_A ? (uint8_t)(SYM_A + 3 - (c - SYM_A)) : c;
+        // F, then F reversed without its trailing separator with the bases complemented, closed by a separator
+#pragma omp parallel for schedule(static) num_threads(nm::pd_threads())
+        for (int64_t i = 0; i < (int64_t)nf; i++) {
+            T[(uint64_t)i] = ft.f[(uint64_t)i];
+            if ((uint64_t)i + 1 < nf) {
+                const uint8_t c = ft.f[nf - 2 - (uint64_t)i];
+                T[nf + (uint64_t)i] = c >= SYM_A ? (uint8_t)(SYM_A + 3 - (c - SYM_A)) : c;
+            }
         }
         T[2 * nf - 1] = SYM_SEP;
     }

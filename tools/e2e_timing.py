@@ -20,6 +20,8 @@ sys.path.insert(0, str(ROOT))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mbp", type=float, default=100.0)
+    ap.add_argument("--config", default="c2", help="bench genome: c2 (uniform, --mbp), c3 (3.09 Gbp in 24 records), c5")
+    ap.add_argument("--device-index", action="store_true", help="`newmap index --device 0` (suffix sort on the GPU)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     from newmap_amd import synth
@@ -27,31 +29,34 @@ def main():
     res = {"mbp": args.mbp}
     with tempfile.TemporaryDirectory() as td:
         td = Path(td)
-        recs = synth.config_genome("c2", args.mbp)
+        recs = synth.config_genome(args.config, args.mbp if args.config == "c2" else None)
+        (kmin, kmax) = {"c2": (20, 200), "c3": (24, 150), "c5": (20, 255)}[args.config]
         fa = synth.write_fasta(td / "genome.fa", recs)
         idx = td / "genome.awfmi"
         t0 = time.time()
-        subprocess.run([sys.executable, "-m", "newmap_amd.main", "index", str(fa), "-i", str(idx)], check=True, cwd=ROOT)
+        subprocess.run([sys.executable, "-m", "newmap_amd.main", "index"] + (["--device", "0"] if args.device_index else []) +
+                       [str(fa), "-i", str(idx)], check=True, cwd=ROOT)
         res["cli_index_s"] = time.time() - t0
         out = td / "out"
         t0 = time.time()
         subprocess.run([sys.executable, "-m", "newmap_amd.main", "search", str(fa), str(idx), "-o", str(out),
-                        "--search-range", "20:200"], check=True, cwd=ROOT)
+                        "--search-range", f"{kmin}:{kmax}"], check=True, cwd=ROOT)
         res["cli_search_s"] = time.time() - t0
         n = recs[0][1].size
-        res["cli_search_positions_per_s"] = n / res["cli_search_s"]
-        got = np.fromfile(out / "chr1.unique.uint8", dtype=np.uint8)
+        res["positions"] = int(sum(r.size for _, r in recs))
+        res["cli_search_positions_per_s"] = res["positions"] / res["cli_search_s"]
+        got = np.fromfile(out / f"{recs[0][0]}.unique.uint8", dtype=np.uint8)
         assert got.size == n
         # host-buffer API, PCIe included: 10 M positions per call like the CLI
         seq = recs[0][1]
         with Index(idx, 0) as ix:
-            ix.min_unique_segment(seq[:10_000_199], 10_000_000, 20, 200)          # warm-up
+            ix.min_unique_segment(seq[:10_000_000 + kmax - 1], 10_000_000, kmin, kmax)          # warm-up
             t0 = time.time()
             parts = []
             for p in range(0, n, 10_000_000):
                 nk = min(10_000_000, n - p)
-                seg = seq[p:min(p + nk + 199, n)]
-                parts.append(ix.min_unique_segment(seg, nk, 20, 200)[0])
+                seg = seq[p:min(p + nk + kmax - 1, n)]
+                parts.append(ix.min_unique_segment(seg, nk, kmin, kmax)[0])
             dt = time.time() - t0
         res["host_api_positions_per_s"] = n / dt
         res["host_api_equals_cli_files"] = bool(np.array_equal(np.concatenate(parts), got))

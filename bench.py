@@ -181,7 +181,16 @@ def cpu_baseline(args, genome: np.ndarray, gpu_out: np.ndarray, KMIN: int, KMAX:
         f"(oracle index {t_index:.1f}s); bit-exact vs GPU: {same}")
     if not same:
         raise SystemExit("GPU output differs from the CPU oracle on the baseline sample")
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": sample / dt, "unit": "positions/s", "cores": threads, "kind": "port",
+            "host": f"{cpu_model}, {os.cpu_count()} logical CPUs visible, oracle built -O3 -march=x86-64-v3 (AVX2, POPCNT), OpenMP",
             "sample": f"first {sample} positions of the same workload, {KMIN}:{KMAX}, "
                       f"{stats['probes'] / sample:.1f} probes and {2 * stats['probe_len'] / sample:.0f} LF steps "
                       "per position (reference schedule), index build excluded"}

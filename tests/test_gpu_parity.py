@@ -700,3 +700,15 @@ def test_cli_end_to_end(tmp_path):
     # list mode and a fixed k through the CLI
     cli("search", "--search-range=4,6,10", "-o", "lin", str(golden / "genome.fa"), "genome.awfmi")
     assert (tmp_path / "lin" / "chr1.unique.uint8").stat().st_size == 20
+
+
+def test_randomised_soak_fast_paths_against_plain_kernels(monkeypatch):
+    """tools/fuzz_gpu.py, a few rounds: quad table + repeat probes + list-mode routing against the plain
+    one-lane-per-position kernels on random genomes with tandem arrays, copies on both strands, ambiguity runs and
+    soft-masked stretches, cut at random batch sizes (the long runs are recorded in DESIGN.md)."""
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "tools"))
+    import fuzz_gpu
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu.py", "--rounds", "6", "--seed", "77"])
+    fuzz_gpu.main()

@@ -1,0 +1,101 @@
+"""Randomised A/B soak on the GPU: the default range path (quad table + repeat probes, list modes routed through
+it) against the plain one-lane-per-position kernels without probes, on genomes with tandem arrays, dispersed and
+reverse-complement copies, N runs and soft-masked stretches, cut into segments at random batch sizes.
+
+    python tools/fuzz_gpu.py [--rounds 40] [--seed 1]
+"""
+import argparse
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+ALPHA = np.frombuffer(b"ACGT", np.uint8)
+COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+
+
+def genome(rng):
+    recs = []
+    for r in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(2_000, 400_000))
+        s = bytearray(bytes(ALPHA[rng.integers(0, 4, n)]))
+        for _ in range(int(rng.integers(0, 12))):
+            kind = int(rng.integers(0, 5))
+            a = int(rng.integers(0, n))
+            m = int(min(n - a, rng.integers(1, 30_000)))
+            if m <= 0:
+                continue
+            if kind == 0:                                   # tandem array
+                unit = bytes(ALPHA[rng.integers(0, 4, int(rng.integers(1, 300)))])
+                s[a:a + m] = (unit * (m // len(unit) + 1))[:m]
+            elif kind == 1:                                 # dispersed copy
+                b = int(rng.integers(0, n - m + 1))
+                s[a:a + m] = s[b:b + m]
+            elif kind == 2:                                 # reverse-complement copy
+                b = int(rng.integers(0, n - m + 1))
+                s[a:a + m] = bytes(s[b:b + m]).translate(COMP)[::-1]
+            elif kind == 3:                                 # ambiguous run
+                m = int(min(m, rng.integers(1, 300)))
+                s[a:a + m] = bytes(rng.choice(np.frombuffer(b"NnRYKMSWBDHV", np.uint8), m))
+            else:                                           # soft-masked stretch
+                s[a:a + m] = bytes(s[a:a + m]).lower()
+        recs.append((f"r{r}".encode(), bytes(s)))
+    if len(recs) > 1 and rng.random() < 0.5:                # a copy across records
+        src = recs[0][1]
+        m = min(len(src), 5000)
+        recs[-1] = (recs[-1][0], recs[-1][1] + src[:m])
+    return recs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    from newmap_amd._c_newmap_generate_index import generate_fm_index
+    from newmap_amd.engine import Index
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    checks = 0
+    with tempfile.TemporaryDirectory() as td:
+        for rnd in range(a.rounds):
+            recs = genome(rng)
+            fa, idx = Path(td) / "g.fa", Path(td) / "g.awfmi"
+            fa.write_bytes(b"".join(b">" + rid + b"\n" + data + b"\n" for rid, data in recs))
+            generate_fm_index(str(fa), str(idx), 8, 12, device=0 if rng.random() < 0.5 else None)
+            mode = "auto" if rng.random() < 0.7 else "auto-small"
+            with Index(idx, 0, mode) as fast, Index(idx, 0, mode) as plain:
+                plain.set_kernel(1)
+                plain.set_repeat_probes(False)
+                plain.set_list_via_range(False)
+                w = fast.info()["quad_core_length"] + 3
+                for _ in range(6):
+                    kmin = int(rng.choice([w, w + 1, 20, 24, 36, 60, 61, 100, 124, int(rng.integers(1, 200))]))
+                    kmax = int(kmin + rng.choice([0, 1, 5, 40, 130, 231, int(rng.integers(0, 3000))]))
+                    batch = int(rng.choice([1 << 30, 10_007, 65_536, int(rng.integers(500, 200_000))]))
+                    lists = [[kmin], [kmin, kmax], sorted({kmin, (kmin + kmax) // 2, kmax}), [kmax, kmin]]
+                    ks = lists[int(rng.integers(0, len(lists)))]
+                    for rid, data in recs:
+                        n = len(data)
+                        for p in range(0, n, batch):
+                            cnt = min(batch, n - p)
+                            seg = data[p:min(p + cnt + kmax - 1, n)]
+                            x, ax = fast.min_unique_segment(seg, cnt, kmin, kmax)
+                            y, ay = plain.min_unique_segment(seg, cnt, kmin, kmax)
+                            assert ax == ay and np.array_equal(x, y), ("range", rnd, rid, kmin, kmax, batch, p, mode)
+                            x, ax = fast.fixed_k_segment(seg, cnt, ks)
+                            y, ay = plain.fixed_k_segment(seg, cnt, ks)
+                            assert ax == ay and np.array_equal(x, y), ("list", rnd, rid, ks, batch, p, mode)
+                            checks += 2
+            if rnd % 5 == 4:
+                print(f"[fuzz] round {rnd + 1}/{a.rounds}: {checks} segment comparisons identical, {time.time() - t0:.0f}s", flush=True)
+    print(f"fuzz ok: {checks} segment comparisons identical in {time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,27 @@ NM_HD uint32_t nm_base_code(uint32_t byte) {
     return is_base ? code : 4u;
 }
 
+// Four sequence bytes at once (little-endian word: byte 0 is the first base): the 4-bit groups of the lo plane, the
+// hi plane and the ambiguity plane.  Bit-sliced over the word -- bit K of every byte is brought to bit 7 of its byte
+// by one shift (what spills into the neighbouring byte never reaches its bit 7), the letter test of nm_base_code
+// becomes a dozen word-wide logic ops, and two shift-ors gather bits 7, 15, 23, 31 into the top nibble.
+NM_HD void nm_base_codes4(uint32_t x, uint32_t &lo, uint32_t &hi, uint32_t &amb) {
+    const uint32_t b0 = x << 7, b1 = x << 6, b2 = x << 5, b3 = x << 4, b4 = x << 3, b6 = x << 1, b7 = x;
+    // with bit 5 ignored the letters are 010x0001 (A), 010x0011 (C), 010x0111 (G), 010x0100 with bit 4 set (T)
+    const uint32_t frame = b6 & ~(b7 | b3);                        // bit 7 clear, bit 6 set, bit 3 clear
+    const uint32_t acg = ~b4 & b0 & (b1 | ~b2);                    // bit 4 clear: ...001, ...011, ...111
+    const uint32_t t = b4 & b2 & ~(b1 | b0);                       // bit 4 set:   ...100
+    const uint32_t valid = frame & (acg | t) & 0x80808080u;
+    auto top_nibble = [](uint32_t m) -> uint32_t {                // bits 7, 15, 23, 31 -> bits 0 .. 3
+        m |= m << 7;                                              // 23 -> 30, 15 -> 22, 7 -> 14
+        m |= m << 14;                                             // 15 -> 29, 14 -> 28
+        return m >> 28;
+    };
+    lo = top_nibble((b1 ^ b2) & valid);                            // code bit 0 = bit 1 ^ bit 2, code bit 1 = bit 2
+    hi = top_nibble(b2 & valid);
+    amb = top_nibble(valid ^ 0x80808080u);
+}
+
 NM_HD uint32_t nm_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
 
 // number of separator positions s with a <= s < b (b - a <= 64); only reached for the rare

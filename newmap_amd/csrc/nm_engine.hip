@@ -94,13 +94,14 @@ __global__ __launch_bounds__(NM_BLOCK) void k_encode16(const uint8_t *__restrict
         valid = base < seq_len ? (uint32_t)(seq_len - base) : 0;
         for (uint32_t j = 0; j < valid; j++) b[j >> 2] |= (uint32_t)seq[base + j] << (8 * (j & 3));
     }
-    uint32_t lo = 0, hi = 0, amb = 0;
+    uint32_t lo = 0, hi = 0, amb = 0;                    // bytes past the end of the data are 0 in b[]: ambiguous
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) {
-        const uint32_t code = j < valid ? nm_base_code((b[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 4u;
-        lo |= ((code & 1u) & (code < 4)) << j;
-        hi |= (((code >> 1) & 1u) & (code < 4)) << j;
-        amb |= (uint32_t)(code > 3) << j;
+    for (uint32_t j = 0; j < 4; j++) {
+        uint32_t l4, h4, a4;
+        nm_base_codes4(b[j], l4, h4, a4);
+        lo |= l4 << (4 * j);
+        hi |= h4 << (4 * j);
+        amb |= a4 << (4 * j);
     }
     const uint32_t sub = threadIdx.x & 3;
     uint64_t wlo = (uint64_t)lo << (16 * sub), whi = (uint64_t)hi << (16 * sub), wamb = (uint64_t)amb << (16 * sub);

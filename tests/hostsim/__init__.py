@@ -34,6 +34,8 @@ def lib():
     L.hs_check_rank2.argtypes = [vp, u64]
     L.hs_check_levels.restype = u64
     L.hs_check_levels.argtypes = [vp, u32]
+    L.hs_check_codes4.restype = u64
+    L.hs_check_codes4.argtypes = [u64]
     L.hs_check_quad.restype = u64
     L.hs_check_quad.argtypes = [vp]
     L.hs_check_pair.restype = u64
@@ -134,6 +136,11 @@ class HostSim:
         out = np.zeros(max(num_kmers, 1), dtype=np.uint32)
         lib().hs_upper(buf.ctypes.data, buf.size, num_kmers, kmax, out.ctypes.data)
         return out[:num_kmers]
+
+
+def check_codes4(rounds=200):
+    """nm_base_codes4 against nm_base_code; returns the number of disagreements"""
+    return int(lib().hs_check_codes4(rounds))
 
 
 def multi(sims, seqs, num_kmers, kmin, kmax, ks=None, use_rc=True, dtype=np.uint8):

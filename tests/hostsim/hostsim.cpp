@@ -274,6 +274,27 @@ int hs_min_unique(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t n
     return status[1] ? 8 : 0;
 }
 
+// nm_base_codes4 (the encode kernel's word-wide classification) against nm_base_code on every byte value in every
+// byte position with pseudo-random neighbours; returns the number of disagreements
+uint64_t hs_check_codes4(uint64_t rounds) {
+    uint64_t bad = 0, state = 0x9E3779B97F4A7C15ULL;
+    for (uint64_t r = 0; r < rounds; r++)
+        for (uint32_t pos = 0; pos < 4; pos++)
+            for (uint32_t v = 0; v < 256; v++) {
+                state = state * 6364136223846793005ULL + 1442695040888963407ULL;
+                uint32_t x = (uint32_t)(state >> 32);
+                x = (x & ~(0xFFu << (8 * pos))) | (v << (8 * pos));
+                uint32_t lo, hi, amb;
+                nm_base_codes4(x, lo, hi, amb);
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint32_t c = nm_base_code((x >> (8 * i)) & 0xFFu);
+                    const uint32_t wl = c < 4 ? (c & 1u) : 0u, wh = c < 4 ? (c >> 1) : 0u, wa = c > 3;
+                    if (((lo >> i) & 1u) != wl || ((hi >> i) & 1u) != wh || ((amb >> i) & 1u) != wa) bad++;
+                }
+            }
+    return bad;
+}
+
 // the repeat probes of one segment (k_repeat_probe): the probe word of every stride, and what the consumers
 // make of them: decided[p] = the element nm_probe_kstar / nm_probe_element give position p, 0xFFFFFFFF where the
 // probes leave it open.  Returns the LF steps spent.

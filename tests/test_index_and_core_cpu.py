@@ -328,3 +328,10 @@ def test_quad_table_bits_equal_direct_counts(tmp_path, m, force_big):
         words, decided, _ = sim.repeat_probes(rec, len(rec), kmin, kmax, 16)
         closed = decided != 0xFFFFFFFF
         assert closed.any() and np.array_equal(decided[closed].astype(np.int64), want[closed])
+
+
+def test_word_wide_base_classification_equals_the_bytewise_one():
+    """nm_base_codes4 (k_encode16 classifies four sequence bytes per word-wide op) == nm_base_code on every byte
+    value in every position of the word, with varying neighbours"""
+    from tests.hostsim import check_codes4
+    assert check_codes4(300) == 0

@@ -419,9 +419,12 @@ NM_HD bool nm_quad_once_first(const nm_view &ix, const nm_window &w, uint32_t km
     return ((ix.quad[slot * 4] >> i0) & 1ULL) != 0;
 }
 
+// (settled <= stride and exact are returned separately: the coarse probes use strides that do not fit the word)
 template <bool BIG>
-NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64_t P, uint32_t kmax,
-                               uint32_t stride, nm_tally &t) {
+NM_HD void nm_repeat_probe_ex(const nm_view &ix, const nm_enc_word *enc, uint64_t P, uint32_t kmax,
+                              uint32_t stride, nm_tally &t, uint32_t &settled, uint32_t &exact) {
+    settled = 0;
+    exact = 0;
     nm_window w;
     if (P & 63) {
         w = nm_load_window(enc, P);
@@ -429,29 +432,30 @@ NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64
         const nm_enc_word &e0 = enc[P >> 6];
         w.lo = e0.lo; w.hi = e0.hi; w.amb = e0.amb;
     }
-    if (w.amb & 1ULL) return 0;
+    if (w.amb & 1ULL) return;
     const uint32_t cap = kmax + stride - 1;
     const uint32_t s = ix.seed_len;
     uint64_t lo = 0, hi = ix.n;
     uint32_t k = 0, kbase = 0;
-    if (ix.quad && nm_quad_once_first(ix, w, kmax)) return 0;   // unique within the quad table's window: nothing to tell
+    if (ix.quad && nm_quad_once_first(ix, w, kmax)) return;     // unique within the quad table's window: nothing to tell
     if (ix.seed && s && s <= kmax && (w.amb & ((1ULL << s) - 1ULL)) == 0) {
         t.seeds++;
         if (nm_seed_decode(NM_SEED_LOAD(ix, nm_seed_slot(w, s)), lo, hi)) {
-            if (hi - lo <= 1) return 0;                   // unique (or absent) within the seed: nothing to tell
+            if (hi - lo <= 1) return;                     // unique (or absent) within the seed: nothing to tell
             k = s;
         } else { lo = 0; hi = ix.n; }
     }
-    uint32_t first_unique, exact = 0, settled;            // first_unique: a lower bound of the least unique length at P
+    uint32_t first_unique;                                // a lower bound of the least unique length at P
     for (;;) {
         const uint64_t cnt = hi - lo;
-        if (cnt == 0) return 0;                           // absent k-mer: the ordinary path reports it
+        if (cnt == 0) return;                             // absent k-mer: the ordinary path reports it
         if (cnt == 1) { first_unique = exact = k; break; }   // every shorter prefix occurs twice
         if (k >= cap) { first_unique = cap + 1; break; }
         uint32_t j = k - kbase;
         if (j >= 64) { w = nm_load_window(enc, P + k); kbase = k; j = 0; }
         if ((w.amb >> j) & 1ULL) {                        // S[P .. P+k) occurs twice and ends the run: all of it is 0
-            return k < stride ? k : stride;
+            settled = k < stride ? k : stride;
+            return;
         }
         const uint32_t c = 3u - nm_window_code(w, j);
         t.steps++;
@@ -462,7 +466,22 @@ NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64
     settled = first_unique > kmax ? first_unique - kmax : 0u;            // q - P < first_unique - kmax
     if (settled > stride) settled = stride;
     if (exact >= (1u << 24)) exact = 0;
-    return settled | (exact << 8);
+}
+
+template <bool BIG>
+NM_HD uint32_t nm_repeat_probe(const nm_view &ix, const nm_enc_word *enc, uint64_t P, uint32_t kmax,
+                               uint32_t stride, nm_tally &t) {
+    uint32_t settled, exact;
+    nm_repeat_probe_ex<BIG>(ix, enc, P, kmax, stride, t, settled, exact);
+    return settled | (exact << 8);                         // stride <= 255
+}
+
+// Coarse probes: one walk per NM_COARSE_STRIDE positions, to at most kmax + NM_COARSE_STRIDE - 1 bases.  Deep inside
+// a long repeat the eight fine probes of those positions would each walk kmax + 63 steps over nearly the same text;
+// when the coarse probe settles a fine stride completely, its probe word is known (all 64 positions 0) without a walk.
+#define NM_COARSE_STRIDE 512u
+NM_HD bool nm_coarse_covers(uint32_t coarse_settled, uint32_t offset_in_coarse, uint32_t fine_stride) {
+    return coarse_settled >= offset_in_coarse + fine_stride;
 }
 
 // What the probe words of a position's stride (wj) and of the next stride (wj1) say about the position at

@@ -166,17 +166,55 @@ __device__ __forceinline__ void nm_store(void *out, int elem_bytes, uint64_t p, 
 // a wave probe neighbouring strides, so inside a long repeat they walk in step.  probe[n_probes] = 0 (the
 // consumers read strides j and j+1).  probe_tally (counter builds): LF steps, blocks, seed entries, settled.
 #define NM_PROBE_STRIDE 64u
+// coarse[c] = positions from c * NM_COARSE_STRIDE on that one walk of <= kmax + NM_COARSE_STRIDE - 1 bases settles as 0
+template <bool BIG, bool STATS>
+__global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe_coarse(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_coarse,
+                                                                  uint32_t kmax, uint32_t *__restrict__ coarse,
+                                                                  unsigned long long *__restrict__ probe_tally) {
+    const uint64_t c = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    nm_tally t = {0, 0, 0, 0};
+    if (c < n_coarse) {
+        uint32_t settled, exact;
+        nm_repeat_probe_ex<BIG>(ix, enc, c * NM_COARSE_STRIDE, kmax, NM_COARSE_STRIDE, t, settled, exact);
+        coarse[c] = settled;
+    }
+    if (STATS) {
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), d = wave_sum(t.seeds);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&probe_tally[0], (unsigned long long)a);
+            atomicAdd(&probe_tally[1], (unsigned long long)b);
+            atomicAdd(&probe_tally[2], (unsigned long long)d);
+        }
+    }
+}
+
 template <bool BIG, bool STATS>
 __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_probes,
                                                            uint32_t kmax, uint32_t *__restrict__ probe,
-                                                           unsigned long long *__restrict__ probe_tally) {
+                                                           unsigned long long *__restrict__ probe_tally,
+                                                           const uint32_t *__restrict__ coarse, volatile uint32_t *repeats_seen,
+                                                           uint32_t *__restrict__ seen_latch) {
     const uint64_t j = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     nm_tally t = {0, 0, 0, 0};
     uint32_t c = 0;
     if (j <= n_probes) {
-        const uint32_t word = j < n_probes ? nm_repeat_probe<BIG>(ix, enc, j * NM_PROBE_STRIDE, kmax, NM_PROBE_STRIDE, t) : 0u;
+        uint32_t word = 0;
+        if (j < n_probes) {
+            const uint64_t P = j * NM_PROBE_STRIDE;
+            // a stride the coarse probe settles completely: the word this probe would find after kmax + 63 steps
+            if (coarse && nm_coarse_covers(coarse[P / NM_COARSE_STRIDE], (uint32_t)(P % NM_COARSE_STRIDE), NM_PROBE_STRIDE)) word = NM_PROBE_STRIDE;
+            else word = nm_repeat_probe<BIG>(ix, enc, P, kmax, NM_PROBE_STRIDE, t);
+        }
         probe[j] = word;
         c = word & 0xFFu;
+    }
+    // tell the host (a word of pinned, device-visible memory, read without synchronisation before later launches)
+    // that this input has stretches repeated over more than kmax bases: the coarse probes then pay off
+    // (once per handle: a latch in device memory keeps later blocks from writing across PCIe again)
+    // (wave by wave -- a block barrier here would hold finished waves' slots until the longest walk of the block ends)
+    if (repeats_seen && __ballot(c == NM_PROBE_STRIDE) && (threadIdx.x & 63) == 0 && *seen_latch == 0u) {
+        *seen_latch = 1u;
+        *repeats_seen = 1u;
     }
     if (STATS) {
         const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), d = wave_sum(t.seeds), e = wave_sum(c);
@@ -944,7 +982,12 @@ struct nm_index {
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
-    nm_buffer enc, seq, out, status, ks, starts, lens, work, settled;
+    nm_buffer enc, seq, out, status, ks, starts, lens, work, settled, coarse;
+    uint64_t coarse_min = 32ull << 20;    // launches of at least this many positions also run the coarse probes (NEWMAP_AMD_COARSE_MIN) ...
+    int coarse_mode = 1;                  // ... 1: once an earlier launch has met long repeats, 2: always, 0: never (NEWMAP_AMD_COARSE)
+    uint32_t *h_repeats_seen = nullptr;   // pinned word the fine probes set; d_repeats_seen = its device address
+    uint32_t *d_repeats_seen = nullptr;
+    uint32_t *d_seen_latch = nullptr;     // device-side copy of the flag
     bool list_via_range = true;           // list mode with one length runs on the range kernels (NM_OPT_LIST_VIA_RANGE, A/B)
     int quad_block = 256;                 // workgroup size of k_min_unique_quad (64 or 256, NEWMAP_AMD_QUAD_BLOCK)
     bool repeat_probes = true;            // k_repeat_probe before the both-strand range kernels (NM_OPT_REPEAT_PROBES)
@@ -1345,6 +1388,19 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     const bool have_quad = ix->view.quad != nullptr;
     if (const char *qb = getenv("NEWMAP_AMD_QUAD_BLOCK")) ix->quad_block = atoi(qb) == 64 ? 64 : 256;
+    if (const char *cm = getenv("NEWMAP_AMD_COARSE_MIN")) ix->coarse_min = strtoull(cm, nullptr, 10);
+    if (const char *cm = getenv("NEWMAP_AMD_COARSE")) ix->coarse_mode = atoi(cm);
+    if (hipHostMalloc((void **)&ix->h_repeats_seen, 64, hipHostMallocMapped) == hipSuccess) {
+        *ix->h_repeats_seen = 0;
+        if (hipHostGetDevicePointer((void **)&ix->d_repeats_seen, ix->h_repeats_seen, 0) != hipSuccess ||
+            hipMalloc((void **)&ix->d_seen_latch, 64) != hipSuccess || hipMemset(ix->d_seen_latch, 0, 64) != hipSuccess) {
+            (void)hipGetLastError();
+            ix->d_repeats_seen = nullptr;
+        }
+    } else {
+        (void)hipGetLastError();
+        ix->h_repeats_seen = nullptr;
+    }
     const char *force_pair = getenv("NEWMAP_AMD_PAIR");
     if (seed_len_override < -1 && s >= 5 && (!have_quad || (force_pair && force_pair[0] == '1'))) {
         // without a quad table: the pair table (cores of s-1 bases, same resolution as the
@@ -1382,9 +1438,11 @@ extern "C" void nm_index_close(nm_index *ix) {
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_quad, ix->d_rank2, ix->d_super2, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
-                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p, ix->settled.p};
+                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p, ix->settled.p, ix->coarse.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (ix->h_repeats_seen) (void)hipHostFree(ix->h_repeats_seen);
+    if (ix->d_seen_latch) (void)hipFree(ix->d_seen_latch);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
@@ -1512,6 +1570,30 @@ static int nm_check_segment_args(const nm_index *ix, uint64_t seq_len, uint64_t 
     return NM_OK;
 }
 
+// the repeat probes of a launch over `n` positions: (coarse probes for large launches,) fine probes -> ix->settled
+template <bool BIG>
+static int nm_launch_probes(nm_index *ix, const nm_view &view, uint64_t n, uint32_t kmax, hipStream_t st, const uint32_t **words) {
+    const dim3 block(NM_BLOCK);
+    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    const uint64_t n_probes = (n + NM_PROBE_STRIDE - 1) / NM_PROBE_STRIDE;
+    int rc = nm_grow(ix->settled, (n_probes + 1) * sizeof(uint32_t));
+    if (rc != NM_OK) return rc;
+    unsigned long long *tally = (unsigned long long *)ix->work.p + 1;
+    const uint32_t *coarse = nullptr;
+    const bool repeats_met = ix->h_repeats_seen && *(volatile uint32_t *)ix->h_repeats_seen != 0;
+    if (n >= ix->coarse_min && (ix->coarse_mode == 2 || (ix->coarse_mode == 1 && repeats_met))) {
+        const uint64_t n_coarse = (n + NM_COARSE_STRIDE - 1) / NM_COARSE_STRIDE;
+        if ((rc = nm_grow(ix->coarse, n_coarse * sizeof(uint32_t))) != NM_OK) return rc;
+        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally);
+        else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally);
+        coarse = (const uint32_t *)ix->coarse.p;
+    }
+    if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch);
+    else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch);
+    *words = (const uint32_t *)ix->settled.p;
+    return NM_OK;
+}
+
 template <bool BIG, bool RC>
 static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, void *d_out,
                               int elem_bytes, uint64_t *d_status, hipStream_t st) {
@@ -1523,13 +1605,8 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kme
     // repeat probes feed the kernels that take the probe words: the quad and pair kernels and k_min_unique
     const uint32_t *settled = nullptr;
     if (RC && ix->repeat_probes && ix->kernel_version != 2 && ix->kernel_version != 3) {   // (versions 4 and 5 fall back to 1 without their table)
-        const uint64_t n_probes = (num_kmers + NM_PROBE_STRIDE - 1) / NM_PROBE_STRIDE;
-        const int rc = nm_grow(ix->settled, (n_probes + 1) * sizeof(uint32_t));
+        const int rc = nm_launch_probes<BIG>(ix, view, num_kmers, kmax, st, &settled);
         if (rc != NM_OK) return rc;
-        unsigned long long *tally = (unsigned long long *)ix->work.p + 1;
-        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally);
-        else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally);
-        settled = (const uint32_t *)ix->settled.p;
     }
     nm_timed timed(ix, st);
     if (RC && ix->kernel_version == 2) {
@@ -1613,17 +1690,11 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
 template <bool BIG>
 static int launch_list_quad(nm_index *ix, const nm_view &view, uint64_t seq_len, uint64_t head, uint32_t k_first, uint32_t k_longest,
                             const uint32_t *d_ks, uint32_t nk, void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st) {
-    const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
     const uint32_t *settled = nullptr;
     if (ix->repeat_probes) {
-        const uint64_t n_probes = (head + NM_PROBE_STRIDE - 1) / NM_PROBE_STRIDE;
-        const int rc = nm_grow(ix->settled, (n_probes + 1) * sizeof(uint32_t));
+        const int rc = nm_launch_probes<BIG>(ix, view, head, k_longest, st, &settled);
         if (rc != NM_OK) return rc;
-        unsigned long long *tally = (unsigned long long *)ix->work.p + 1;
-        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, k_longest, (uint32_t *)ix->settled.p, tally);
-        else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, k_longest, (uint32_t *)ix->settled.p, tally);
-        settled = (const uint32_t *)ix->settled.p;
     }
     nm_timed timed(ix, st);
     const uint64_t per_block = (uint64_t)(256 / NM_WAVE) * NM_QUAD_PER_WAVE;

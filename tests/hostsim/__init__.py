@@ -45,7 +45,7 @@ def lib():
     L.hs_min_unique.restype = i32
     L.hs_min_unique.argtypes = [vp, vp, u64, u64, u32, u32, i32, i32, vp, vp]
     L.hs_repeat_probes.restype = u64
-    L.hs_repeat_probes.argtypes = [vp, vp, u64, u64, u32, u32, u32, vp, vp]
+    L.hs_repeat_probes.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, vp, vp]
     L.hs_fixed_k.restype = i32
     L.hs_fixed_k.argtypes = [vp, vp, u64, u64, vp, u32, i32, i32, vp, vp]
     L.hs_count.argtypes = [vp, vp, vp, vp, u64, vp]
@@ -102,14 +102,14 @@ class HostSim:
                                   out.dtype.itemsize, out.ctypes.data, status.ctypes.data)
         return out[:num_kmers], status, rc
 
-    def repeat_probes(self, seq: bytes, num_kmers, kmin, kmax, stride=64):
+    def repeat_probes(self, seq: bytes, num_kmers, kmin, kmax, stride=64, coarse_stride=0):
         """probe word of every stride (newmap_amd/csrc/nm_core.h: nm_repeat_probe), the element the probes decide
         for every position (0xFFFFFFFF = left open), and the LF steps spent."""
         buf = np.frombuffer(seq, dtype=np.uint8)
         n_probes = (num_kmers + stride - 1) // stride
         words = np.zeros(n_probes + 1, dtype=np.uint32)
         decided = np.zeros(max(num_kmers, 1), dtype=np.uint32)
-        steps = self.L.hs_repeat_probes(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, stride,
+        steps = self.L.hs_repeat_probes(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, stride, coarse_stride,
                                         words.ctypes.data, decided.ctypes.data)
         return words[:n_probes], decided[:num_kmers], int(steps)
 

@@ -299,15 +299,31 @@ uint64_t hs_check_codes4(uint64_t rounds) {
 // make of them: decided[p] = the element nm_probe_kstar / nm_probe_element give position p, 0xFFFFFFFF where the
 // probes leave it open.  Returns the LF steps spent.
 uint64_t hs_repeat_probes(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin,
-                          uint32_t kmax, uint32_t stride, uint32_t *words, uint32_t *decided) {
+                          uint32_t kmax, uint32_t stride, uint32_t coarse_stride, uint32_t *words, uint32_t *decided) {
     std::vector<nm_enc_word> enc;
     hs_encode(seq, seq_len, enc);
     uint64_t steps = 0;
     const uint64_t n_probes = (num_kmers + stride - 1) / stride;
+    // coarse probes first (k_repeat_probe_coarse; coarse_stride 0 = none): strides they settle completely get their
+    // word without a walk (k_repeat_probe)
+    std::vector<uint32_t> coarse;
+    if (coarse_stride) {
+        coarse.resize((num_kmers + coarse_stride - 1) / coarse_stride);
+        for (uint64_t c = 0; c < coarse.size(); c++) {
+            nm_tally t = {0, 0, 0, 0};
+            uint32_t settled, exact;
+            if (ix->big) nm_repeat_probe_ex<true>(ix->v, enc.data(), c * coarse_stride, kmax, coarse_stride, t, settled, exact);
+            else nm_repeat_probe_ex<false>(ix->v, enc.data(), c * coarse_stride, kmax, coarse_stride, t, settled, exact);
+            coarse[c] = settled;
+            steps += t.steps;
+        }
+    }
     for (uint64_t j = 0; j < n_probes; j++) {
         nm_tally t = {0, 0, 0, 0};
-        words[j] = ix->big ? nm_repeat_probe<true>(ix->v, enc.data(), j * stride, kmax, stride, t)
-                           : nm_repeat_probe<false>(ix->v, enc.data(), j * stride, kmax, stride, t);
+        const uint64_t P = j * stride;
+        if (coarse_stride && nm_coarse_covers(coarse[P / coarse_stride], (uint32_t)(P % coarse_stride), stride)) { words[j] = stride; continue; }
+        words[j] = ix->big ? nm_repeat_probe<true>(ix->v, enc.data(), P, kmax, stride, t)
+                           : nm_repeat_probe<false>(ix->v, enc.data(), P, kmax, stride, t);
         steps += t.steps;
     }
     words[n_probes] = 0;

@@ -298,6 +298,16 @@ def test_repeat_probes_decide_only_what_the_oracle_confirms(tmp_path):
         # the reverse-complement copy is seen through the both-strand index
         words, decided, _ = sim.repeat_probes(r2, len(r2), 20, 200, 64)
         assert (decided[5100:5600] != 0xFFFFFFFF).sum() > 400
+        # coarse probes in front (one walk per 512 positions): still nothing the oracle contradicts, the array is
+        # settled as before, and the probes walk fewer steps in all
+        rec = bytes(r1)
+        want = rd.closed_form_min_unique(rec, oracle, 20, 60, True).astype(np.int64)
+        _, fine_only, steps_fine = sim.repeat_probes(rec, len(rec), 20, 60, 64)
+        _, with_coarse, steps_coarse = sim.repeat_probes(rec, len(rec), 20, 60, 64, coarse_stride=512)
+        closed = with_coarse != 0xFFFFFFFF
+        assert np.array_equal(with_coarse[closed].astype(np.int64), want[closed])
+        assert int((closed[3000:9000] & (want[3000:9000] == 0)).sum()) >= int(((fine_only != 0xFFFFFFFF)[3000:9000] & (want[3000:9000] == 0)).sum())
+        assert steps_coarse < steps_fine
 
 
 @pytest.mark.parametrize("m,force_big", [(4, False), (6, False), (5, True)])

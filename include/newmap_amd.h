@@ -66,8 +66,7 @@ int nm_index_build_device(const char *fasta_path, const char *index_path, uint8_
  * length recorded in the file (the reference's --seed-length, default 12), -2 = automatic
  * (ceil(log4 n) + 2 bases, at most 16 and at most a quarter of the free HBM: with 288 GB the table
  * can be long enough that most positions resolve in ONE lookup; automatic mode also builds the LF
- * blocks and the quad table -- or the pair table -- that the fast range kernels read, DESIGN.md
- * sec. 3-4), -3 = automatic with small tables (seed <= 15, quad cores <= 14, 17 GB at most: what a
+ * blocks and the quad table that the sites read), -3 = automatic with small tables (seed <= 15, quad cores <= 14, 17 GB at most: what a
  * one-shot run wants, the large ones cost 3 - 5 s of allocation), 0 disables the seed table, 1..16
  * forces a length.  Searches whose shortest length is below the table's get a second small
  * table of that length on first use.  Replaces createIndex()
@@ -77,8 +76,8 @@ void nm_index_close(nm_index *ix);
 
 /* index facts: 0 n (BWT length), 1 forward text length, 2 separators, 3 records, 4 raw bases,
  * 5 seed length in use, 6 device bytes held, 7 sa_ratio recorded, 8 range kernel used by the last
- * launch (see NM_OPT_KERNEL), 9 core length of the pair table (0 = none), 10 device index,
- * 11 LF blocks in use, 12 two-step rank blocks in use, 13 repeat probes enabled; of the last
+ * launch (see NM_OPT_KERNEL), 9 and 12 always 0 (structures of earlier versions), 10 device index,
+ * 11 LF blocks in use, 13 repeat probes enabled; of the last
  * range-mode launch's repeat probes (waits for the device; 14..16 need
  * NM_OPT_COUNT_STEPS): 14 LF steps, 15 rank blocks read, 16 seed entries read, 17 positions
  * settled without a search; 18 core length of the quad table (0 = none) */
@@ -141,28 +140,27 @@ int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, ui
 enum {
     NM_OPT_COUNT_STEPS = 1,
     NM_OPT_TIMING = 3,
-    NM_OPT_KERNEL = 4,             /* range-mode kernel: 0 automatic (default), 1 one lane per position,
-                                      2 persistent lanes, 3 several positions per lane, 4 position
-                                      pairs on the pair table (one 128-byte line per two positions),
-                                      5 position quads on the quad table (one line per four positions;
-                                      needs kmin >= its core length + 3) */
-    NM_OPT_PERSISTENT_BLOCKS = 5,  /* grid size of the persistent kernel (default 8 x CUs) */
+    NM_OPT_KERNEL = 4,             /* range-mode kernel: 0 automatic (default), 1 one lane per position (k_min_unique),
+                                      5 the sites (k_sites + k_resolve: one 128-byte quad-table line per group of
+                                      kmin - core length + 1 positions; needs core length + 3 <= kmin <= 252) */
     NM_OPT_FORCE_BIG = 6,          /* tests: use the kernels for indexes beyond 2^31 positions */
     NM_OPT_SEED_POLICY = 7,        /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */
-    NM_OPT_TWO_STEP = 8,           /* walks on the two-step rank blocks (built only with NEWMAP_AMD_TWO_STEP=1) */
     NM_OPT_LF_BLOCKS = 9,          /* LF steps on the 16-byte LF entries (default when built) or the packed rank blocks */
     NM_OPT_REPEAT_PROBES = 10,     /* both-strand range mode: one probe per 64 positions settles stretches that occur
                                       twice over more than kmax bases (default 1; 0 = every position searches for itself) */
     NM_OPT_LIST_VIA_RANGE = 11     /* list mode on both strands runs on the range kernels (one length: kmin = kmax = k;
-                                      several lengths >= the quad window: the quad kernel's list form); default 1,
-                                      0 = always the list kernel, for A/B */
+                                      several lengths >= the quad window: the sites + the list form of k_resolve);
+                                      default 1, 0 = always the list kernel, for A/B */
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 
-/* NM_OPT_TIMING = 1 brackets every search-kernel launch (k_min_unique / k_fixed_k, not the
- * encode pass) with HIP events recorded on the launch stream.  nm_timing_read waits for them,
- * returns their number, summed and longest duration in ms, and resets the record. */
+/* NM_OPT_TIMING = 1 records HIP events on the launch stream, two kinds of start/stop pairs per segment:
+ * kind 0 around the dominant search kernel alone (k_sites / k_min_unique / k_fixed_k -- the kernel the roofline
+ * figure is quoted for), kind 1 around ALL kernels of the segment (encode pass, sites, repeat probes, resolve).
+ * nm_timing_read_kind waits for the events of one kind, returns their number, summed and longest duration in
+ * ms, and resets that record; nm_timing_read = kind 0. */
 int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_ms, double *max_ms);
+int nm_timing_read_kind(nm_index *ix, int kind, uint64_t *n_launches, double *total_ms, double *max_ms);
 
 /* --------------------------------------------------------------- native search driver --------
  * The whole of newmap/search.py:197-380 `write_unique_counts` for one FASTA and one index in one

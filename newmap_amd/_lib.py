@@ -17,10 +17,8 @@ NM_STATUS_WORDS = 8
 NM_OPT_COUNT_STEPS = 1
 NM_OPT_TIMING = 3
 NM_OPT_KERNEL = 4
-NM_OPT_PERSISTENT_BLOCKS = 5
 NM_OPT_FORCE_BIG = 6
 NM_OPT_SEED_POLICY = 7
-NM_OPT_TWO_STEP = 8
 NM_OPT_LF_BLOCKS = 9
 NM_OPT_REPEAT_PROBES = 10
 NM_OPT_LIST_VIA_RANGE = 11
@@ -30,7 +28,7 @@ EXPORTS = [
     "nm_index_info", "nm_count_kmers", "nm_count_from_sequence", "nm_min_unique_segment",
     "nm_fixed_k_segment", "nm_upper_bound_segment", "nm_min_unique_segment_dev",
     "nm_fixed_k_segment_dev", "nm_set_option", "nm_dev_alloc", "nm_dev_free", "nm_dev_upload",
-    "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read", "nm_search_fasta", "nm_track_file", "nm_search_segment_multi", "nm_index_build_device",
+    "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read", "nm_timing_read_kind", "nm_search_fasta", "nm_track_file", "nm_search_segment_multi", "nm_index_build_device",
 ]
 
 _lib = None
@@ -143,6 +141,8 @@ def lib():
                                 c.POINTER(u64), c.POINTER(u64)]
     L.nm_timing_read.restype = i32
     L.nm_timing_read.argtypes = [vp, c.POINTER(u64), c.POINTER(c.c_double), c.POINTER(c.c_double)]
+    L.nm_timing_read_kind.restype = i32
+    L.nm_timing_read_kind.argtypes = [vp, i32, c.POINTER(u64), c.POINTER(c.c_double), c.POINTER(c.c_double)]
     _lib = L
     return L
 

@@ -48,11 +48,7 @@ struct nm_view {                // the index as the kernels see it
     uint32_t seed_len;
     uint32_t n_super;
     uint32_t seed_policy;       // experiment knob: cache policy of the seed-table load (0 = default)
-    uint32_t pair_m;            // core length of the pair table (0 = none)
-    const uint64_t *pair;       // 4^pair_m blocks of 8 entries: [a] interval of a.Y, [4+b] interval of Y.b
     const nm_lf_entry *lfb;     // LF blocks: one 16-byte load per LF step (nullptr = use the packed rank blocks)
-    const nm_rank2_block *rank2;   // two-step rank blocks (nullptr = not built)
-    const uint64_t *superC2;    // [n_super][16]: first row of the suffixes starting "y x" + pairs before the superblock
     const uint64_t *quad;       // quad table: 4^quad_m entries of 4 x u64 (nullptr = not built), see nm_quad_build_one
     uint32_t quad_m;            // its core length; it answers windows of quad_m + 3 bases
 };
@@ -199,24 +195,6 @@ NM_HD bool nm_bwt_code(const nm_view &ix, uint64_t i, uint32_t &code) {
     return true;
 }
 
-// one step and two steps from the same 128-byte block: out1 = LF_x(i), out2 = LF_y(LF_x(i))
-NM_HD void nm_lf12(const nm_view &ix, uint32_t x, uint32_t y, uint64_t i, uint64_t &out1, uint64_t &out2) {
-    const nm_rank2_block *b = ix.rank2 + (i >> 6);
-    const uint64_t low = (1ULL << (i & 63)) - 1ULL;
-    const uint64_t m1 = ((x & 1u) ? b->c1lo : ~b->c1lo) & ((x & 2u) ? b->c1hi : ~b->c1hi) & low;
-    const uint64_t m2 = ((y & 1u) ? b->c2lo : ~b->c2lo) & ((y & 2u) ? b->c2hi : ~b->c2hi);
-    const uint64_t sb = i >> NM_SUPER_SHIFT;
-    out1 = ix.superC[sb * 4 + x] + b->cnt1[x] + nm_popc64(b->valid1 & m1);
-    out2 = ix.superC2[sb * 16 + x * 4 + y] + b->cnt2[x * 4 + y] + nm_popc64(b->valid2 & m1 & m2);
-}
-
-NM_HD uint64_t nm_lf1_r2(const nm_view &ix, uint32_t x, uint64_t i) {
-    const nm_rank2_block *b = ix.rank2 + (i >> 6);
-    const uint64_t low = (1ULL << (i & 63)) - 1ULL;
-    const uint64_t m1 = ((x & 1u) ? b->c1lo : ~b->c1lo) & ((x & 2u) ? b->c1hi : ~b->c1hi) & low;
-    return ix.superC[(i >> NM_SUPER_SHIFT) * 4 + x] + b->cnt1[x] + nm_popc64(b->valid1 & m1);
-}
-
 struct nm_window { uint64_t lo, hi, amb; };      // sequence positions [pos, pos+64)
 
 NM_HD nm_window nm_window_from(const nm_enc_word &a, const nm_enc_word &b, uint32_t s) {
@@ -303,52 +281,6 @@ NM_HD uint32_t nm_min_unique_walk(const nm_view &ix, const nm_enc_word *enc, uin
     return ans;
 }
 
-// The same walk, two bases per memory round trip (both strands only): each iteration reads the two-step
-// rank blocks of lo and hi (one 128-byte line each) and obtains the intervals after one AND after two
-// more bases, so the first length with a single occurrence is still found exactly.
-NM_HD uint32_t nm_min_unique_walk2(const nm_view &ix, const nm_enc_word *enc, uint64_t p, nm_window w,
-                                   uint32_t kbase, uint64_t lo, uint64_t hi, uint32_t k, uint32_t kmin,
-                                   uint32_t kmax, bool &err, nm_tally &t) {
-    for (;;) {
-        const uint64_t cnt = hi - lo;
-        if (cnt == 0) { err = true; return 0; }
-        if (cnt == 1) break;
-        if (k >= kmax) return 0;
-        uint32_t j = k - kbase;
-        if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
-        if ((w.amb >> j) & 1ULL) return 0;
-        const uint32_t x = 3u - nm_window_code(w, j);
-        const bool two = j < 63 && k + 1 < kmax && !((w.amb >> (j + 1)) & 1ULL);
-        t.blocks += ((lo >> 6) == (hi >> 6)) ? 4u : 8u;    // 128-byte blocks, counted in 32-byte units
-        if (!two) {
-            lo = nm_lf1_r2(ix, x, lo);
-            hi = nm_lf1_r2(ix, x, hi);
-            k++;
-            t.steps++;
-            continue;
-        }
-        const uint32_t y = 3u - nm_window_code(w, j + 1);
-        uint64_t lo1, lo2, hi1, hi2;
-        nm_lf12(ix, x, y, lo, lo1, lo2);
-        nm_lf12(ix, x, y, hi, hi1, hi2);
-        t.steps += 2;
-        if (hi1 - lo1 <= 1) { lo = lo1; hi = hi1; k += 1; continue; }    // decided after ONE base (0 -> err, 1 -> found)
-        lo = lo2; hi = hi2; k += 2;
-    }
-    const uint32_t ans = k > kmin ? k : kmin;
-    if (!nm_all_valid(enc, p, w, kbase, k, ans)) return 0;
-    return ans;
-}
-
-// picks the two-step walk when its blocks exist (both-strand searches)
-template <bool BIG, bool RC>
-NM_HD uint32_t nm_min_unique_walk_any(const nm_view &ix, const nm_enc_word *enc, uint64_t p, const nm_window &w,
-                                      uint64_t lo, uint64_t hi, uint32_t k, uint32_t kmin, uint32_t kmax,
-                                      bool &err, nm_tally &t) {
-    if (RC && ix.rank2) return nm_min_unique_walk2(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);
-    return nm_min_unique_walk<BIG, RC>(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);
-}
-
 // Range mode, first half: what the window alone decides.  Returns true when the position is
 // settled without touching the index (result 0): its own byte is ambiguous (amb0), or an ambiguous
 // byte sits inside the first s <= kmin bases (U_p < kmin, search.py:437).
@@ -388,7 +320,7 @@ NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint
         if (nm_seed_decode(NM_SEED_LOAD(ix, nm_seed_slot(w, s)), lo, hi)) k = s;
         else { lo = 0; hi = ix.n; }
     }
-    return nm_min_unique_walk_any<BIG, RC>(ix, enc, p, w, lo, hi, k, kmin, kmax, err, t);
+    return nm_min_unique_walk<BIG, RC>(ix, enc, p, w, 0, lo, hi, k, kmin, kmax, err, t);
 }
 
 // Repeat probe (both-strand range mode): one walk from every stride-th position P that knows two things
@@ -713,29 +645,6 @@ NM_HD uint32_t nm_upper_one(const nm_enc_word *enc, uint64_t p, uint32_t kmax) {
     return k < kmax ? k : kmax;
 }
 
-// pair-table entry: core Y = the m-mer spelled by `slot` (same bit layout as a seed slot);
-// e < 4: the (m+1)-mer e.Y, e >= 4: the (m+1)-mer Y.(e-4)
-template <bool BIG>
-NM_HD uint64_t nm_pair_entry(const nm_view &ix, uint64_t slot, uint32_t m, uint32_t e) {
-    uint64_t lo = 0, hi = ix.n;
-    if (e < 4) {
-        lo = nm_lf<BIG>(ix, 3u - e, lo);
-        hi = nm_lf<BIG>(ix, 3u - e, hi);
-    }
-    for (uint32_t j = 0; j < m && lo < hi; j++) {
-        const uint32_t c = 3u - nm_seed_slot_code(slot, m, j);
-        lo = nm_lf<BIG>(ix, c, lo);
-        hi = nm_lf<BIG>(ix, c, hi);
-    }
-    if (e >= 4 && lo < hi) {
-        lo = nm_lf<BIG>(ix, 3u - (e - 4), lo);
-        hi = nm_lf<BIG>(ix, 3u - (e - 4), hi);
-    }
-    uint64_t cnt = hi > lo ? hi - lo : 0;
-    if (cnt >= NM_SEED_CNT_SAT) cnt = NM_SEED_CNT_SAT;
-    return cnt ? ((lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS)) : 0;     // empty intervals are stored as 0
-}
-
 // seed-table entry of slot `slot`: interval of the reverse complement of the s-mer it spells
 template <bool BIG>
 NM_HD uint64_t nm_seed_entry(const nm_view &ix, uint64_t slot, uint32_t s) {
@@ -770,24 +679,14 @@ NM_HD uint64_t nm_seed_entry_from_parent(const nm_view &ix, uint64_t parent_entr
     return cnt ? ((lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS)) : 0;
 }
 
-// seed-table slot (level m+1) of the (m+1)-mer a pair-table entry stands for
-NM_HD uint64_t nm_pair_seed_slot(uint64_t core_slot, uint32_t m, uint32_t e) {
-    const uint32_t s = m + 1;
-    const uint64_t mask = (1ULL << m) - 1ULL;
-    const uint64_t ylo = core_slot & mask, yhi = core_slot >> m;
-    if (e < 4) return (uint64_t)(e & 1u) | (ylo << 1) | ((uint64_t)(e >> 1) << s) | (yhi << (s + 1));
-    const uint32_t b = e - 4;
-    return ylo | ((uint64_t)(b & 1u) << m) | (yhi << s) | ((uint64_t)(b >> 1) << (s + m));
-}
-
 // ---- quad table: ONE 32-byte entry settles FOUR neighbouring positions ---------------------------
 // Range mode only asks "which is the least length with one occurrence", and when the window of
 // w = m + 3 bases at a position already occurs once and w <= kmin the answer is kmin -- one BIT per
 // w-mer is enough.  Positions p .. p+3 share the m-mer core Y = S[p+3 .. p+3+m): the window of
 // position p+i is  L.Y.R  with the 3-i bases L before the core and the i bases R after it, so the
 // 4 x 4^3 = 256 bits "L.Y.R occurs exactly once (both strands)" of one core fill one 32-byte entry
-// and a lane that owns four positions reads one 128-byte line for all of them (the pair table needs
-// two lines, a plain seed table four).  Word i of an entry belongs to position p+i; bit index:
+// and a lane that owns four positions reads one 128-byte line for all of them (a plain seed
+// table needs four).  Word i of an entry belongs to position p+i; bit index:
 //      i = 0:  l0 | l1<<2 | l2<<4        i = 1:  l0 | l1<<2 | r0<<4
 //      i = 2:  r0 | r1<<2 | l0<<4        i = 3:  r0 | r1<<2 | r2<<4         (bases in text order)
 // The table is derived from the seed table of length m without atomics: the lane of m-mer Z walks the
@@ -890,6 +789,85 @@ NM_HD uint32_t nm_quad_bits(const nm_window &w, uint32_t m, const uint64_t e[4])
     const uint32_t i3 = r0 | (r1 << 2) | (r2 << 4);
     return (uint32_t)((e[0] >> i0) & 1ULL) | ((uint32_t)((e[1] >> i1) & 1ULL) << 1) |
            ((uint32_t)((e[2] >> i2) & 1ULL) << 2) | ((uint32_t)((e[3] >> i3) & 1ULL) << 3);
+}
+
+// ---- sites: one quad entry settles 4 + d positions (nm_engine.hip: k_sites, k_resolve) -----------
+// A string that contains a string occurring once occurs once itself.  If the w-mer (w = m + 3) that starts at P + i
+// occurs exactly once, then every position q with  q <= P + i  and  P + i + w <= q + kmin  has a kmin-mer that
+// contains it: its least unique length is <= kmin and its element is kmin (given kmin unambiguous bases).  With
+// d = kmin - w that is q in [P + i - d, P + i].  A SITE is the entry lookup at P = p0 + d for the GROUP of
+// G = d + 4 positions p0 .. p0 + d + 3: bit i of the entry (i = 0 .. 3) settles the positions t = q - p0 in
+// [i, i + d], so the four bits together cover the whole group and the table is read once per G positions instead
+// of once per 4.  What no bit settles (the window is repeated, or the bit's window holds an ambiguous base) is
+// left to k_resolve: repeat probes, then the seed table and the walk.  The reference asks the index about every
+// position on its own (newmap/search.py:383-548); results are identical.
+#define NM_SITE_MAX_D 60u           /* G <= 64: a group's settled bits fit one word */
+#define NM_SITE_MAX_KMIN 252u       /* the kmin bases of a block's last position lie inside the words the block stages */
+
+// the core of the site whose 64-base window is `w` lies in unambiguous bases
+NM_HD bool nm_site_core_valid(const nm_window &w, uint32_t m) {
+    return ((w.amb >> NM_QUAD_EXT) & ((1ULL << m) - 1ULL)) == 0;
+}
+
+// bit i: the (m+3)-mer at position i of the site occurs exactly once AND its window is free of ambiguity
+NM_HD uint32_t nm_site_bits(const nm_window &w, uint32_t m, const uint64_t e[4]) {
+    const uint32_t once = nm_quad_bits(w, m, e);
+    const uint64_t wm = (1ULL << (m + NM_QUAD_EXT)) - 1ULL;
+    uint32_t ok = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) ok |= (uint32_t)(((w.amb >> i) & wm) == 0) << i;
+    return once & ok;
+}
+
+// bit t of the result: position t of the group (t = 0 .. d + 3) is settled by one of the site's bits
+NM_HD uint64_t nm_site_settled(uint32_t bits4, uint32_t d) {
+    const uint64_t run = (1ULL << (d + 1)) - 1ULL;        // d <= NM_SITE_MAX_D
+    uint64_t s = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+        if ((bits4 >> i) & 1u) s |= run << i;
+    return s;
+}
+
+// bit t of the result (t = 0 .. 3): the kmin bases from position q + t on are free of ambiguity (U_p >= kmin,
+// newmap/search.py:437).  q is a multiple of 4; amb_word(i) = ambiguity plane of bases [64 i, 64 i + 64) in q's
+// coordinates; words up to (q + 3 + kmin) / 64 + 1 are read.
+template <class AmbWord>
+NM_HD uint32_t nm_valid4(AmbWord amb_word, uint64_t q, uint32_t kmin, uint32_t &own_amb4) {
+    const uint64_t wi = q >> 6;
+    const uint32_t sh = (uint32_t)(q & 63);
+    auto window = [&](uint64_t j) -> uint64_t {             // bases q + 64 j .. q + 64 j + 63
+        const uint64_t a = amb_word(wi + j);
+        return sh ? (a >> sh) | (amb_word(wi + j + 1) << (64 - sh)) : a;
+    };
+    const uint64_t A = window(0);
+    own_amb4 = (uint32_t)(A & 0xFu);
+    // first ambiguous base at or after q + 64, as an offset from q (looked for up to q + kmin + 2)
+    uint64_t first = ~0ULL;
+    for (uint32_t off = 64; off < kmin + 3; off += 64) {
+        const uint64_t b = window(off >> 6);
+        if (b) { first = off + (uint32_t)__builtin_ctzll(b); break; }
+    }
+    uint32_t valid = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) {
+        const uint32_t n_head = kmin < 64u - t ? kmin : 64u - t;           // bases of the kmin-mer inside A
+        const uint64_t mask = n_head == 64 ? ~0ULL : (1ULL << n_head) - 1ULL;
+        bool ok = ((A >> t) & mask) == 0;
+        if (kmin > 64u - t) ok = ok && first >= (uint64_t)t + kmin;
+        valid |= (uint32_t)ok << t;
+    }
+    return valid;
+}
+
+// Which strides get a repeat probe when the probes run AFTER the sites: a stretch that occurs twice over more than a
+// stride leaves (nearly) all its positions unsettled, so a probe is worth its walk only where the stride itself or
+// the stride before it (whose positions read this stride's word, nm_probe_kstar) is mostly unsettled.  A stride
+// without a probe has the word 0: nothing decided, its positions search for themselves.
+#define NM_PROBE_GATE_BITS 32u
+NM_HD bool nm_probe_gate(const uint64_t *need, uint64_t j, uint64_t n_words) {
+    if (j < n_words && nm_popc64(need[j]) >= NM_PROBE_GATE_BITS) return true;
+    return j > 0 && j - 1 < n_words && nm_popc64(need[j - 1]) >= NM_PROBE_GATE_BITS;
 }
 
 #endif

@@ -2,16 +2,18 @@
 //
 // Kernels (all integer / bit work, HBM-gather bound, no MFMA):
 //   k_encode16 / k_encode   sequence bytes -> 2 bit-planes + ambiguity plane, 32 B / 64 bases
-//   k_repeat_probe          one walk per 64 positions: settles long repeats, fixes lengths between equal ends
-//   k_min_unique_quad       range mode, four positions per 32-byte quad-table entry (default, newmap/search.py:383-548)
-//   k_min_unique_pair       range mode, two positions per pair-table block
-//   k_min_unique            range mode, one lane per genome position (also --norc and short kmin)
-//   k_min_unique_v2, _mp    earlier schedules of the same arithmetic, kept for A/B
+//   k_sites                 range mode: ONE quad-table entry per group of kmin - m + 1 positions settles the group
+//                           (nm_core.h "sites"); writes the elements and the bitmap of positions left open
+//   k_repeat_probe(_coarse) one walk per 64 (512) positions where the bitmap is dense: settles long repeats,
+//                           fixes the lengths between equal ends
+//   k_resolve               the positions k_sites left open: probe words, else seed table + walk
+//                           (the three together: newmap/search.py:383-548)
+//   k_min_unique            range mode, one lane per genome position (--norc, kmin below the table's window, A/B)
 //   k_fixed_k               list mode,  one lane per genome position (newmap/search.py:551-644)
 //   k_multi                 several FASTA files x several index files (newmap/search.py:461, 656-697)
 //   k_count                 forward-strand counts of (start, len) k-mers (src/newmap-count.c:91-206)
 //   k_upper                 per-position upper search length (newmap/search.py:744-882)
-//   k_seed, k_seed_level, k_quad_build, k_pair_gather, k_pair, k_lf_blocks, k_rank2_*   tables built at open
+//   k_seed, k_seed_level, k_quad_build, k_lf_blocks   tables built at open
 // The per-position logic lives in nm_core.h.
 #include <hip/hip_runtime.h>
 
@@ -166,16 +168,21 @@ __device__ __forceinline__ void nm_store(void *out, int elem_bytes, uint64_t p, 
 // a wave probe neighbouring strides, so inside a long repeat they walk in step.  probe[n_probes] = 0 (the
 // consumers read strides j and j+1).  probe_tally (counter builds): LF steps, blocks, seed entries, settled.
 #define NM_PROBE_STRIDE 64u
+static_assert(NM_PROBE_STRIDE == 64, "one word of the need bitmap per probe stride");
 // coarse[c] = positions from c * NM_COARSE_STRIDE on that one walk of <= kmax + NM_COARSE_STRIDE - 1 bases settles as 0
 template <bool BIG, bool STATS>
 __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe_coarse(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_coarse,
                                                                   uint32_t kmax, uint32_t *__restrict__ coarse,
-                                                                  unsigned long long *__restrict__ probe_tally) {
+                                                                  unsigned long long *__restrict__ probe_tally,
+                                                                  const uint64_t *__restrict__ need, uint64_t n_need) {
     const uint64_t c = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     nm_tally t = {0, 0, 0, 0};
     if (c < n_coarse) {
-        uint32_t settled, exact;
-        nm_repeat_probe_ex<BIG>(ix, enc, c * NM_COARSE_STRIDE, kmax, NM_COARSE_STRIDE, t, settled, exact);
+        uint32_t settled = 0, exact;
+        // after k_sites (need != nullptr): only where the first fine stride is mostly open -- the start of a long repeat
+        const uint64_t j0 = c * (NM_COARSE_STRIDE / NM_PROBE_STRIDE);
+        if (!need || (j0 < n_need && nm_popc64(need[j0]) >= NM_PROBE_GATE_BITS))
+            nm_repeat_probe_ex<BIG>(ix, enc, c * NM_COARSE_STRIDE, kmax, NM_COARSE_STRIDE, t, settled, exact);
         coarse[c] = settled;
     }
     if (STATS) {
@@ -193,7 +200,8 @@ __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe(nm_view ix, const nm_
                                                            uint32_t kmax, uint32_t *__restrict__ probe,
                                                            unsigned long long *__restrict__ probe_tally,
                                                            const uint32_t *__restrict__ coarse, volatile uint32_t *repeats_seen,
-                                                           uint32_t *__restrict__ seen_latch) {
+                                                           uint32_t *__restrict__ seen_latch,
+                                                           const uint64_t *__restrict__ need, uint64_t n_need) {
     const uint64_t j = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     nm_tally t = {0, 0, 0, 0};
     uint32_t c = 0;
@@ -202,7 +210,8 @@ __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe(nm_view ix, const nm_
         if (j < n_probes) {
             const uint64_t P = j * NM_PROBE_STRIDE;
             // a stride the coarse probe settles completely: the word this probe would find after kmax + 63 steps
-            if (coarse && nm_coarse_covers(coarse[P / NM_COARSE_STRIDE], (uint32_t)(P % NM_COARSE_STRIDE), NM_PROBE_STRIDE)) word = NM_PROBE_STRIDE;
+            if (need && !nm_probe_gate(need, j, n_need)) word = 0;      // (after k_sites: nothing open here, nothing to tell)
+            else if (coarse && nm_coarse_covers(coarse[P / NM_COARSE_STRIDE], (uint32_t)(P % NM_COARSE_STRIDE), NM_PROBE_STRIDE)) word = NM_PROBE_STRIDE;
             else word = nm_repeat_probe<BIG>(ix, enc, P, kmax, NM_PROBE_STRIDE, t);
         }
         probe[j] = word;
@@ -254,399 +263,214 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique(nm_view ix, const nm_en
     nm_epilogue<STATS>(inb, amb0, err, p, t, status);
 }
 
-
-// ---- k_min_unique_mp: NM_MP positions per lane --------------------------------------------------
-// Same arithmetic as k_min_unique.  Two changes in how the work is laid out on a wave:
-//   * a wave owns 64*NM_MP consecutive positions, so the encoded words its windows are cut from are
-//     wave-uniform: NM_MP+1 scalar 32-byte loads replace 4 vector loads per lane and position;
-//   * a lane first issues the seed-table lookups of all its NM_MP positions (independent HBM
-//     gathers in flight together) and only then consumes them, walking further where needed.
-#define NM_MP 4
-
-template <bool BIG, bool RC, bool STATS>
-__global__ __launch_bounds__(NM_BLOCK) void k_min_unique_mp(nm_view ix, const nm_enc_word *__restrict__ enc,
-                                                            uint64_t n_enc_words, uint64_t num_kmers,
-                                                            uint32_t kmin, uint32_t kmax, void *__restrict__ out,
-                                                            int elem_bytes, uint64_t *__restrict__ status) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * (64ull * NM_MP);
-    if (wave_base >= num_kmers) return;                                  // whole wave out of range
-    const uint32_t s = ix.seed_len;
-    const bool use_seed = s && kmin >= s;
-
-    // wave-uniform words (scalar loads); indexes beyond the array are clamped to the all-ambiguous pad
-    nm_enc_word W[NM_MP + 1];
-    const uint64_t w0 = wave_base >> 6;
-#pragma unroll
-    for (int j = 0; j <= NM_MP; j++) {
-        uint64_t wi = w0 + j;
-        if (wi >= n_enc_words) wi = n_enc_words - 1;
-        W[j] = enc[wi];
-    }
-    nm_window win[NM_MP];
-    uint64_t e[NM_MP];
-    bool amb0[NM_MP], settled[NM_MP];
-    uint32_t n_amb = 0, n_searched = 0;
-    nm_tally t = {0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < NM_MP; j++) {
-        const uint64_t p = wave_base + 64ull * j + lane;
-        win[j] = nm_window_from(W[j], W[j + 1], lane);
-        settled[j] = nm_min_unique_settled(win[j], s, use_seed, amb0[j]);
-        if (p >= num_kmers) { settled[j] = true; amb0[j] = false; }
-        e[j] = 0;
-        if (!settled[j] && use_seed) e[j] = NM_SEED_LOAD(ix, nm_seed_slot(win[j], s));   // NM_MP gathers in flight
-    }
-    bool any_err = false;
-    uint64_t err_pos = ~0ULL;
-#pragma unroll
-    for (int j = 0; j < NM_MP; j++) {
-        const uint64_t p = wave_base + 64ull * j + lane;
-        if (p >= num_kmers) continue;
-        uint32_t r = 0;
-        if (amb0[j]) n_amb++;
-        if (!settled[j]) {
-            uint64_t lo = 0, hi = ix.n;
-            uint32_t k = 0;
-            if (use_seed) {
-                if (STATS) t.seeds++;
-                if (nm_seed_decode(e[j], lo, hi)) k = s;
-                else { lo = 0; hi = ix.n; }
-            }
-            bool err = false;
-            r = nm_min_unique_walk_any<BIG, RC>(ix, enc, p, win[j], lo, hi, k, kmin, kmax, err, t);
-            if (err) { any_err = true; if (p < err_pos) err_pos = p; }
-        }
-        if (STATS && !amb0[j]) n_searched++;
-        nm_store(out, elem_bytes, p, r);
-    }
-    // wave totals
-    const uint32_t amb_sum = wave_sum(n_amb);
-    if (lane == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
-    if (__ballot(any_err)) {
-        if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
-        if (lane == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
-    }
-    if (STATS) {
-        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), c = wave_sum(t.seeds),
-                       d = wave_sum(t.strands), f = wave_sum(n_searched);
-        if (lane == 0) {
-            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
-            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
-            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
-            atomicAdd((unsigned long long *)&status[6], (unsigned long long)d);
-            atomicAdd((unsigned long long *)&status[7], (unsigned long long)f);
-        }
-    }
+// ---- k_sites: one 128-byte table line serves a GROUP of 4 + d positions ---------------------------
+// (nm_core.h "sites".)  Range mode on both strands with m + 3 <= kmin <= NM_SITE_MAX_KMIN, and list mode whose
+// first length takes the place of kmin.  A block owns BP = 512 G consecutive positions (G = d + 4, d = kmin - m - 3
+// capped at NM_SITE_MAX_D): every lane looks up the sites of two groups (both loads in flight before either is
+// used), ORs the positions its entries settle into a bitmap in LDS, and the block then writes the elements four
+// at a time in position order -- kmin where settled and the kmin bases are unambiguous, else 0 -- together with the
+// bitmap of the positions that are still open (unambiguous over kmin bases, not settled): need[j] = positions
+// 64 j .. 64 j + 63 of the segment.  k_resolve finishes those.  The block's encoded words are staged in LDS once.
+#define NM_SITE_BLOCK 256
+#define NM_SITE_PER_LANE 2
+static inline uint32_t nm_site_block_positions(uint32_t d) { return NM_SITE_BLOCK * NM_SITE_PER_LANE * (d + 4); }
+static inline size_t nm_site_lds_bytes(uint32_t d) {
+    const uint32_t bp = nm_site_block_positions(d);
+    return (size_t)(bp / 64 + 5) * 24 + (size_t)bp / 8 * 2;
 }
 
-// ---- k_min_unique_pair: one 128-byte line serves TWO positions ---------------------------------
-// Measured (profiles/round1): with a long seed table the range kernel is bound by HBM line fetches --
-// every L2 miss is a 128-byte read (TCC_EA0_RDREQ_128B), one per position for its 8-byte seed entry,
-// ~5.8 TB/s of real traffic whatever the kernel's structure.  The only lever left is fewer lines per
-// position.  Neighbouring positions p and p+1 share the m-mer core Y = S[p+1 .. p+1+m): their
-// (m+1)-mers are S[p].Y and Y.S[p+1+m].  The pair table stores, per core, the intervals of all four
-// a.Y and all four Y.b in one 64-byte block, so a lane that owns positions (2i, 2i+1) touches ONE line
-// for both seeds.
-template <bool BIG, bool STATS>
-__global__ __launch_bounds__(NM_BLOCK) void k_min_unique_pair(nm_view ix, const nm_enc_word *__restrict__ enc,
-                                                              uint64_t n_enc_words, uint64_t num_kmers,
-                                                              uint32_t kmin, uint32_t kmax, void *__restrict__ out,
-                                                              int elem_bytes, uint64_t *__restrict__ status,
-                                                              const uint32_t *__restrict__ probe) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_BLOCK / NM_WAVE) + wave_in_block) * 128ull;
-    // (no early exit for waves past the end: every wave of the block reaches the barriers below)
-    const uint32_t m = ix.pair_m, s = m + 1;
-    const uint64_t core_mask = (1ULL << m) - 1ULL;
-
-    nm_enc_word W[3];                                     // wave-uniform -> scalar loads
-    const uint64_t w0 = wave_base >> 6;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        uint64_t wi = w0 + j;
-        if (wi >= n_enc_words) wi = n_enc_words - 1;
-        W[j] = enc[wi];
+template <bool STATS>
+__global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_enc_words,
+                                                         uint64_t num_kmers, uint32_t kmin, uint32_t d, void *__restrict__ out,
+                                                         int elem_bytes, uint64_t *__restrict__ status, uint64_t *__restrict__ need) {
+    extern __shared__ uint64_t s_mem[];
+    const uint32_t G = d + 4, m = ix.quad_m;
+    const uint32_t BP = NM_SITE_BLOCK * NM_SITE_PER_LANE * G;          // a multiple of 512
+    const uint32_t n_stage = BP / 64 + 5;
+    uint64_t *s_lo = s_mem, *s_hi = s_lo + n_stage, *s_amb = s_hi + n_stage;
+    uint32_t *s_set = reinterpret_cast<uint32_t *>(s_amb + n_stage);  // BP bits: settled by a site
+    uint32_t *s_need = s_set + BP / 32;                               // BP bits: open
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * BP;
+    const uint64_t w0 = base >> 6;
+    for (uint32_t i = tid; i < n_stage; i += NM_SITE_BLOCK) {
+        const uint64_t wi = w0 + i < n_enc_words ? w0 + i : n_enc_words - 1;      // (the last words are all-ambiguous padding)
+        const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(enc + wi)[0];
+        s_lo[i] = a.x; s_hi[i] = a.y;
+        s_amb[i] = enc[wi].amb;
     }
-    const uint32_t q = 2 * lane;                          // offset of the even position in the wave's 128
-    const nm_enc_word &Wa = q < 64 ? W[0] : W[1];
-    const nm_enc_word &Wb = q < 64 ? W[1] : W[2];
-    const uint64_t p0 = wave_base + q, p1 = p0 + 1;
-    const nm_window win0 = nm_window_from(Wa, Wb, q & 63);
-    const nm_window win1 = nm_window_from(Wa, Wb, (q & 63) + 1);   // (q & 63) <= 62
-    const bool in0 = p0 < num_kmers, in1 = p1 < num_kmers;
-    const bool amb0 = (win0.amb & 1ULL) != 0, amb1 = (win0.amb & 2ULL) != 0;
-    const bool core_ok = ((win0.amb >> 1) & core_mask) == 0;
-    // positions the repeat probes decide store their element and read nothing (p0, p1 share a probe stride)
-    uint32_t ks0 = NM_PROBE_OPEN, ks1 = NM_PROBE_OPEN;
-    if (probe && in0) {
-        const uint32_t wj = probe[p0 / NM_PROBE_STRIDE], wj1 = probe[p0 / NM_PROBE_STRIDE + 1];
-        const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
-        ks0 = nm_probe_kstar(wj, wj1, off0, NM_PROBE_STRIDE, kmax);
-        ks1 = nm_probe_kstar(wj, wj1, off0 + 1, NM_PROBE_STRIDE, kmax);
-    }
-    const bool go0 = in0 && !amb0 && core_ok && ks0 == NM_PROBE_OPEN;                        // bases 0..m unambiguous
-    const bool go1 = in1 && core_ok && !((win0.amb >> s) & 1ULL) && ks1 == NM_PROBE_OPEN;     // bases 1..m+1 unambiguous
-    const uint64_t slot = ((win0.lo >> 1) & core_mask) | (((win0.hi >> 1) & core_mask) << m);
-    const uint64_t *blk = ix.pair + slot * 8;
-    uint64_t e0 = 0, e1 = 0;
-    if (go0) e0 = blk[nm_window_code(win0, 0)];                                  // both in one 64-byte block
-    if (go1) e1 = blk[4 + nm_window_code(win0, s)];
-    nm_tally t = {0, 0, 0, 0};
-    bool any_err = false;
-    uint64_t err_pos = ~0ULL;
-    // ---- stage 1: what the table line alone decides.  Most positions end here (interval of one
-    // element); the rest are queued in LDS so that only as many waves as there is work stay resident
-    __shared__ uint64_t q_p[NM_BLOCK * 2], q_lo[NM_BLOCK * 2];
-    __shared__ uint32_t q_cnt[NM_BLOCK * 2];
-    __shared__ uint32_t q_n;
-    if (threadIdx.x == 0) q_n = 0;
+    for (uint32_t i = tid; i < BP / 16; i += NM_SITE_BLOCK) s_set[i] = 0;          // both bitmaps
     __syncthreads();
-    auto stage1 = [&](bool go, bool in_range, uint64_t p, const nm_window &win, uint64_t e, uint32_t ks) {
-        if (!in_range) return;
-        uint32_t r = 0;
-        if (ks != NM_PROBE_OPEN) {                         // decided by the probes
-            nm_window w = win;
-            uint32_t kbase = 0;
-            r = nm_probe_element(ks, kmin, kmax, ks < kmin && nm_all_valid(enc, p, w, kbase, 0, kmin));
-        } else if (go) {
-            uint64_t lo = 0, hi = ix.n;
-            const bool have = nm_seed_decode(e, lo, hi);
-            const uint64_t cnt = hi - lo;
-            if (have && cnt == 1) {                       // unique already: max(s, kmin) if within U_p
-                nm_window w = win;
-                uint32_t kbase = 0;
-                const uint32_t ans = s > kmin ? s : kmin;
-                r = nm_all_valid(enc, p, w, kbase, s, ans) ? ans : 0u;
-            } else if (have && cnt == 0) {                // search.py:699-722
-                any_err = true;
-                if (p < err_pos) err_pos = p;
-            } else {                                      // needs a walk: queue it
-                const uint32_t slot_i = atomicAdd(&q_n, 1u);
-                q_p[slot_i] = p;
-                q_lo[slot_i] = have ? lo : 0;
-                q_cnt[slot_i] = have ? (uint32_t)cnt : 0u; // 0 = saturated entry, walk from scratch
-                return;                                   // stored by stage 2
-            }
+    auto lds_window = [&](uint32_t rel) -> nm_window {
+        const uint32_t wi = rel >> 6, sh = rel & 63;
+        nm_window w;
+        w.lo = s_lo[wi]; w.hi = s_hi[wi]; w.amb = s_amb[wi];
+        if (sh) {
+            w.lo = (w.lo >> sh) | (s_lo[wi + 1] << (64 - sh));
+            w.hi = (w.hi >> sh) | (s_hi[wi + 1] << (64 - sh));
+            w.amb = (w.amb >> sh) | (s_amb[wi + 1] << (64 - sh));
         }
-        nm_store(out, elem_bytes, p, r);
+        return w;
     };
-    stage1(go0, in0, p0, win0, e0, ks0);
-    stage1(go1, in1, p1, win1, e1, ks1);
-    __syncthreads();
-    // ---- stage 2: dense walks; waves beyond the queue length leave and free their slots
-    const uint32_t n_walk = q_n;
-    for (uint32_t i = threadIdx.x; i < n_walk; i += NM_BLOCK) {
-        const uint64_t p = q_p[i];
-        uint64_t lo = q_lo[i], hi = lo + q_cnt[i];
-        uint32_t k = s;
-        if (q_cnt[i] == 0) { lo = 0; hi = ix.n; k = 0; }
-        bool err = false;
-        const nm_window w = nm_load_window(enc, p);
-        const uint32_t r = nm_min_unique_walk_any<BIG, true>(ix, enc, p, w, lo, hi, k, kmin, kmax, err, t);
-        if (err) { any_err = true; if (p < err_pos) err_pos = p; }
-        nm_store(out, elem_bytes, p, r);
-    }
-
-    const uint32_t amb_sum = wave_sum((uint32_t)(in0 && amb0) + (uint32_t)(in1 && amb1));
-    if (lane == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
-    if (__ballot(any_err)) {
-        if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
-        if (lane == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
-    }
-    if (STATS) {
-        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks),
-                       c = wave_sum((uint32_t)go0 + (uint32_t)go1),                 // 8-byte entries read
-                       f = wave_sum((uint32_t)(in0 && !amb0) + (uint32_t)(in1 && !amb1));
-        if (lane == 0) {
-            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
-            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
-            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
-            atomicAdd((unsigned long long *)&status[7], (unsigned long long)f);
-        }
-    }
-}
-
-
-// ---- k_min_unique_quad: one 128-byte line serves FOUR positions ---------------------------------
-// The pair kernel is bound by the table lines it fetches (one per two positions).  When kmin is at
-// least w = m + 3, all a position needs from the table is ONE BIT -- "the w-mer here occurs once" --
-// because the element stored is then kmin itself.  The quad table (nm_core.h) packs those bits for the
-// four positions that share an m-mer core into one 32-byte entry: a lane owns positions 4i .. 4i+3,
-// reads one entry, and only the positions whose w-mer is repeated (or absent) go on to the seed table
-// and the walk (stage 2, compacted through LDS like the pair kernel's).
-// A lane owns NM_QUAD_GROUPS groups of four positions (group g of lane l: wave base + 256 g + 4 l) and issues
-// the entry loads of all its groups before it looks at any: with 32 waves per CU the requests in flight,
-// not the lines per position, were what kept the kernel below the HBM's random-line rate.
-#define NM_QUAD_GROUPS 2
-#define NM_QUAD_MAX_KMIN 124u     /* kmin bases from any of a lane's four positions lie inside its two 64-base windows */
-#define NM_QUAD_PER_WAVE (256u * NM_QUAD_GROUPS)
-// Workgroup size (template argument QB): 256 lanes share one walk queue, so the walks of a stretch of repeated
-// positions (the last kmax positions of every repeat) spread over four waves instead of running as four passes
-// of one; 64 saves the barriers' waiting on unique input (2 % there, measured) -- NEWMAP_AMD_QUAD_BLOCK.
-// LIST: list mode with several lengths, all of them >= m + 3 (newmap/search.py:551-644).  kmin = the FIRST listed
-// length, kmax = the longest: a position whose (m+3)-mer occurs once is unique at every listed length, so its
-// element is the first one (if its bases are unambiguous); positions the probes settle as repeated over more than
-// kmax bases are 0; everything else -- repeated windows and lengths fixed by the probes -- goes through
-// nm_fixed_k_one in stage 2.  The caller keeps the positions whose longest k-mer leaves the data out of this kernel.
-template <bool BIG, bool STATS, int NM_QUAD_BLOCK, bool LONGK, bool LIST = false>
-__global__ __launch_bounds__(NM_QUAD_BLOCK) void k_min_unique_quad(nm_view ix, const nm_enc_word *__restrict__ enc,
-                                                              uint64_t n_enc_words, uint64_t num_kmers,
-                                                              uint32_t kmin, uint32_t kmax, void *__restrict__ out,
-                                                              int elem_bytes, uint64_t *__restrict__ status,
-                                                              const uint32_t *__restrict__ probe,
-                                                              uint64_t seq_len = 0, const uint32_t *__restrict__ list = nullptr,
-                                                              uint32_t n_list = 0) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t wave_base = ((uint64_t)blockIdx.x * (NM_QUAD_BLOCK / NM_WAVE) + wave_in_block) * NM_QUAD_PER_WAVE;
-    const uint32_t m = ix.quad_m;
-
-    // the 4 * NM_QUAD_GROUPS + 1 encoded words of the wave: wave-uniform -> scalar loads.  Separate variables,
-    // not an array: a lane picks its words by (lane >> 4), and selects over array elements are turned into an
-    // indexed load from scratch memory
-    const uint64_t w0 = wave_base >> 6;
-#define NM_LOAD_WORD(j) const nm_enc_word W##j = enc[w0 + j < n_enc_words ? w0 + j : n_enc_words - 1];
-    NM_LOAD_WORD(0) NM_LOAD_WORD(1) NM_LOAD_WORD(2) NM_LOAD_WORD(3) NM_LOAD_WORD(4)
-    NM_LOAD_WORD(5) NM_LOAD_WORD(6) NM_LOAD_WORD(7) NM_LOAD_WORD(8) NM_LOAD_WORD(9)
-#undef NM_LOAD_WORD
-    static_assert(NM_QUAD_GROUPS == 2, "the word variables above are written out for two groups");
-    const uint32_t q = 4 * lane;                          // offset of the lane's first position in a group's 256
-    const uint32_t qw = q >> 6;
-    // go: the position takes part in the lookup.  kmin <= NM_QUAD_MAX_KMIN (the launcher sees to it), so the
-    // lane's 64-base window -- plus the ambiguity plane of the next 64 bases when kmin > 60 -- shows whether the
-    // first kmin bases are free of ambiguity (if not: U_p < kmin, element 0, search.py:437); stage 1 is branch-free.
-    constexpr bool long_kmin = LONGK;                      // kmin > 60: its own instantiation (6 more VGPRs cost a wave per SIMD)
-    nm_window win[NM_QUAD_GROUPS];
-    uint64_t amb_next[NM_QUAD_GROUPS];                     // ambiguity plane of bases p0+64 .. p0+127 (long_kmin only)
-    auto kmin_bases_valid = [&](int g, uint32_t i) -> bool {
-        const uint64_t a = win[g].amb >> i;
-        if (!long_kmin) return (a & ((1ULL << kmin) - 1ULL)) == 0;
-        const uint32_t n_lo = kmin < 64u - i ? kmin : 64u - i, n_hi = kmin - n_lo;        // n_hi <= 63
-        const uint64_t lo_mask = n_lo == 64 ? ~0ULL : ((1ULL << n_lo) - 1ULL);
-        return (a & lo_mask) == 0 && (amb_next[g] & ((1ULL << n_hi) - 1ULL)) == 0;
-    };
-#define NM_SEL4(f, a, b, c, d) (qw == 0 ? a.f : (qw == 1 ? b.f : (qw == 2 ? c.f : d.f)))
-    uint64_t e[NM_QUAD_GROUPS][4];
-    uint32_t go[NM_QUAD_GROUPS], inb[NM_QUAD_GROUPS];     // bit i: position i of the group
-    uint32_t pw[NM_QUAD_GROUPS][2];                       // probe words of the group's stride and of the next one
-    uint32_t n_amb = 0, n_searched = 0, n_entries = 0;
+    // ---- phase 1: the sites
+    nm_window win[NM_SITE_PER_LANE];
+    uint64_t e[NM_SITE_PER_LANE][4];
+    bool go[NM_SITE_PER_LANE];
+    uint32_t n_entries = 0;
 #pragma unroll
-    for (int g = 0; g < NM_QUAD_GROUPS; g++) {
-        {
-            nm_enc_word Wa, Wb;
-            Wa.pad = Wb.pad = 0;
-            if (g == 0) {
-                Wa.lo = NM_SEL4(lo, W0, W1, W2, W3); Wa.hi = NM_SEL4(hi, W0, W1, W2, W3); Wa.amb = NM_SEL4(amb, W0, W1, W2, W3);
-                Wb.lo = NM_SEL4(lo, W1, W2, W3, W4); Wb.hi = NM_SEL4(hi, W1, W2, W3, W4); Wb.amb = NM_SEL4(amb, W1, W2, W3, W4);
-            } else {
-                Wa.lo = NM_SEL4(lo, W4, W5, W6, W7); Wa.hi = NM_SEL4(hi, W4, W5, W6, W7); Wa.amb = NM_SEL4(amb, W4, W5, W6, W7);
-                Wb.lo = NM_SEL4(lo, W5, W6, W7, W8); Wb.hi = NM_SEL4(hi, W5, W6, W7, W8); Wb.amb = NM_SEL4(amb, W5, W6, W7, W8);
-            }
-            win[g] = nm_window_from(Wa, Wb, q & 63);      // bases p0 .. p0+63
-            amb_next[g] = 0;
-            if (long_kmin) {
-                const uint64_t c = g == 0 ? NM_SEL4(amb, W2, W3, W4, W5) : NM_SEL4(amb, W6, W7, W8, W9);
-                const uint32_t sh = q & 63;
-                amb_next[g] = sh ? (Wb.amb >> sh) | (c << (64 - sh)) : Wb.amb;
-            }
-        }
-        const uint64_t p0 = wave_base + 256u * g + q;
-        uint32_t wj = 0, wj1 = 0;                          // four positions, one probe stride (words 0, 0: nothing decided)
-        if (probe && p0 < num_kmers) { wj = probe[p0 / NM_PROBE_STRIDE]; wj1 = probe[p0 / NM_PROBE_STRIDE + 1]; }
-        pw[g][0] = wj; pw[g][1] = wj1;
-        const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
-        go[g] = 0; inb[g] = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) {
-            const bool in = p0 + i < num_kmers;
-            const bool amb = ((win[g].amb >> i) & 1ULL) != 0;
-            const bool kmin_valid = kmin_bases_valid(g, i);
-            const uint32_t ks = nm_probe_kstar(wj, wj1, off0 + i, NM_PROBE_STRIDE, kmax);
-            inb[g] |= (uint32_t)in << i;
-            n_amb += (uint32_t)(in && amb);
-            n_searched += (uint32_t)(in && !amb);
-            go[g] |= (uint32_t)(in && kmin_valid && ks == NM_PROBE_OPEN) << i;
-        }
-        e[g][0] = e[g][1] = e[g][2] = e[g][3] = 0;
-        if (go[g] && !(ix.seed_policy & 0x200u)) {        // the core lies inside every window that is free of ambiguity
-            const ulonglong2 *ep = reinterpret_cast<const ulonglong2 *>(ix.quad + nm_quad_slot(win[g], m) * 4);
+    for (int s = 0; s < NM_SITE_PER_LANE; s++) {
+        const uint32_t g = (uint32_t)s * NM_SITE_BLOCK + tid;          // group g: positions base + g G .. + G - 1, site at + d
+        win[s] = lds_window(g * G + d);
+        go[s] = base + (uint64_t)g * G < num_kmers && nm_site_core_valid(win[s], m) && !(ix.seed_policy & 0x200u);
+        e[s][0] = e[s][1] = e[s][2] = e[s][3] = 0;
+        if (go[s]) {
+            const ulonglong2 *ep = reinterpret_cast<const ulonglong2 *>(ix.quad + nm_quad_slot(win[s], m) * 4);
             const ulonglong2 a = ep[0], b = ep[1];
-            e[g][0] = a.x; e[g][1] = a.y; e[g][2] = b.x; e[g][3] = b.y;
+            e[s][0] = a.x; e[s][1] = a.y; e[s][2] = b.x; e[s][3] = b.y;
             n_entries += 4;
         }
     }
-    nm_tally t = {0, 0, 0, 0};
-    bool any_err = false;
-    uint64_t err_pos = ~0ULL;
-    __shared__ uint64_t q_p[NM_QUAD_BLOCK * 4 * NM_QUAD_GROUPS];
-    __shared__ uint32_t q_n;
-    if (threadIdx.x == 0) q_n = 0;
+#pragma unroll
+    for (int s = 0; s < NM_SITE_PER_LANE; s++) {
+        const uint64_t settled = go[s] ? nm_site_settled(nm_site_bits(win[s], m, e[s]), d) : 0ULL;
+        if (settled) {
+            const uint32_t o = ((uint32_t)s * NM_SITE_BLOCK + tid) * G;   // bit offset of the group in the block
+            const uint32_t wi = o >> 5, sh = o & 31;
+            atomicOr(&s_set[wi], (uint32_t)(settled << sh));
+            const uint64_t rest = sh ? settled >> (32 - sh) : settled >> 16 >> 16;
+            if ((uint32_t)rest) atomicOr(&s_set[wi + 1], (uint32_t)rest);
+            if (rest >> 32) atomicOr(&s_set[wi + 2], (uint32_t)(rest >> 32));
+        }
+    }
     __syncthreads();
-    // ---- stage 1: what the entry alone decides.  once: least unique length <= w <= kmin, the element is kmin
-    // (if within U_p); otherwise the w-mer is repeated or absent: seed table + walk in stage 2
-#pragma unroll
-    for (int g = 0; g < NM_QUAD_GROUPS; g++) {
-        const uint64_t p0 = wave_base + 256u * g + q;
-        const uint32_t once = nm_quad_bits(win[g], m, e[g]);
-        uint32_t r[4] = {0, 0, 0, 0};
-        const uint32_t hit = go[g] & once;
-        uint32_t walk = go[g] & ~once;
-        const uint32_t off0 = (uint32_t)(p0 & (NM_PROBE_STRIDE - 1));
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) {
-            r[i] = ((hit >> i) & 1u) ? kmin : 0u;
-            const uint32_t ks = nm_probe_kstar(pw[g][0], pw[g][1], off0 + i, NM_PROBE_STRIDE, kmax);
-            if (ks == NM_PROBE_OPEN) continue;
-            if (!LIST) r[i] = nm_probe_element(ks, kmin, kmax, kmin_bases_valid(g, i));   // decided by the probes
-            else if (ks <= kmax && ((inb[g] >> i) & 1u)) walk |= 1u << i;                  // (list mode: stage 2 picks the length)
-        }
-        if (walk) {
-            uint32_t at = atomicAdd(&q_n, (uint32_t)__builtin_popcount(walk));
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++)
-                if ((walk >> i) & 1u) q_p[at++] = p0 + i;
-        }
-        if (elem_bytes == 1 && inb[g] == 0xFu && (((uintptr_t)out) & 3u) == 0) {
-            reinterpret_cast<uint32_t *>(out)[p0 >> 2] = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+    // ---- phase 2: elements and open bits, four positions per lane and turn, in position order
+    uint32_t n_amb = 0, n_searched = 0;
+    auto amb_word = [&](uint64_t i) -> uint64_t { return s_amb[i]; };
+    const bool wide = elem_bytes == 1 && (((uintptr_t)out) & 3u) == 0;
+    for (uint32_t j = tid; j < BP / 4; j += NM_SITE_BLOCK) {
+        const uint32_t rel = 4 * j;
+        const uint64_t q = base + rel;
+        if (q >= num_kmers) break;
+        const uint64_t left = num_kmers - q;
+        const uint32_t inb = left >= 4 ? 0xFu : (1u << left) - 1u;
+        uint32_t own_amb;
+        const uint32_t valid = nm_valid4(amb_word, rel, kmin, own_amb) & inb;
+        const uint32_t set4 = (s_set[rel >> 5] >> (rel & 31)) & 0xFu;
+        const uint32_t hit = valid & set4, open = valid & ~set4;
+        n_amb += (uint32_t)__builtin_popcount(own_amb & inb);
+        n_searched += (uint32_t)__builtin_popcount(~own_amb & inb);
+        if (open) atomicOr(&s_need[rel >> 5], open << (rel & 31));
+        if (wide && inb == 0xFu) {
+            reinterpret_cast<uint32_t *>(out)[q >> 2] = (hit & 1u ? kmin : 0u) | (hit & 2u ? kmin << 8 : 0u) |
+                                                         (hit & 4u ? kmin << 16 : 0u) | (hit & 8u ? kmin << 24 : 0u);
         } else {
 #pragma unroll
-            for (uint32_t i = 0; i < 4; i++)
-                if ((inb[g] >> i) & 1u) nm_store(out, elem_bytes, p0 + i, r[i]);
+            for (uint32_t t = 0; t < 4; t++)
+                if ((inb >> t) & 1u) nm_store(out, elem_bytes, q + t, (hit >> t) & 1u ? kmin : 0u);
         }
     }
-    __syncthreads();                                       // stage 2 overwrites the placeholders of queued positions
-    // ---- stage 2: dense walks
-    const uint32_t n_walk = (ix.seed_policy & 0x100u) ? 0u : q_n;     // (0x100 / 0x200: timing experiments, wrong results)
-    for (uint32_t i = threadIdx.x; i < n_walk; i += NM_QUAD_BLOCK) {
-        const uint64_t p = q_p[i];
-        bool amb0 = false, err = false;
-        const uint32_t v = LIST ? nm_fixed_k_one<BIG, true>(ix, enc, p, seq_len, list, n_list, amb0, err, t)
-                                : nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
-        if (err) { any_err = true; if (p < err_pos) err_pos = p; }
-        nm_store(out, elem_bytes, p, v);
-    }
+    __syncthreads();
+    for (uint32_t i = tid; i < BP / 64; i += NM_SITE_BLOCK)
+        if (base + 64ull * i < num_kmers) need[w0 + i] = (uint64_t)s_need[2 * i] | ((uint64_t)s_need[2 * i + 1] << 32);
 
     const uint32_t amb_sum = wave_sum(n_amb);
-    if (lane == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
-    if (__ballot(any_err)) {
-        if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
-        if (lane == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
-    }
+    if ((tid & 63) == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
     if (STATS) {
-        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks),
-                       c = wave_sum(n_entries + t.seeds),                            // 8-byte table words read
-                       f = wave_sum(n_searched);
-        if (lane == 0) {
-            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
-            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
-            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
+        const uint32_t c = wave_sum(n_entries), f = wave_sum(n_searched);
+        if ((tid & 63) == 0) {
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);           // 8-byte table words read
             atomicAdd((unsigned long long *)&status[7], (unsigned long long)f);
         }
     }
-#undef NM_SEL4
+}
+
+// ---- k_resolve: the positions k_sites left open -----------------------------------------------------
+// A block owns NM_RES_WORDS words of the need bitmap (64 positions each; four words per lane).  Scan: a lane goes
+// through the set bits of its words; what the repeat probes decide (nm_probe_kstar) is stored at once, everything else
+// is queued in LDS.  Walk: the queue is worked off densely by all lanes (seed table + walk, nm_min_unique_one; list
+// mode: nm_fixed_k_one).  A full queue ends the scan early; it resumes after the walks.  On input without long
+// repeats the bitmap is nearly empty: one scan, one short walk phase.
+// LIST: list mode with several lengths (see nm_fixed_k_segment_dev): the probes only rule positions out (repeated
+// over more than the longest length -> 0); every other open position goes through nm_fixed_k_one.
+#define NM_RES_BLOCK 256
+#define NM_RES_WORDS 1024u
+#define NM_RES_QCAP 2048u
+template <bool BIG, bool STATS, bool LIST>
+__global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t num_kmers,
+                                                          uint32_t kmin, uint32_t kmax, void *__restrict__ out, int elem_bytes,
+                                                          uint64_t *__restrict__ status, const uint64_t *__restrict__ need,
+                                                          uint64_t n_need, const uint32_t *__restrict__ probe,
+                                                          uint64_t seq_len, const uint32_t *__restrict__ list, uint32_t n_list) {
+    __shared__ uint32_t q_p[NM_RES_QCAP];
+    __shared__ uint32_t q_n;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t wbase = (uint64_t)blockIdx.x * NM_RES_WORDS;
+    uint32_t r = 0;                                        // words of this lane taken so far
+    uint64_t bits = 0, cur = 0;                            // open bits left in the current word, its index
+    uint32_t wj = 0, wj1 = 0;                              // probe words of the current stride and of the next one
+    nm_tally t = {0, 0, 0, 0};
+    bool any_err = false;
+    uint64_t err_pos = ~0ULL;
+    for (;;) {
+        if (tid == 0) q_n = 0;
+        __syncthreads();
+        // ---- scan
+        for (;;) {
+            if (!bits) {
+                if (r >= NM_RES_WORDS / NM_RES_BLOCK) break;
+                cur = wbase + tid + (uint64_t)NM_RES_BLOCK * r;
+                r++;
+                if (cur >= n_need) { r = NM_RES_WORDS / NM_RES_BLOCK; break; }
+                bits = need[cur];
+                if (bits && probe) {
+                    wj = probe[cur]; wj1 = probe[cur + 1];
+                    const uint32_t zeros = wj & 0xFFu;     // positions repeated over more than kmax bases: element 0, as stored
+                    bits &= zeros >= 64 ? 0ULL : ~((1ULL << zeros) - 1ULL);
+                }
+                continue;
+            }
+            const uint32_t o = (uint32_t)__builtin_ctzll(bits);
+            const uint64_t p = cur * 64 + o;
+            const uint32_t ks = probe ? nm_probe_kstar(wj, wj1, o, NM_PROBE_STRIDE, kmax) : NM_PROBE_OPEN;
+            if (ks != NM_PROBE_OPEN && (!LIST || ks > kmax)) {
+                // (an open position has kmin unambiguous bases.)  Range mode: the probes fixed its least unique length
+                const uint32_t v = LIST ? 0u : nm_probe_element(ks, kmin, kmax, true);
+                if (v) nm_store(out, elem_bytes, p, v);
+                bits &= bits - 1;
+                continue;
+            }
+            const uint32_t slot = atomicAdd(&q_n, 1u);
+            if (slot >= NM_RES_QCAP) break;                // queue full: this bit waits for the next round
+            q_p[slot] = (uint32_t)(p - wbase * 64);
+            bits &= bits - 1;
+        }
+        __syncthreads();
+        // ---- walk
+        const uint32_t n_walk = q_n < NM_RES_QCAP ? q_n : NM_RES_QCAP;
+        for (uint32_t i = tid; i < n_walk; i += NM_RES_BLOCK) {
+            const uint64_t p = wbase * 64 + q_p[i];
+            bool amb0 = false, err = false;
+            const uint32_t v = LIST ? nm_fixed_k_one<BIG, true>(ix, enc, p, seq_len, list, n_list, amb0, err, t)
+                                    : nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
+            if (err) { any_err = true; if (p < err_pos) err_pos = p; }
+            nm_store(out, elem_bytes, p, v);
+        }
+        const bool done = !bits && r >= NM_RES_WORDS / NM_RES_BLOCK;
+        if (__syncthreads_and(done)) break;
+    }
+    (void)num_kmers;
+    if (__ballot(any_err)) {
+        if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
+        if ((tid & 63) == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
+    }
+    if (STATS) {
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), c = wave_sum(t.seeds);
+        if ((tid & 63) == 0 && (a | b | c)) {
+            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
+        }
+    }
 }
 
 // quad table from the seed table of the same length (nm_core.h: nm_quad_build_one)
@@ -665,20 +489,6 @@ __global__ __launch_bounds__(NM_BLOCK) void k_seed_level(nm_view ix, const uint6
     if (slot < n_slots) table[slot] = nm_seed_entry_from_parent<BIG>(ix, parent[nm_seed_parent_slot(slot, s)], slot, s);
 }
 
-// the pair table is a rearrangement of the seed table of level m+1
-__global__ __launch_bounds__(NM_BLOCK) void k_pair_gather(const uint64_t *__restrict__ seed, uint64_t *__restrict__ table,
-                                                          uint64_t first, uint64_t n_entries, uint32_t m) {
-    const uint64_t i = first + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
-    if (i < n_entries) table[i] = seed[nm_pair_seed_slot(i >> 3, m, (uint32_t)(i & 7))];
-}
-
-template <bool BIG>
-__global__ __launch_bounds__(NM_BLOCK) void k_pair(nm_view ix, uint64_t *__restrict__ table, uint64_t first,
-                                                   uint64_t n_entries, uint32_t m) {
-    const uint64_t i = first + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
-    if (i < n_entries) table[i] = nm_pair_entry<BIG>(ix, i >> 3, m, (uint32_t)(i & 7));
-}
-
 // ---- LF blocks (nm_format.h: nm_lf_entry): re-layout of the packed rank blocks, built at open ----
 template <bool BIG>
 __global__ __launch_bounds__(NM_BLOCK) void k_lf_blocks(nm_view ix, nm_lf_entry *__restrict__ lfb, uint64_t n_blocks) {
@@ -688,210 +498,6 @@ __global__ __launch_bounds__(NM_BLOCK) void k_lf_blocks(nm_view ix, nm_lf_entry 
     nm_lf_entries_of_block<BIG>(ix, b, e);
 #pragma unroll
     for (int c = 0; c < 4; c++) lfb[b * 4 + c] = e[c];
-}
-
-// ---- two-step rank blocks (nm_format.h: nm_rank2_block), built on the device at open -----------
-// one wave per block of 64 BWT rows: row -> (c1, c2) by one LF step, six ballots give the planes,
-// lanes 0..19 count the block's 16 pairs and 4 singles
-template <bool BIG>
-__global__ __launch_bounds__(NM_BLOCK) void k_rank2_planes(nm_view ix, nm_rank2_block *__restrict__ r2, uint64_t n_blocks,
-                                                           uint64_t *__restrict__ counts /* [20][n_blocks] */) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t b = (blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x) >> 6;
-    if (b >= n_blocks) return;                              // whole waves
-    const uint64_t i = b * 64 + lane;
-    uint32_t c1 = 0, c2 = 0;
-    bool v1 = false, v2 = false;
-    if (i < ix.n) {
-        v1 = nm_bwt_code(ix, i, c1);
-        if (v1) v2 = nm_bwt_code(ix, nm_lf<BIG>(ix, c1, i), c2);
-    }
-    const uint64_t valid1 = __ballot(v1), valid2 = __ballot(v2);
-    const uint64_t c1lo = __ballot(v1 && (c1 & 1u)), c1hi = __ballot(v1 && (c1 & 2u));
-    const uint64_t c2lo = __ballot(v2 && (c2 & 1u)), c2hi = __ballot(v2 && (c2 & 2u));
-    if (lane == 0) {
-        nm_rank2_block &o = r2[b];
-        o.c1lo = c1lo; o.c1hi = c1hi; o.c2lo = c2lo; o.c2hi = c2hi; o.valid1 = valid1; o.valid2 = valid2;
-    }
-    if (lane < 20) {
-        uint64_t m;
-        if (lane < 16) {
-            const uint32_t x = lane >> 2, y = lane & 3;
-            m = valid2 & ((x & 1u) ? c1lo : ~c1lo) & ((x & 2u) ? c1hi : ~c1hi) & ((y & 1u) ? c2lo : ~c2lo) & ((y & 2u) ? c2hi : ~c2hi);
-        } else {
-            const uint32_t x = lane - 16;
-            m = valid1 & ((x & 1u) ? c1lo : ~c1lo) & ((x & 2u) ? c1hi : ~c1hi);
-        }
-        counts[(uint64_t)lane * n_blocks + b] = (uint64_t)__popcll(m);
-    }
-}
-
-// counts[] now holds exclusive prefix sums per counter: make them superblock-relative and fill the
-// superblock table (first row of the suffixes starting "y x" + pairs before the superblock)
-template <bool BIG>
-__global__ __launch_bounds__(NM_BLOCK) void k_rank2_finish(nm_view ix, nm_rank2_block *__restrict__ r2, uint64_t n_blocks,
-                                                           const uint64_t *__restrict__ counts, uint64_t *__restrict__ superC2) {
-    const uint64_t t = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
-    const uint64_t b = t / 20;
-    const uint32_t c = (uint32_t)(t % 20);
-    if (b >= n_blocks) return;
-    const uint64_t per_super = 1ULL << (NM_SUPER_SHIFT - 6);
-    const uint64_t sb = b / per_super, b0 = sb * per_super;
-    const uint64_t at_super = counts[(uint64_t)c * n_blocks + b0];
-    const uint32_t rel = (uint32_t)(counts[(uint64_t)c * n_blocks + b] - at_super);
-    if (c < 16) r2[b].cnt2[c] = rel; else r2[b].cnt1[c - 16] = rel;
-    if (b == b0 && c < 16) {
-        const uint32_t x = c >> 2, y = c & 3;
-        superC2[sb * 16 + c] = nm_lf<BIG>(ix, y, ix.C[x]) + at_super;
-    }
-}
-
-// ---- k_min_unique_v2: persistent waves, one lane = one position AT A TIME --------------------
-// Same arithmetic as k_min_unique (nm_min_unique_one), different schedule.  In the simple kernel a
-// wave runs as long as its slowest lane: with ~3 LF steps on average but a long tail, most lanes
-// idle.  Here every wave owns a queue of positions (chunks of NM_CHUNK consecutive positions taken
-// from a global counter); a lane that finishes its position takes the next one in the same loop
-// iteration, so every iteration every lane issues exactly one dependent memory round trip:
-//     SEED lane: its seed-table entry           STEP lane: the two rank blocks of lo and hi
-// The chunk's encoded words (18 x 32 B) are staged in LDS, one coalesced load per chunk,
-// prefetched one chunk ahead; a lane builds its 64-base window from LDS without touching HBM.
-#define NM_CHUNK 1024u
-#define NM_CHUNK_WORDS 18u
-enum { NM_IDLE = 0, NM_SEED = 1, NM_STEP = 2 };
-
-__device__ __forceinline__ uint64_t nm_wave_bcast64(uint64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
-template <bool BIG, bool STATS>
-__global__ __launch_bounds__(NM_BLOCK) void k_min_unique_v2(nm_view ix, const nm_enc_word *__restrict__ enc,
-                                                            uint64_t n_enc_words, uint64_t num_kmers,
-                                                            uint32_t kmin, uint32_t kmax, void *__restrict__ out,
-                                                            int elem_bytes, uint64_t *__restrict__ status,
-                                                            unsigned long long *__restrict__ work) {
-    __shared__ nm_enc_word s_words[NM_BLOCK / NM_WAVE][NM_CHUNK_WORDS];
-    const uint32_t lane = threadIdx.x & 63;
-    nm_enc_word *sw = s_words[threadIdx.x >> 6];
-    const uint32_t s = ix.seed_len;
-    const bool use_seed = s && kmin >= s;
-    const uint64_t seed_mask = (1ULL << s) - 1ULL;
-
-    // wave-uniform queue state
-    uint64_t chunk_base = 0, next_base;
-    uint32_t chunk_len = 0, chunk_next = 0;
-    bool more = true;
-    nm_enc_word pre = {0, 0, 0, 0};
-    auto grab = [&]() {
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(work, (unsigned long long)NM_CHUNK);
-        next_base = nm_wave_bcast64(b);
-        if (next_base < num_kmers && lane < NM_CHUNK_WORDS) {
-            uint64_t w = (next_base >> 6) + lane;
-            if (w >= n_enc_words) w = n_enc_words - 1;          // padding words are all-ambiguous
-            pre = enc[w];
-        }
-    };
-    grab();
-
-    // per-lane search state
-    uint32_t state = NM_IDLE, k = 0, kbase = 0;
-    uint64_t p = 0, lo = 0, hi = 0, slot = 0;
-    nm_window w = {0, 0, 0};
-    uint32_t n_amb = 0;
-    nm_tally t = {0, 0, 0, 0};
-    uint32_t n_done = 0;
-
-    for (uint32_t guard = 0; guard < (1u << 24); guard++) {      // every wave reaches an exit
-        // ---- advance to the prefetched chunk when the current one is used up
-        if (chunk_next >= chunk_len && more) {
-            chunk_base = next_base;
-            if (chunk_base >= num_kmers) { more = false; chunk_len = 0; chunk_next = 0; }
-            else {
-                const uint64_t left = num_kmers - chunk_base;
-                chunk_len = left < NM_CHUNK ? (uint32_t)left : NM_CHUNK;
-                chunk_next = 0;
-                if (lane < NM_CHUNK_WORDS) sw[lane] = pre;
-                __builtin_amdgcn_wave_barrier();
-                grab();
-            }
-        }
-        // ---- hand the next positions of the chunk to idle lanes
-        const uint64_t idle_mask = __ballot(state == NM_IDLE);
-        const uint32_t rem = chunk_len - chunk_next;
-        if (idle_mask && rem) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-            if (state == NM_IDLE && rank < rem) {
-                const uint32_t q = chunk_next + rank;
-                p = chunk_base + q;
-                w = nm_window_from(sw[q >> 6], sw[(q >> 6) + 1], q & 63);
-                kbase = 0;
-                if (w.amb & 1ULL) { n_amb++; nm_store(out, elem_bytes, p, 0); }
-                else if (use_seed) {
-                    if (w.amb & seed_mask) nm_store(out, elem_bytes, p, 0);      // U_p < s <= kmin
-                    else { slot = nm_seed_slot(w, s); state = NM_SEED; if (STATS) n_done++; }
-                } else { lo = 0; hi = ix.n; k = 0; state = NM_STEP; if (STATS) n_done++; }
-                if (STATS && state == NM_IDLE && !(w.amb & 1ULL)) n_done++;
-            }
-            const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-            chunk_next += n_idle < rem ? n_idle : rem;
-        }
-        if (!__ballot(state != NM_IDLE)) {
-            if (!more && chunk_next >= chunk_len) break;
-            continue;
-        }
-        // ---- one memory round trip per lane
-        nm_blk ba = {0, 0, 0, 0, 0, 0}, bb = {0, 0, 0, 0, 0, 0};
-        uint64_t e = 0;
-        if (state == NM_STEP) { ba = nm_load_blk(ix, lo); bb = nm_load_blk(ix, hi); }
-        else if (state == NM_SEED) e = NM_SEED_LOAD(ix, slot);
-        // ---- consume it
-        if (state == NM_SEED) {
-            const uint32_t c = (uint32_t)(e >> NM_SEED_LO_BITS);
-            if (c != NM_SEED_CNT_SAT) { lo = e & NM_SEED_LO_MASK; hi = lo + c; k = s; }
-            else { lo = 0; hi = ix.n; k = 0; }
-            state = NM_STEP;
-            if (STATS) t.seeds++;
-        } else if (state == NM_STEP) {
-            const uint32_t c = 3u - nm_window_code(w, k - kbase);
-            if (STATS) { t.steps++; t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u; }
-            lo = nm_lf_blk<BIG>(ix, c, lo, ba);
-            hi = nm_lf_blk<BIG>(ix, c, hi, bb);
-            k++;
-        }
-        // ---- decide: finished, or which base comes next
-        if (state == NM_STEP) {
-            const uint64_t cnt = hi - lo;
-            uint32_t result = 0;
-            bool done = true;
-            if (cnt == 0) {                                         // search.py:699-722
-                atomicMin((unsigned long long *)&status[2], (unsigned long long)p);
-                atomicOr((unsigned long long *)&status[1], 1ULL);
-            } else if (cnt == 1) {
-                const uint32_t ans = k > kmin ? k : kmin;
-                result = nm_all_valid(enc, p, w, kbase, k, ans) ? ans : 0u;
-            } else if (k < kmax) {
-                uint32_t j = k - kbase;
-                if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
-                done = ((w.amb >> j) & 1ULL) != 0;                  // k == U_p and still not unique
-            }
-            if (done) { nm_store(out, elem_bytes, p, result); state = NM_IDLE; }
-        }
-    }
-    // ---- wave totals
-    const uint32_t amb_sum = wave_sum(n_amb);
-    if (lane == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
-    if (STATS) {
-        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), c = wave_sum(t.seeds), d = wave_sum(n_done);
-        if (lane == 0) {
-            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
-            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
-            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
-            atomicAdd((unsigned long long *)&status[7], (unsigned long long)d);
-        }
-    }
 }
 
 template <bool BIG, bool RC, bool STATS>
@@ -975,45 +581,46 @@ struct nm_index {
     void *d_rank = nullptr, *d_strand = nullptr, *d_sep = nullptr, *d_seed = nullptr, *d_super = nullptr;
     void *d_seed2 = nullptr;              // small secondary seed table (nm_view_for)
     uint32_t seed2_len = 0;
-    void *d_quad = nullptr;               // quad table (k_min_unique_quad)
-    void *d_pair = nullptr;               // pair table (k_min_unique_pair)
-    void *d_rank2 = nullptr, *d_super2 = nullptr;   // two-step rank blocks + their superblock table
+    void *d_quad = nullptr;               // quad table (k_sites)
     void *d_lfb = nullptr;                // LF blocks
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     // scratch owned by the handle (grown on demand)
-    nm_buffer enc, seq, out, status, ks, starts, lens, work, settled, coarse;
+    nm_buffer enc, seq, out, status, ks, starts, lens, work, settled, coarse, need;
     uint64_t coarse_min = 32ull << 20;    // launches of at least this many positions also run the coarse probes (NEWMAP_AMD_COARSE_MIN) ...
     int coarse_mode = 1;                  // ... 1: once an earlier launch has met long repeats, 2: always, 0: never (NEWMAP_AMD_COARSE)
     uint32_t *h_repeats_seen = nullptr;   // pinned word the fine probes set; d_repeats_seen = its device address
     uint32_t *d_repeats_seen = nullptr;
     uint32_t *d_seen_latch = nullptr;     // device-side copy of the flag
     bool list_via_range = true;           // list mode with one length runs on the range kernels (NM_OPT_LIST_VIA_RANGE, A/B)
-    int quad_block = 256;                 // workgroup size of k_min_unique_quad (64 or 256, NEWMAP_AMD_QUAD_BLOCK)
     bool repeat_probes = true;            // k_repeat_probe before the both-strand range kernels (NM_OPT_REPEAT_PROBES)
     uint64_t enc_words = 0;               // words written by the last nm_encode
-    int kernel_version = 0;               // 0 = automatic (pair kernel when its table exists, else 1); 1..4 force a kernel
-    unsigned persistent_blocks = 2048;    // set from the device properties at open
+    int kernel_version = 0;               // 0 = automatic (sites when the quad table applies, else 1); 1 / 5 force a kernel
+    uint32_t site_d_cap = NM_SITE_MAX_D;  // measurement knob (NEWMAP_AMD_SITE_D): cap on d = kmin - window of the sites
     bool count_steps = false;
     int last_kernel = 0;                  // which range kernel the last launch used (nm_index_info 8)
-    // NM_OPT_TIMING: HIP events around every search-kernel launch, on the launch stream
+    // NM_OPT_TIMING: HIP events on the launch stream, two kinds of start/stop pairs:
+    // kind 0 around the dominant search kernel of a segment (k_sites / k_min_unique / k_fixed_k), kind 1 around ALL the
+    // kernels of the segment (encode pass, sites, probes, resolve)
     bool timing = false;
-    std::vector<hipEvent_t> ev_pool;      // start/stop pairs, reused
-    size_t ev_used = 0;                   // events consumed since the last read
+    std::vector<hipEvent_t> ev_pool[2];   // start/stop pairs, reused
+    size_t ev_used[2] = {0, 0};           // events consumed since the last read
 };
 
 struct nm_timed {                         // records start on construction, stop on destruction
     nm_index *ix; hipStream_t st; hipEvent_t stop = nullptr;
-    nm_timed(nm_index *ix_, hipStream_t st_) : ix(ix_), st(st_) {
+    nm_timed(nm_index *ix_, hipStream_t st_, int kind = 0) : ix(ix_), st(st_) {
         if (!ix->timing) return;
-        if (ix->ev_used + 2 > ix->ev_pool.size()) {
+        std::vector<hipEvent_t> &pool = ix->ev_pool[kind];
+        size_t &used = ix->ev_used[kind];
+        if (used + 2 > pool.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-            ix->ev_pool.push_back(a); ix->ev_pool.push_back(b);
+            pool.push_back(a); pool.push_back(b);
         }
-        (void)hipEventRecord(ix->ev_pool[ix->ev_used], st);
-        stop = ix->ev_pool[ix->ev_used + 1];
-        ix->ev_used += 2;
+        (void)hipEventRecord(pool[used], st);
+        stop = pool[used + 1];
+        used += 2;
     }
     ~nm_timed() { if (stop) (void)hipEventRecord(stop, st); }
 };
@@ -1164,71 +771,6 @@ static int nm_build_lf_blocks(nm_index *ix) {
     return NM_OK;
 }
 
-// two-step rank blocks: 128 B per 64 BWT rows, derived on the device from the one-step structure
-static int nm_build_rank2(nm_index *ix) {
-    const uint64_t n_blocks = ix->h.n / 64 + 1;
-    void *d_counts = nullptr, *d_scratch = nullptr, *d_total = nullptr;
-    HIP_TRY(hipMalloc(&ix->d_rank2, n_blocks * sizeof(nm_rank2_block)));
-    HIP_TRY(hipMalloc(&ix->d_super2, (uint64_t)ix->h.n_super * 16 * sizeof(uint64_t)));
-    ix->device_bytes += n_blocks * sizeof(nm_rank2_block);
-    const uint64_t scratch_n = n_blocks / TILE + n_blocks / ((uint64_t)TILE * TILE) + 8192;
-    int rc = NM_OK;
-    if (hipMalloc(&d_counts, 20 * n_blocks * sizeof(uint64_t)) != hipSuccess || hipMalloc(&d_scratch, scratch_n * 8) != hipSuccess ||
-        hipMalloc(&d_total, 16) != hipSuccess) {
-        nm_set_error("hipMalloc failed while building the two-step rank blocks");
-        rc = NM_E_ALLOC;
-    }
-    nm_view v = ix->view;
-    if (rc == NM_OK) {
-        const dim3 block(NM_BLOCK);
-        const unsigned g1 = nm_grid(n_blocks * 64);
-        if (ix->big) hipLaunchKernelGGL(k_rank2_planes<true>, dim3(g1), block, 0, ix->stream, v, (nm_rank2_block *)ix->d_rank2, n_blocks, (uint64_t *)d_counts);
-        else         hipLaunchKernelGGL(k_rank2_planes<false>, dim3(g1), block, 0, ix->stream, v, (nm_rank2_block *)ix->d_rank2, n_blocks, (uint64_t *)d_counts);
-        for (int c = 0; c < 20 && rc == NM_OK; c++)
-            rc = scan_exclusive((uint64_t *)d_counts + (uint64_t)c * n_blocks, n_blocks, (uint64_t *)d_scratch, (uint64_t *)d_total, ix->stream);
-        if (rc == NM_OK) {
-            const unsigned g2 = nm_grid(n_blocks * 20);
-            if (ix->big) hipLaunchKernelGGL(k_rank2_finish<true>, dim3(g2), block, 0, ix->stream, v, (nm_rank2_block *)ix->d_rank2, n_blocks, (const uint64_t *)d_counts, (uint64_t *)ix->d_super2);
-            else         hipLaunchKernelGGL(k_rank2_finish<false>, dim3(g2), block, 0, ix->stream, v, (nm_rank2_block *)ix->d_rank2, n_blocks, (const uint64_t *)d_counts, (uint64_t *)ix->d_super2);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess) { nm_set_error("building the two-step rank blocks failed"); rc = NM_E_DEVICE; }
-        }
-    }
-    if (d_counts) (void)hipFree(d_counts);
-    if (d_scratch) (void)hipFree(d_scratch);
-    if (d_total) (void)hipFree(d_total);
-    if (rc == NM_OK) {
-        ix->view.rank2 = (const nm_rank2_block *)ix->d_rank2;
-        ix->view.superC2 = (const uint64_t *)ix->d_super2;
-    }
-    return rc;
-}
-
-// pair table for cores of m bases: 4^m blocks x 8 entries x 8 bytes
-static int nm_build_pair(nm_index *ix, uint32_t m) {
-    ix->view.pair = nullptr;
-    ix->view.pair_m = 0;
-    if (m < 3 || ix->h.n < 2) return NM_OK;
-    const uint64_t n_entries = 8ULL << (2 * m);
-    HIP_TRY(hipMalloc(&ix->d_pair, n_entries * sizeof(uint64_t)));
-    ix->device_bytes += n_entries * sizeof(uint64_t);
-    nm_view v = ix->view;
-    v.seed = nullptr;
-    v.seed_len = 0;
-    const uint64_t slice = 1ULL << 30;
-    const bool gather = ix->view.seed && ix->view.seed_len == m + 1;      // rearrange the seed table
-    for (uint64_t first = 0; first < n_entries; first += slice) {
-        const uint64_t cnt = n_entries - first < slice ? n_entries - first : slice;
-        if (gather) hipLaunchKernelGGL(k_pair_gather, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, ix->view.seed, (uint64_t *)ix->d_pair, first, n_entries, m);
-        else if (ix->big) hipLaunchKernelGGL(k_pair<true>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_pair, first, n_entries, m);
-        else         hipLaunchKernelGGL(k_pair<false>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_pair, first, n_entries, m);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipStreamSynchronize(ix->stream));
-    ix->view.pair = (const uint64_t *)ix->d_pair;
-    ix->view.pair_m = m;
-    return NM_OK;
-}
-
 static int nm_build_seed(nm_index *ix, uint32_t s, uint32_t quad_m = 0) {
     ix->view.seed = nullptr;
     ix->view.seed_len = 0;
@@ -1350,10 +892,6 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.seed_len = 0;
     v.n_super = (uint32_t)h.n_super;
     v.seed_policy = 0;
-    v.pair_m = 0;
-    v.pair = nullptr;
-    v.rank2 = nullptr;
-    v.superC2 = nullptr;
     v.lfb = nullptr;
     v.quad = nullptr;
     v.quad_m = 0;
@@ -1386,10 +924,9 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     }
     rc = nm_build_seed(ix, s, quad_m);
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
-    const bool have_quad = ix->view.quad != nullptr;
-    if (const char *qb = getenv("NEWMAP_AMD_QUAD_BLOCK")) ix->quad_block = atoi(qb) == 64 ? 64 : 256;
     if (const char *cm = getenv("NEWMAP_AMD_COARSE_MIN")) ix->coarse_min = strtoull(cm, nullptr, 10);
     if (const char *cm = getenv("NEWMAP_AMD_COARSE")) ix->coarse_mode = atoi(cm);
+    if (const char *sd = getenv("NEWMAP_AMD_SITE_D")) { ix->site_d_cap = (uint32_t)atoi(sd); if (ix->site_d_cap > NM_SITE_MAX_D) ix->site_d_cap = NM_SITE_MAX_D; }
     if (hipHostMalloc((void **)&ix->h_repeats_seen, 64, hipHostMallocMapped) == hipSuccess) {
         *ix->h_repeats_seen = 0;
         if (hipHostGetDevicePointer((void **)&ix->d_repeats_seen, ix->h_repeats_seen, 0) != hipSuccess ||
@@ -1401,34 +938,9 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         (void)hipGetLastError();
         ix->h_repeats_seen = nullptr;
     }
-    const char *force_pair = getenv("NEWMAP_AMD_PAIR");
-    if (seed_len_override < -1 && s >= 5 && (!have_quad || (force_pair && force_pair[0] == '1'))) {
-        // without a quad table: the pair table (cores of s-1 bases, same resolution as the
-        // seed table, twice its bytes) unless it would take more than 40 % of the free HBM
-        uint32_t m = s - 1 > 15 ? 15 : s - 1;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (m > 4 && (64ULL << (2 * m)) > free_b * 2 / 5) m--;   // at most 40 % of what is still free
-        rc = nm_build_pair(ix, m);
-        if (rc != NM_OK) { nm_index_close(ix); return rc; }
-    }
-    if (seed_len_override < -1 && ix->h.n >= 2) {
-        // opt-in (NEWMAP_AMD_TWO_STEP=1): the two-step rank blocks, 2 bytes per BWT row; measured no faster
-        // than one-step walks, kept for A/B
-        const char *on = getenv("NEWMAP_AMD_TWO_STEP");
-        if (on && on[0] == '1') {
-            rc = nm_build_rank2(ix);
-            if (rc != NM_OK) { nm_index_close(ix); return rc; }
-        }
-    }
     rc = nm_grow(ix->status, NM_STATUS_WORDS * sizeof(uint64_t));
     if (rc == NM_OK) rc = nm_grow(ix->work, NM_WORK_WORDS * sizeof(unsigned long long));
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            ix->persistent_blocks = (unsigned)prop.multiProcessorCount * 8u;    // 8 x 256 threads = 32 waves / CU
-    }
     *out = ix;
     return NM_OK;
 }
@@ -1437,13 +949,13 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_pair, ix->d_quad, ix->d_rank2, ix->d_super2, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
-                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p, ix->settled.p, ix->coarse.p};
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
+                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p, ix->settled.p, ix->coarse.p, ix->need.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ix->h_repeats_seen) (void)hipHostFree(ix->h_repeats_seen);
     if (ix->d_seen_latch) (void)hipFree(ix->d_seen_latch);
-    for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
+    for (auto &pool : ix->ev_pool) for (hipEvent_t e : pool) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -1460,10 +972,10 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 6: return ix->device_bytes;
         case 7: return ix->h.sa_ratio;
         case 8: return (uint64_t)ix->last_kernel;
-        case 9: return ix->view.pair_m;
+        case 9: return 0;                                  // (pair table: removed)
         case 10: return (uint64_t)ix->device;
         case 11: return ix->view.lfb ? 1 : 0;
-        case 12: return ix->view.rank2 ? 1 : 0;
+        case 12: return 0;                                 // (two-step rank blocks: removed)
         case 13: return ix->repeat_probes ? 1 : 0;
         case 18: return ix->view.quad_m;
         case 14: case 15: case 16: case 17: {              // probe tally of the last range-mode launch
@@ -1479,14 +991,9 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
 extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
     if (option == NM_OPT_COUNT_STEPS) { ix->count_steps = value != 0; return NM_OK; }
-    if (option == NM_OPT_TIMING) { ix->timing = value != 0; ix->ev_used = 0; return NM_OK; }
+    if (option == NM_OPT_TIMING) { ix->timing = value != 0; ix->ev_used[0] = ix->ev_used[1] = 0; return NM_OK; }
     if (option == NM_OPT_LF_BLOCKS) {      // A/B: LF steps read the 16-byte LF entries (if built) or the packed blocks
         ix->view.lfb = value ? (const nm_lf_entry *)ix->d_lfb : nullptr;
-        return NM_OK;
-    }
-    if (option == NM_OPT_TWO_STEP) {       // A/B: walks use the two-step rank blocks (if built) or the one-step ones
-        ix->view.rank2 = value ? (const nm_rank2_block *)ix->d_rank2 : nullptr;
-        ix->view.superC2 = value ? (const uint64_t *)ix->d_super2 : nullptr;
         return NM_OK;
     }
     if (option == NM_OPT_SEED_POLICY) {
@@ -1507,35 +1014,36 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_KERNEL) {
-        if (value < 0 || value > 5) { nm_set_error("kernel version must be 0..5"); return NM_E_ARGUMENT; }
+        if (value != 0 && value != 1 && value != 5) { nm_set_error("kernel version must be 0 (automatic), 1 (one lane per position) or 5 (sites)"); return NM_E_ARGUMENT; }
         ix->kernel_version = (int)value;
-        return NM_OK;
-    }
-    if (option == NM_OPT_PERSISTENT_BLOCKS) {
-        if (value < 1 || value > 65536) { nm_set_error("persistent block count out of range"); return NM_E_ARGUMENT; }
-        ix->persistent_blocks = (unsigned)value;
         return NM_OK;
     }
     nm_set_error("unknown option %d", option);
     return NM_E_ARGUMENT;
 }
 
-extern "C" int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_ms, double *max_ms) {
+extern "C" int nm_timing_read_kind(nm_index *ix, int kind, uint64_t *n_launches, double *total_ms, double *max_ms) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
+    if (kind != 0 && kind != 1) { nm_set_error("timing kind must be 0 (dominant kernel) or 1 (all kernels of a segment)"); return NM_E_ARGUMENT; }
     HIP_TRY(hipSetDevice(ix->device));
     double total = 0.0, mx = 0.0;
-    for (size_t i = 0; i + 1 < ix->ev_used; i += 2) {
-        HIP_TRY(hipEventSynchronize(ix->ev_pool[i + 1]));
+    std::vector<hipEvent_t> &pool = ix->ev_pool[kind];
+    for (size_t i = 0; i + 1 < ix->ev_used[kind]; i += 2) {
+        HIP_TRY(hipEventSynchronize(pool[i + 1]));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ix->ev_pool[i], ix->ev_pool[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, pool[i], pool[i + 1]));
         total += ms;
         if (ms > mx) mx = ms;
     }
-    if (n_launches) *n_launches = ix->ev_used / 2;
+    if (n_launches) *n_launches = ix->ev_used[kind] / 2;
     if (total_ms) *total_ms = total;
     if (max_ms) *max_ms = mx;
-    ix->ev_used = 0;
+    ix->ev_used[kind] = 0;
     return NM_OK;
+}
+
+extern "C" int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_ms, double *max_ms) {
+    return nm_timing_read_kind(ix, 0, n_launches, total_ms, max_ms);
 }
 
 // -------------------------------------------------------------------------- launch helpers --
@@ -1570,9 +1078,11 @@ static int nm_check_segment_args(const nm_index *ix, uint64_t seq_len, uint64_t 
     return NM_OK;
 }
 
-// the repeat probes of a launch over `n` positions: (coarse probes for large launches,) fine probes -> ix->settled
+// the repeat probes of a launch over `n` positions: (coarse probes for large launches,) fine probes -> ix->settled.
+// need != nullptr (after k_sites): only the strides whose positions are mostly open get a probe.
 template <bool BIG>
-static int nm_launch_probes(nm_index *ix, const nm_view &view, uint64_t n, uint32_t kmax, hipStream_t st, const uint32_t **words) {
+static int nm_launch_probes(nm_index *ix, const nm_view &view, uint64_t n, uint32_t kmax, hipStream_t st, const uint32_t **words,
+                            const uint64_t *need = nullptr) {
     const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
     const uint64_t n_probes = (n + NM_PROBE_STRIDE - 1) / NM_PROBE_STRIDE;
@@ -1584,77 +1094,66 @@ static int nm_launch_probes(nm_index *ix, const nm_view &view, uint64_t n, uint3
     if (n >= ix->coarse_min && (ix->coarse_mode == 2 || (ix->coarse_mode == 1 && repeats_met))) {
         const uint64_t n_coarse = (n + NM_COARSE_STRIDE - 1) / NM_COARSE_STRIDE;
         if ((rc = nm_grow(ix->coarse, n_coarse * sizeof(uint32_t))) != NM_OK) return rc;
-        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally);
-        else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally);
+        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally, need, n_probes);
+        else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally, need, n_probes);
         coarse = (const uint32_t *)ix->coarse.p;
     }
-    if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch);
-    else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch);
+    if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes);
+    else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes);
     *words = (const uint32_t *)ix->settled.p;
+    return NM_OK;
+}
+
+// can the sites (k_sites + k_resolve) take a both-strand search whose shortest length is kmin?
+static bool nm_sites_apply(const nm_index *ix, const nm_view &view, uint32_t kmin) {
+    return (ix->kernel_version == 0 || ix->kernel_version == 5) && view.quad && kmin >= view.quad_m + NM_QUAD_EXT && kmin <= NM_SITE_MAX_KMIN;
+}
+
+// k_sites -> repeat probes where the bitmap is dense -> k_resolve, over positions [0, n).  Range mode: kmin .. kmax.
+// List mode (d_list != nullptr): kmin = the first listed length, kmax = the longest.
+template <bool BIG>
+static int launch_sites(nm_index *ix, const nm_view &view, uint64_t n, uint32_t kmin, uint32_t kmax, void *d_out, int elem_bytes,
+                        uint64_t *d_status, hipStream_t st, uint64_t seq_len = 0, const uint32_t *d_list = nullptr, uint32_t n_list = 0) {
+    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    const uint64_t n_need = (n + 63) / 64;
+    int rc = nm_grow(ix->need, (n_need + 1) * sizeof(uint64_t));
+    if (rc != NM_OK) return rc;
+    uint64_t *need = (uint64_t *)ix->need.p;
+    uint32_t d = kmin - (view.quad_m + NM_QUAD_EXT);
+    if (d > ix->site_d_cap) d = ix->site_d_cap;
+    const uint32_t bp = nm_site_block_positions(d);
+    const dim3 sgrid((unsigned)((n + bp - 1) / bp)), sblock(NM_SITE_BLOCK);
+    const size_t lds = nm_site_lds_bytes(d);
+    ix->last_kernel = 5;
+    {
+        nm_timed timed(ix, st);
+        if (ix->count_steps) hipLaunchKernelGGL((k_sites<true>), sgrid, sblock, lds, st, view, enc, ix->enc_words, n, kmin, d, d_out, elem_bytes, d_status, need);
+        else                 hipLaunchKernelGGL((k_sites<false>), sgrid, sblock, lds, st, view, enc, ix->enc_words, n, kmin, d, d_out, elem_bytes, d_status, need);
+    }
+    const uint32_t *probe = nullptr;
+    if (ix->repeat_probes && (rc = nm_launch_probes<BIG>(ix, view, n, kmax, st, &probe, need)) != NM_OK) return rc;
+    const dim3 rgrid((unsigned)((n_need + NM_RES_WORDS - 1) / NM_RES_WORDS)), rblock(NM_RES_BLOCK);
+#define NM_LAUNCH_RES(STATS_, LIST_) hipLaunchKernelGGL((k_resolve<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, \
+                                                        d_status, (const uint64_t *)need, n_need, probe, seq_len, d_list, n_list)
+    if (d_list) { if (ix->count_steps) NM_LAUNCH_RES(true, true); else NM_LAUNCH_RES(false, true); }
+    else        { if (ix->count_steps) NM_LAUNCH_RES(true, false); else NM_LAUNCH_RES(false, false); }
+#undef NM_LAUNCH_RES
     return NM_OK;
 }
 
 template <bool BIG, bool RC>
 static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, void *d_out,
                               int elem_bytes, uint64_t *d_status, hipStream_t st) {
+    if (RC && nm_sites_apply(ix, view, kmin)) return launch_sites<BIG>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st);
     const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
-    const bool quad_kernel = RC && (ix->kernel_version == 5 || ix->kernel_version == 0) && view.quad && kmin >= view.quad_m + NM_QUAD_EXT &&
-                             kmin <= NM_QUAD_MAX_KMIN;
-    const bool pair_kernel = !quad_kernel && RC && (ix->kernel_version == 4 || ix->kernel_version == 0) && view.pair && kmin >= view.pair_m + 1;
-    // repeat probes feed the kernels that take the probe words: the quad and pair kernels and k_min_unique
+    // one lane per position; on both strands the repeat probes run first (every stride: there is no bitmap to gate them)
     const uint32_t *settled = nullptr;
-    if (RC && ix->repeat_probes && ix->kernel_version != 2 && ix->kernel_version != 3) {   // (versions 4 and 5 fall back to 1 without their table)
+    if (RC && ix->repeat_probes) {
         const int rc = nm_launch_probes<BIG>(ix, view, num_kmers, kmax, st, &settled);
         if (rc != NM_OK) return rc;
     }
     nm_timed timed(ix, st);
-    if (RC && ix->kernel_version == 2) {
-        ix->last_kernel = 2;
-        // persistent grid: enough waves to fill the chip, never more than there are chunks
-        const uint64_t chunks = (num_kmers + NM_CHUNK - 1) / NM_CHUNK;
-        uint64_t blocks = (chunks + NM_BLOCK / NM_WAVE - 1) / (NM_BLOCK / NM_WAVE);
-        if (blocks > ix->persistent_blocks) blocks = ix->persistent_blocks;
-        const dim3 pgrid((unsigned)blocks);
-        unsigned long long *work = (unsigned long long *)ix->work.p;
-        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_v2<BIG, true>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
-        else                 hipLaunchKernelGGL((k_min_unique_v2<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, work);
-        return NM_OK;
-    }
-    if (quad_kernel) {
-        const unsigned qb = ix->quad_block == 64 ? 64u : 256u;
-        const uint64_t per_block = (uint64_t)(qb / NM_WAVE) * NM_QUAD_PER_WAVE;
-        const dim3 qgrid((unsigned)((num_kmers + per_block - 1) / per_block)), qblock(qb);
-        ix->last_kernel = 5;
-        const bool longk = kmin > 60;
-#define NM_LAUNCH_QUAD(STATS_, QB_, LONG_) hipLaunchKernelGGL((k_min_unique_quad<BIG, STATS_, QB_, LONG_>), qgrid, qblock, 0, st, view, enc, ix->enc_words, \
-                                                              num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled)
-        if (qb == 64) {
-            if (ix->count_steps) { if (longk) NM_LAUNCH_QUAD(true, 64, true); else NM_LAUNCH_QUAD(true, 64, false); }
-            else                 { if (longk) NM_LAUNCH_QUAD(false, 64, true); else NM_LAUNCH_QUAD(false, 64, false); }
-        } else {
-            if (ix->count_steps) { if (longk) NM_LAUNCH_QUAD(true, 256, true); else NM_LAUNCH_QUAD(true, 256, false); }
-            else                 { if (longk) NM_LAUNCH_QUAD(false, 256, true); else NM_LAUNCH_QUAD(false, 256, false); }
-        }
-#undef NM_LAUNCH_QUAD
-        return NM_OK;
-    }
-    if (pair_kernel) {
-        const uint64_t per_block = (uint64_t)NM_BLOCK * 2;
-        const dim3 pgrid((unsigned)((num_kmers + per_block - 1) / per_block));
-        ix->last_kernel = 4;
-        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_pair<BIG, true>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
-        else                 hipLaunchKernelGGL((k_min_unique_pair<BIG, false>), pgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
-        return NM_OK;
-    }
-    if (ix->kernel_version == 3) {
-        ix->last_kernel = 3;
-        const uint64_t per_block = (uint64_t)NM_BLOCK * NM_MP;
-        const dim3 mgrid((unsigned)((num_kmers + per_block - 1) / per_block));
-        if (ix->count_steps) hipLaunchKernelGGL((k_min_unique_mp<BIG, RC, true>), mgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
-        else                 hipLaunchKernelGGL((k_min_unique_mp<BIG, RC, false>), mgrid, block, 0, st, view, enc, ix->enc_words, num_kmers, kmin, kmax, d_out, elem_bytes, d_status);
-        return NM_OK;
-    }
     const dim3 grid(nm_grid(num_kmers));
     ix->last_kernel = 1;
     if (ix->count_steps) hipLaunchKernelGGL((k_min_unique<BIG, RC, true>), grid, block, 0, st, view, enc, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, settled);
@@ -1673,38 +1172,16 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
     if (num_kmers == 0) return nm_reset_status(ix, d_status, st);
-    if ((rc = nm_encode(ix, d_seq, seq_len, st, d_status)) != NM_OK) return rc;
     nm_view view;
     if ((rc = nm_view_for(ix, kmin, &view)) != NM_OK) return rc;
+    nm_timed whole(ix, st, 1);
+    if ((rc = nm_encode(ix, d_seq, seq_len, st, d_status)) != NM_OK) return rc;
     if (ix->big) rc = use_revcomp ? launch_min_unique<true, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st)
                                   : launch_min_unique<true, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st);
     else         rc = use_revcomp ? launch_min_unique<false, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st)
                                   : launch_min_unique<false, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st);
     if (rc != NM_OK) return rc;
     HIP_TRY(hipGetLastError());
-    return NM_OK;
-}
-
-// list mode with several lengths on the quad kernel (LIST instantiation): positions [0, head), whose longest k-mer
-// lies inside the data.  The caller has checked: quad table, every length >= its window, first length <= 124.
-template <bool BIG>
-static int launch_list_quad(nm_index *ix, const nm_view &view, uint64_t seq_len, uint64_t head, uint32_t k_first, uint32_t k_longest,
-                            const uint32_t *d_ks, uint32_t nk, void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st) {
-    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
-    const uint32_t *settled = nullptr;
-    if (ix->repeat_probes) {
-        const int rc = nm_launch_probes<BIG>(ix, view, head, k_longest, st, &settled);
-        if (rc != NM_OK) return rc;
-    }
-    nm_timed timed(ix, st);
-    const uint64_t per_block = (uint64_t)(256 / NM_WAVE) * NM_QUAD_PER_WAVE;
-    const dim3 qgrid((unsigned)((head + per_block - 1) / per_block)), qblock(256);
-    ix->last_kernel = 5;
-#define NM_LAUNCH_LIST(STATS_, LONG_) hipLaunchKernelGGL((k_min_unique_quad<BIG, STATS_, 256, LONG_, true>), qgrid, qblock, 0, st, view, enc, ix->enc_words, \
-                                                          head, k_first, k_longest, d_out, elem_bytes, d_status, settled, seq_len, d_ks, nk)
-    if (ix->count_steps) { if (k_first > 60) NM_LAUNCH_LIST(true, true); else NM_LAUNCH_LIST(true, false); }
-    else                 { if (k_first > 60) NM_LAUNCH_LIST(false, true); else NM_LAUNCH_LIST(false, false); }
-#undef NM_LAUNCH_LIST
     return NM_OK;
 }
 
@@ -1735,6 +1212,7 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
     if ((rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
     if (num_kmers == 0) return NM_OK;
+    nm_timed whole(ix, st, 1);
     if ((rc = nm_grow(ix->ks, (uint64_t)nk * sizeof(uint32_t))) != NM_OK) return rc;
     HIP_TRY(hipMemcpyAsync(ix->ks.p, ks, (uint64_t)nk * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
@@ -1748,7 +1226,7 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     // range kernels with their tables and repeat probes; the up to K-1 positions at the end of the data, whose
     // k-mer the reference truncates (search.py:590), keep the list kernel.
     uint64_t first = 0;
-    if (nk == 1 && use_revcomp && ix->list_via_range && (view.quad || view.pair) && seq_len >= ks[0]) {
+    if (nk == 1 && use_revcomp && ix->list_via_range && view.quad && seq_len >= ks[0]) {
         const uint64_t head = num_kmers < seq_len - ks[0] + 1 ? num_kmers : seq_len - ks[0] + 1;
         if (head) {
             rc = ix->big ? launch_min_unique<true, true>(ix, view, head, ks[0], ks[0], d_out, elem_bytes, d_status, st)
@@ -1757,13 +1235,14 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
             first = head;
         }
     }
-    // several lengths, all at least as long as the quad table's window: the LIST instantiation of the quad kernel
-    if (nk > 1 && use_revcomp && ix->list_via_range && view.quad && (ix->kernel_version == 0 || ix->kernel_version == 5) &&
-        kshort >= view.quad_m + NM_QUAD_EXT && ks[0] <= NM_QUAD_MAX_KMIN && seq_len >= kmax) {
+    // several lengths, all at least as long as the quad table's window: the sites with the FIRST length in the place
+    // of kmin (a position whose first-length k-mer contains a window that occurs once is unique at that length), the
+    // list form of k_resolve for the rest
+    if (nk > 1 && use_revcomp && ix->list_via_range && kshort >= view.quad_m + NM_QUAD_EXT && nm_sites_apply(ix, view, ks[0]) && seq_len >= kmax) {
         const uint64_t head = num_kmers < seq_len - kmax + 1 ? num_kmers : seq_len - kmax + 1;
         if (head) {
-            rc = ix->big ? launch_list_quad<true>(ix, view, seq_len, head, ks[0], kmax, d_ks, nk, d_out, elem_bytes, d_status, st)
-                         : launch_list_quad<false>(ix, view, seq_len, head, ks[0], kmax, d_ks, nk, d_out, elem_bytes, d_status, st);
+            rc = ix->big ? launch_sites<true>(ix, view, head, ks[0], kmax, d_out, elem_bytes, d_status, st, seq_len, d_ks, nk)
+                         : launch_sites<false>(ix, view, head, ks[0], kmax, d_out, elem_bytes, d_status, st, seq_len, d_ks, nk);
             if (rc != NM_OK) return rc;
             first = head;
         }

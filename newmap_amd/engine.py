@@ -107,12 +107,8 @@ class Index:
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_COUNT_STEPS, int(bool(on))))
 
     def set_kernel(self, version: int):
-        """0 = automatic, 1 = one lane per position, 2 = persistent lanes, 3 = several positions per lane,
-        4 = position pairs on the pair table, 5 = position quads on the quad table"""
+        """0 = automatic, 1 = one lane per position (k_min_unique), 5 = the sites (k_sites + k_resolve)"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_KERNEL, int(version)))
-
-    def set_persistent_blocks(self, blocks: int):
-        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_PERSISTENT_BLOCKS, int(blocks)))
 
     def set_repeat_probes(self, on: bool):
         """A/B: one probe per 64 positions settles stretches that occur twice over more than kmax bases
@@ -127,10 +123,6 @@ class Index:
         """LF steps read one 16-byte LF entry (default) or the packed 32-byte rank block"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LF_BLOCKS, int(bool(on))))
 
-    def set_two_step(self, on: bool):
-        """walks read the two-step rank blocks (two bases per memory round trip) or the one-step ones"""
-        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_TWO_STEP, int(bool(on))))
-
     def set_force_big(self, on: bool):
         """tests: exercise the code path of indexes beyond 2^31 positions on a small index"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_FORCE_BIG, int(bool(on))))
@@ -138,10 +130,11 @@ class Index:
     def set_timing(self, on: bool):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_TIMING, int(bool(on))))
 
-    def read_timing(self):
-        """(launches, total ms, longest ms) of the search kernels since the last read."""
+    def read_timing(self, kind: int = 0):
+        """(launches, total ms, longest ms) since the last read.  kind 0: the dominant search kernel of each segment
+        alone; kind 1: all kernels of each segment (encode pass, sites, repeat probes, resolve)."""
         n, tot, mx = ctypes.c_uint64(0), ctypes.c_double(0), ctypes.c_double(0)
-        _lib.raise_for(self._L.nm_timing_read(self.handle, ctypes.byref(n), ctypes.byref(tot), ctypes.byref(mx)))
+        _lib.raise_for(self._L.nm_timing_read_kind(self.handle, int(kind), ctypes.byref(n), ctypes.byref(tot), ctypes.byref(mx)))
         return int(n.value), float(tot.value), float(mx.value)
 
     # compat seam --------------------------------------------------------------------------

@@ -26,26 +26,24 @@ def lib():
     L.hs_open.restype = vp
     L.hs_open.argtypes = [ctypes.c_char_p, i32, i32]
     L.hs_close.argtypes = [vp]
-    L.hs_enable_rank2.argtypes = [vp, i32]
     L.hs_enable_lfb.argtypes = [vp, i32]
     L.hs_check_lfb.restype = u64
     L.hs_check_lfb.argtypes = [vp]
-    L.hs_check_rank2.restype = u64
-    L.hs_check_rank2.argtypes = [vp, u64]
     L.hs_check_levels.restype = u64
     L.hs_check_levels.argtypes = [vp, u32]
     L.hs_check_codes4.restype = u64
     L.hs_check_codes4.argtypes = [u64]
     L.hs_check_quad.restype = u64
     L.hs_check_quad.argtypes = [vp]
-    L.hs_check_pair.restype = u64
-    L.hs_check_pair.argtypes = [vp, u32]
     L.hs_info.restype = u64
     L.hs_info.argtypes = [vp, i32]
     L.hs_min_unique.restype = i32
     L.hs_min_unique.argtypes = [vp, vp, u64, u64, u32, u32, i32, i32, vp, vp]
     L.hs_repeat_probes.restype = u64
     L.hs_repeat_probes.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, vp, vp]
+    L.hs_valid_bits.argtypes = [vp, u64, u32, vp]
+    L.hs_sites.restype = i32
+    L.hs_sites.argtypes = [vp, vp, u64, u64, u32, u32, u32, i32, vp, u32, i32, vp, vp, vp, vp]
     L.hs_fixed_k.restype = i32
     L.hs_fixed_k.argtypes = [vp, vp, u64, u64, vp, u32, i32, i32, vp, vp]
     L.hs_count.argtypes = [vp, vp, vp, vp, u64, vp]
@@ -74,12 +72,6 @@ class HostSim:
     def check_lfb(self):
         return int(self.L.hs_check_lfb(self.h))
 
-    def enable_rank2(self, on=True):
-        self.L.hs_enable_rank2(self.h, int(on))
-
-    def check_rank2(self, stride=1):
-        return int(self.L.hs_check_rank2(self.h, stride))
-
     def check_levels(self, s):
         return int(self.L.hs_check_levels(self.h, s))
 
@@ -87,9 +79,6 @@ class HostSim:
         """build the quad table from the simulated seed table (core length = seed length <= 8) and compare every
         bit four neighbouring positions can read with a direct count; returns the number of wrong bits"""
         return int(self.L.hs_check_quad(self.h))
-
-    def check_pair(self, m):
-        return int(self.L.hs_check_pair(self.h, m))
 
     def info(self, what):
         return int(self.L.hs_info(self.h, what))
@@ -112,6 +101,21 @@ class HostSim:
         steps = self.L.hs_repeat_probes(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, stride, coarse_stride,
                                         words.ctypes.data, decided.ctypes.data)
         return words[:n_probes], decided[:num_kmers], int(steps)
+
+    def sites(self, seq: bytes, num_kmers, kmin, kmax, d_cap=60, probes=1, ks=None, dtype=np.uint8):
+        """k_sites -> gated repeat probes -> k_resolve, as the device runs them (needs check_quad() first: it builds the
+        quad table).  ks: list mode (kmin / kmax are then its first / longest length).  Returns (elements, status,
+        rc, need bitmap, counters) -- counters: table entries read, positions walked, probes run, probe-decided."""
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        out = np.zeros(max(num_kmers, 1), dtype=dtype)
+        status = np.zeros(8, dtype=np.uint64)
+        need = np.zeros((num_kmers + 63) // 64 + 1, dtype=np.uint64)
+        counters = np.zeros(4, dtype=np.uint64)
+        k = np.asarray(ks if ks is not None else [], dtype=np.uint32)
+        rc = self.L.hs_sites(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, d_cap, probes,
+                             k.ctypes.data if k.size else None, k.size, out.dtype.itemsize, out.ctypes.data,
+                             status.ctypes.data, need.ctypes.data, counters.ctypes.data)
+        return out[:num_kmers], status, rc, need[:-1], counters
 
     def fixed_k(self, seq: bytes, num_kmers, ks, use_rc=True, dtype=np.uint8):
         buf = np.frombuffer(seq, dtype=np.uint8)
@@ -136,6 +140,14 @@ class HostSim:
         out = np.zeros(max(num_kmers, 1), dtype=np.uint32)
         lib().hs_upper(buf.ctypes.data, buf.size, num_kmers, kmax, out.ctypes.data)
         return out[:num_kmers]
+
+
+def valid_bits(seq: bytes, kmin: int) -> np.ndarray:
+    """nm_valid4 at every position: True when the kmin bases from there on are free of ambiguity"""
+    buf = np.frombuffer(seq, dtype=np.uint8)
+    out = np.zeros(buf.size, dtype=np.uint8)
+    lib().hs_valid_bits(buf.ctypes.data, buf.size, kmin, out.ctypes.data)
+    return out.astype(bool)
 
 
 def check_codes4(rounds=200):

@@ -16,52 +16,12 @@ struct hs_index {
     nm_file_header h;
     std::vector<nm_rank_block> rank;
     std::vector<nm_strand_block> strand;
-    std::vector<uint64_t> sep, seed, superC, superC2;
-    std::vector<nm_rank2_block> rank2;
+    std::vector<uint64_t> sep, seed, superC;
     std::vector<nm_lf_entry> lfb;
     std::vector<uint64_t> quad;
     nm_view v;
     bool big;
 };
-
-// host mirror of the device construction of the two-step rank blocks (nm_engine.hip: k_rank2_*)
-static void hs_build_rank2(hs_index *ix) {
-    const nm_view &v = ix->v;
-    const uint64_t n = v.n, nblk = n / 64 + 1;
-    ix->rank2.assign(nblk, nm_rank2_block{});
-    std::vector<uint64_t> run(20, 0);                       // running absolute counts: 16 pairs + 4 singles
-    std::vector<std::vector<uint64_t>> at_super;            // absolute counts at superblock starts
-    const uint64_t per_super = 1ULL << (NM_SUPER_SHIFT - 6);
-    std::vector<uint64_t> sup(20, 0);
-    for (uint64_t b = 0; b < nblk; b++) {
-        if (b % per_super == 0) { sup = run; at_super.push_back(run); }
-        nm_rank2_block &r = ix->rank2[b];
-        for (int t = 0; t < 16; t++) r.cnt2[t] = (uint32_t)(run[t] - sup[t]);
-        for (int c = 0; c < 4; c++) r.cnt1[c] = (uint32_t)(run[16 + c] - sup[16 + c]);
-        for (uint64_t i = b * 64; i < b * 64 + 64 && i < n; i++) {
-            uint32_t c1 = 0, c2 = 0;
-            const bool v1 = nm_bwt_code(v, i, c1);
-            bool v2 = false;
-            if (v1) {
-                const uint64_t j = ix->big ? nm_lf<true>(v, c1, i) : nm_lf<false>(v, c1, i);
-                v2 = nm_bwt_code(v, j, c2);
-            }
-            const uint64_t bit = 1ULL << (i & 63);
-            if (v1) { r.valid1 |= bit; if (c1 & 1) r.c1lo |= bit; if (c1 & 2) r.c1hi |= bit; run[16 + c1]++; }
-            if (v2) { r.valid2 |= bit; if (c2 & 1) r.c2lo |= bit; if (c2 & 2) r.c2hi |= bit; run[c1 * 4 + c2]++; }
-        }
-    }
-    ix->superC2.assign(at_super.size() * 16, 0);
-    for (size_t sb = 0; sb < at_super.size(); sb++)
-        for (uint32_t x = 0; x < 4; x++)
-            for (uint32_t y = 0; y < 4; y++) {
-                // first row of the suffixes starting "y x": LF_y of the first row starting with x
-                const uint64_t base = ix->big ? nm_lf<true>(v, y, v.C[x]) : nm_lf<false>(v, y, v.C[x]);
-                ix->superC2[sb * 16 + x * 4 + y] = base + at_super[sb][x * 4 + y];
-            }
-    ix->v.rank2 = ix->rank2.data();
-    ix->v.superC2 = ix->superC2.data();
-}
 
 static void hs_encode(const uint8_t *seq, uint64_t seq_len, std::vector<nm_enc_word> &enc) {
     const uint64_t n_words = seq_len / 64 + 3;
@@ -104,7 +64,7 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
     v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
     v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
-    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.pair_m = 0; v.pair = nullptr; v.rank2 = nullptr; v.superC2 = nullptr; v.lfb = nullptr; v.quad = nullptr; v.quad_m = 0;
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.lfb = nullptr; v.quad = nullptr; v.quad_m = 0;
     uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
     if (s > 12) s = 12;                     // keep the simulated table small
     if (s && h.n >= 2) {
@@ -142,50 +102,6 @@ uint64_t hs_check_lfb(hs_index *ix) {
             const uint64_t b = ix->big ? nm_lf<true>(packed, c, i) : nm_lf<false>(packed, c, i);
             if (a != b) bad++;
         }
-    return bad;
-}
-void hs_enable_rank2(hs_index *ix, int on) {
-    if (on && ix->rank2.empty()) hs_build_rank2(ix);
-    ix->v.rank2 = on ? ix->rank2.data() : nullptr;
-    ix->v.superC2 = on ? ix->superC2.data() : nullptr;
-}
-// two-step blocks against the one-step structure: LF_x and LF_y(LF_x) at every row and base pair
-uint64_t hs_check_rank2(hs_index *ix, uint64_t stride) {
-    const nm_view &v = ix->v;
-    uint64_t bad = 0;
-    for (uint64_t i = 0; i <= v.n; i += stride)
-        for (uint32_t x = 0; x < 4; x++) {
-            const uint64_t want1 = ix->big ? nm_lf<true>(v, x, i) : nm_lf<false>(v, x, i);
-            if (nm_lf1_r2(v, x, i) != want1) bad++;
-            for (uint32_t y = 0; y < 4; y++) {
-                uint64_t o1, o2;
-                nm_lf12(v, x, y, i, o1, o2);
-                const uint64_t want2 = ix->big ? nm_lf<true>(v, y, want1) : nm_lf<false>(v, y, want1);
-                if (o1 != want1 || o2 != want2) bad++;
-            }
-        }
-    return bad;
-}
-
-// pair-table entries must equal the plain seed entries of the (m+1)-mers they stand for
-uint64_t hs_check_pair(hs_index *ix, uint32_t m) {
-    const uint32_t s = m + 1;
-    const uint64_t mask = (1ULL << m) - 1;
-    uint64_t bad = 0;
-    for (uint64_t slot = 0; slot < (1ULL << (2 * m)); slot++) {
-        const uint64_t ylo = slot & mask, yhi = slot >> m;
-        for (uint32_t e = 0; e < 8; e++) {
-            uint64_t sl;
-            if (e < 4) sl = (uint64_t)(e & 1) | (ylo << 1) | ((uint64_t)(e >> 1) << s) | (yhi << (s + 1));
-            else { const uint32_t b = e - 4; sl = ylo | ((uint64_t)(b & 1) << m) | (yhi << s) | ((uint64_t)(b >> 1) << (s + m)); }
-            if (sl != nm_pair_seed_slot(slot, m, e)) bad++;
-            const uint64_t want = ix->big ? nm_seed_entry<true>(ix->v, sl, s) : nm_seed_entry<false>(ix->v, sl, s);
-            const uint64_t got = ix->big ? nm_pair_entry<true>(ix->v, slot, m, e) : nm_pair_entry<false>(ix->v, slot, m, e);
-            // an empty interval may sit anywhere: compare sizes, and starts only when non-empty
-            const uint64_t wc = want >> NM_SEED_LO_BITS, gc = got >> NM_SEED_LO_BITS;
-            if (wc != gc || (wc && want != got)) bad++;
-        }
-    }
     return bad;
 }
 // quad table (nm_core.h: nm_quad_build_one, the body of k_quad_build) from the simulated seed table; then
@@ -335,6 +251,164 @@ uint64_t hs_repeat_probes(hs_index *ix, const uint8_t *seq, uint64_t seq_len, ui
         decided[p] = nm_probe_element(ks, kmin, kmax, ks < kmin && nm_all_valid(enc.data(), p, w, kbase, 0, kmin));
     }
     return steps;
+}
+
+// ---- the sites: k_sites -> gated repeat probes -> k_resolve (nm_engine.hip), block by block on the host --------
+// Same helper functions (nm_core.h), same block geometry, same bitmaps; LDS arrays are vectors, lanes are loops.
+// Needs the quad table (hs_check_quad builds it from the simulated seed table; core length = seed length).
+// probes: 0 none, 1 fine, 2 coarse + fine.  list / n_list: list mode (kmin = first length, kmax = the longest).
+// need_out (may be null): the bitmap k_sites leaves.  counters[0] = table entries read, [1] = positions walked,
+// [2] = fine probes run, [3] = positions the probes decided.  Returns 0 ok, 8 k-mer not found, -1 not applicable.
+int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, uint32_t d_cap,
+             int probes, const uint32_t *list, uint32_t n_list, int elem_bytes, void *out, uint64_t *status,
+             uint64_t *need_out, uint64_t *counters) {
+    const nm_view &v = ix->v;
+    const uint32_t m = v.quad_m;
+    if (!v.quad || kmin < m + NM_QUAD_EXT || kmin > NM_SITE_MAX_KMIN || d_cap > NM_SITE_MAX_D) return -1;
+    std::vector<nm_enc_word> enc;
+    hs_encode(seq, seq_len, enc);
+    const uint64_t n_enc_words = enc.size();
+    for (int i = 0; i < 8; i++) status[i] = 0;
+    status[2] = ~0ULL;
+    for (int i = 0; i < 4; i++) counters[i] = 0;
+    auto store = [&](uint64_t p, uint32_t val) {
+        if (elem_bytes == 1) ((uint8_t *)out)[p] = (uint8_t)val;
+        else if (elem_bytes == 2) ((uint16_t *)out)[p] = (uint16_t)val;
+        else ((uint32_t *)out)[p] = val;
+    };
+    uint32_t d = kmin - (m + NM_QUAD_EXT);
+    if (d > d_cap) d = d_cap;
+    const uint32_t G = d + 4, BLOCK = 256, PER_LANE = 2, BP = BLOCK * PER_LANE * G, n_stage = BP / 64 + 5;
+    const uint64_t n_need = (num_kmers + 63) / 64;
+    std::vector<uint64_t> need(n_need + 1, 0);
+    // ---- k_sites
+    for (uint64_t blk = 0; blk * BP < num_kmers; blk++) {
+        const uint64_t base = blk * BP, w0 = base >> 6;
+        std::vector<uint64_t> s_lo(n_stage), s_hi(n_stage), s_amb(n_stage);
+        for (uint32_t i = 0; i < n_stage; i++) {
+            const uint64_t wi = w0 + i < n_enc_words ? w0 + i : n_enc_words - 1;
+            s_lo[i] = enc[wi].lo; s_hi[i] = enc[wi].hi; s_amb[i] = enc[wi].amb;
+        }
+        std::vector<uint32_t> s_set(BP / 32 + 2, 0), s_need(BP / 32, 0);
+        auto lds_window = [&](uint32_t rel) {
+            const uint32_t wi = rel >> 6, sh = rel & 63;
+            nm_window w{s_lo[wi], s_hi[wi], s_amb[wi]};
+            if (sh) {
+                w.lo = (w.lo >> sh) | (s_lo[wi + 1] << (64 - sh));
+                w.hi = (w.hi >> sh) | (s_hi[wi + 1] << (64 - sh));
+                w.amb = (w.amb >> sh) | (s_amb[wi + 1] << (64 - sh));
+            }
+            return w;
+        };
+        for (uint32_t g = 0; g < BLOCK * PER_LANE; g++) {
+            const nm_window win = lds_window(g * G + d);
+            if (!(base + (uint64_t)g * G < num_kmers && nm_site_core_valid(win, m))) continue;
+            counters[0]++;
+            const uint64_t settled = nm_site_settled(nm_site_bits(win, m, v.quad + nm_quad_slot(win, m) * 4), d);
+            if (!settled) continue;
+            const uint32_t o = g * G, wi = o >> 5, sh = o & 31;
+            s_set[wi] |= (uint32_t)(settled << sh);
+            const uint64_t rest = sh ? settled >> (32 - sh) : settled >> 16 >> 16;
+            if ((uint32_t)rest) s_set[wi + 1] |= (uint32_t)rest;
+            if (rest >> 32) s_set[wi + 2] |= (uint32_t)(rest >> 32);
+        }
+        auto amb_word = [&](uint64_t i) -> uint64_t { return s_amb[i]; };
+        for (uint32_t j = 0; j < BP / 4; j++) {
+            const uint32_t rel = 4 * j;
+            const uint64_t q = base + rel;
+            if (q >= num_kmers) break;
+            const uint64_t left = num_kmers - q;
+            const uint32_t inb = left >= 4 ? 0xFu : (1u << left) - 1u;
+            uint32_t own_amb;
+            const uint32_t valid = nm_valid4(amb_word, rel, kmin, own_amb) & inb;
+            const uint32_t set4 = (s_set[rel >> 5] >> (rel & 31)) & 0xFu;
+            const uint32_t hit = valid & set4, open = valid & ~set4;
+            status[0] += (uint64_t)__builtin_popcount(own_amb & inb);
+            status[7] += (uint64_t)__builtin_popcount(~own_amb & inb);
+            if (open) s_need[rel >> 5] |= open << (rel & 31);
+            for (uint32_t t = 0; t < 4; t++)
+                if ((inb >> t) & 1u) store(q + t, (hit >> t) & 1u ? kmin : 0u);
+        }
+        for (uint32_t i = 0; i < BP / 64; i++)
+            if (base + 64ull * i < num_kmers) need[w0 + i] = (uint64_t)s_need[2 * i] | ((uint64_t)s_need[2 * i + 1] << 32);
+    }
+    if (need_out) for (uint64_t i = 0; i < n_need; i++) need_out[i] = need[i];
+    // ---- repeat probes where the bitmap is dense (k_repeat_probe_coarse, k_repeat_probe)
+    std::vector<uint32_t> words;
+    if (probes) {
+        const uint32_t stride = 64;
+        std::vector<uint32_t> coarse;
+        if (probes == 2) {
+            coarse.assign((num_kmers + NM_COARSE_STRIDE - 1) / NM_COARSE_STRIDE, 0);
+            for (uint64_t c = 0; c < coarse.size(); c++) {
+                const uint64_t j0 = c * (NM_COARSE_STRIDE / stride);
+                if (!(j0 < n_need && nm_popc64(need[j0]) >= NM_PROBE_GATE_BITS)) continue;
+                nm_tally t = {0, 0, 0, 0};
+                uint32_t settled, exact;
+                if (ix->big) nm_repeat_probe_ex<true>(v, enc.data(), c * NM_COARSE_STRIDE, kmax, NM_COARSE_STRIDE, t, settled, exact);
+                else nm_repeat_probe_ex<false>(v, enc.data(), c * NM_COARSE_STRIDE, kmax, NM_COARSE_STRIDE, t, settled, exact);
+                coarse[c] = settled;
+            }
+        }
+        words.assign(n_need + 1, 0);
+        for (uint64_t j = 0; j < n_need; j++) {
+            const uint64_t P = j * stride;
+            nm_tally t = {0, 0, 0, 0};
+            if (!nm_probe_gate(need.data(), j, n_need)) continue;
+            counters[2]++;
+            if (probes == 2 && nm_coarse_covers(coarse[P / NM_COARSE_STRIDE], (uint32_t)(P % NM_COARSE_STRIDE), stride)) { words[j] = stride; continue; }
+            words[j] = ix->big ? nm_repeat_probe<true>(v, enc.data(), P, kmax, stride, t) : nm_repeat_probe<false>(v, enc.data(), P, kmax, stride, t);
+        }
+    }
+    // ---- k_resolve
+    for (uint64_t cur = 0; cur < n_need; cur++) {
+        uint64_t bits = need[cur];
+        uint32_t wj = 0, wj1 = 0;
+        if (bits && probes) {
+            wj = words[cur]; wj1 = words[cur + 1];
+            const uint32_t zeros = wj & 0xFFu;
+            const uint64_t before = bits;
+            bits &= zeros >= 64 ? 0ULL : ~((1ULL << zeros) - 1ULL);
+            counters[3] += nm_popc64(before ^ bits);
+        }
+        for (; bits; bits &= bits - 1) {
+            const uint32_t o = (uint32_t)__builtin_ctzll(bits);
+            const uint64_t p = cur * 64 + o;
+            const uint32_t ks = probes ? nm_probe_kstar(wj, wj1, o, 64, kmax) : NM_PROBE_OPEN;
+            if (ks != NM_PROBE_OPEN && (!list || ks > kmax)) {
+                const uint32_t val = list ? 0u : nm_probe_element(ks, kmin, kmax, true);
+                if (val) store(p, val);
+                counters[3]++;
+                continue;
+            }
+            counters[1]++;
+            bool amb0 = false, err = false;
+            nm_tally t = {0, 0, 0, 0};
+            uint32_t val;
+            if (list) val = ix->big ? nm_fixed_k_one<true, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t)
+                                    : nm_fixed_k_one<false, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t);
+            else      val = ix->big ? nm_min_unique_one<true, true>(v, enc.data(), p, kmin, kmax, amb0, err, t)
+                                    : nm_min_unique_one<false, true>(v, enc.data(), p, kmin, kmax, amb0, err, t);
+            if (err) { status[1] = 1; if (p < status[2]) status[2] = p; }
+            status[3] += t.steps; status[4] += t.blocks; status[5] += t.seeds;
+            store(p, val);
+        }
+    }
+    status[5] += counters[0] * 4;
+    return status[1] ? 8 : 0;
+}
+
+// nm_valid4 over a whole sequence: out[p] = 1 when the kmin bases from p on are free of ambiguity
+void hs_valid_bits(const uint8_t *seq, uint64_t seq_len, uint32_t kmin, uint8_t *out) {
+    std::vector<nm_enc_word> enc;
+    hs_encode(seq, seq_len, enc);
+    enc.resize(seq_len / 64 + 8, nm_enc_word{0, 0, ~0ULL, 0});
+    auto amb_word = [&](uint64_t i) -> uint64_t { return enc[i].amb; };
+    for (uint64_t q = 0; q < seq_len; q += 4) {
+        uint32_t own;
+        const uint32_t v = nm_valid4(amb_word, q, kmin, own);
+        for (uint32_t t = 0; t < 4 && q + t < seq_len; t++) out[q + t] = (v >> t) & 1u;
+    }
 }
 
 int hs_fixed_k(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks,

@@ -173,9 +173,8 @@ def test_parallel_suffix_sort_equals_sais(tmp_path, threads):
     assert out["sais"] == out["pd"]
 
 
-def test_pair_table_entries_equal_seed_entries(tmp_path):
-    """the pair table (k_min_unique_pair) stores, per m-mer core, the intervals of a.Y and Y.b: they must
-    be the plain seed entries of those (m+1)-mers"""
+def test_level_wise_seed_construction(tmp_path):
+    """k_seed_level: level s of the seed table from level s-1 with one LF step per entry == entry by entry"""
     rng = np.random.default_rng(5)
     alpha = np.frombuffer(b"ACGT", np.uint8)
     text = b">x\n" + bytes(alpha[rng.integers(0, 4, 6000)]) + b"NN" + b"ACGT" * 50 + b"\n>y\nAAAAAAAAAAAACCCCCCCCGGGGT\n"
@@ -185,9 +184,7 @@ def test_pair_table_entries_equal_seed_entries(tmp_path):
     generate_fm_index(str(fa), str(idx), 8, 12)
     for big in (False, True):
         sim = HostSim(idx, 0, big)
-        for m in (3, 5):
-            assert sim.check_pair(m) == 0
-        for level in (2, 4, 6):                                # level-wise seed construction == entry by entry
+        for level in (2, 4, 6):
             assert sim.check_levels(level) == 0
 
 
@@ -221,9 +218,9 @@ def test_core_multi_fasta_multi_index_matches_reference(tmp_path):
             assert np.concatenate(got[rid.encode()]).tolist() == exp["values"], (c["name"], rid)
 
 
-def test_two_step_rank_blocks(tmp_path, golden_search):
-    """the two-step rank structure (one 128-byte line answers LF_x and LF_y(LF_x)) against the one-step
-    blocks at every row, and the two-bases-per-round-trip walk against the reference fixtures"""
+def test_lf_blocks_equal_packed_rank_blocks(tmp_path, golden_search):
+    """k_lf_blocks: one 16-byte entry per LF step == the packed rank blocks at every row and base; the walk on them
+    reproduces the reference fixtures"""
     rng = np.random.default_rng(11)
     alpha = np.frombuffer(b"ACGT", np.uint8)
     text = (b">x\n" + bytes(alpha[rng.integers(0, 4, 3000)]) + b"NN" + b"ACGT" * 40 + b"A" * 300 + b"\n>y\nAAAACCCCGGGGT\n>z\nT\n")
@@ -233,26 +230,19 @@ def test_two_step_rank_blocks(tmp_path, golden_search):
     generate_fm_index(str(fa), str(idx), 8, 12)
     for big in (False, True):
         sim = HostSim(idx, 0, big)
-        sim.enable_rank2()
-        assert sim.check_rank2(1) == 0
-        sim.enable_lfb()                                       # one 16-byte entry per LF step
+        sim.enable_lfb()
         assert sim.check_lfb() == 0
-        assert sim.check_rank2(1) == 0                         # (the two-step check now walks the LF blocks)
     for c in golden_search:
-        if "quirk" in c["name"] or not c["is_binary"] or not c["use_reverse_complement"]:
+        if not c["is_binary"] or not c["use_reverse_complement"]:
             continue
         t = c["fasta"].encode("latin-1")
         fa = _write(tmp_path, t)
         generate_fm_index(str(fa), str(idx), 8, 12)
-        for seed, lfb in ((0, False), (4, False), (3, True)):
-            sim = HostSim(idx, seed)
-            sim.enable_rank2()
-            if lfb:
-                sim.enable_rank2(False)
-                sim.enable_lfb()
-            got = _engine_unique(sim, t, c["kmer_lengths"], True, c["batch"], True)
-            for rid, exp in c["expected"].items():
-                assert got[rid.encode()].tolist() == exp["values"], (c["name"], rid, seed)
+        sim = HostSim(idx, 3)
+        sim.enable_lfb()
+        got = _engine_unique(sim, t, c["kmer_lengths"], True, c["batch"], True)
+        for rid, exp in c["expected"].items():
+            assert got[rid.encode()].tolist() == exp["values"], (c["name"], rid)
 
 
 def test_repeat_probes_decide_only_what_the_oracle_confirms(tmp_path):
@@ -313,7 +303,7 @@ def test_repeat_probes_decide_only_what_the_oracle_confirms(tmp_path):
 @pytest.mark.parametrize("m,force_big", [(4, False), (6, False), (5, True)])
 def test_quad_table_bits_equal_direct_counts(tmp_path, m, force_big):
     """nm_quad_build_one / nm_quad_slot / nm_quad_bits (the quad table of k_quad_build and
-    k_min_unique_quad): every 16-bit piece is written exactly once, and for every window of m + 6 bases
+    k_sites): every 16-bit piece is written exactly once, and for every window of m + 6 bases
     the four bits read are 'the (m+3)-mer at this position occurs once over both strands'."""
     rng = np.random.default_rng(5 + m)
     alpha = np.frombuffer(b"ACGT", np.uint8)
@@ -338,6 +328,99 @@ def test_quad_table_bits_equal_direct_counts(tmp_path, m, force_big):
         words, decided, _ = sim.repeat_probes(rec, len(rec), kmin, kmax, 16)
         closed = decided != 0xFFFFFFFF
         assert closed.any() and np.array_equal(decided[closed].astype(np.int64), want[closed])
+
+
+@pytest.mark.parametrize("m,force_big", [(4, False), (6, False), (5, True)])
+def test_sites_pipeline_equals_oracle(tmp_path, m, force_big):
+    """k_sites -> gated repeat probes -> k_resolve as the device runs them (tests/hostsim: same helper functions, same
+    block geometry and bitmaps): one quad entry per group of kmin - m + 1 positions settles the group where one of its
+    windows occurs once (nm_core.h "sites"); the rest goes to the probes and the walk.  Every element equals the
+    oracle's closed form, for every cap of d, with and without probes; list mode equals the reference's linear
+    search; and the table really is read once per group."""
+    rng = np.random.default_rng(40 + m)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    n = {4: 3000, 5: 12000, 6: 60000}[m]
+    r1 = bytearray(bytes(alpha[rng.integers(0, 4, n)]))
+    unit = bytes(alpha[rng.integers(0, 4, 9)])
+    r1[600:1800] = (unit * 200)[:1200]                     # tandem array: dense open bits, probes run
+    r1[2000:2007] = b"NNNNNNN"
+    r1[2100:2101] = b"R"
+    r1[2300:2420] = bytes(r1[300:420]).lower()             # soft-masked dispersed copy
+    r2 = bytes(alpha[rng.integers(0, 4, n // 3)]) + bytes(r1[50:190]) + b"NN" + bytes(alpha[rng.integers(0, 4, 70)])
+    fa = _write(tmp_path, b">a\n" + bytes(r1) + b"\n>b\n" + r2 + b"\n")
+    idx = tmp_path / "s.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    sim = HostSim(idx, m, force_big)
+    assert sim.check_quad() == 0                           # builds the quad table (cores of m bases)
+    sim.enable_lfb(True)
+    oracle = rd.OracleIndex([bytes(r1), r2])
+    w = m + 3
+    for rec in (bytes(r1), r2):
+        n_amb = sum(ch not in b"ACGTacgt" for ch in rec)
+        for kmin, kmax in ((w, 40), (w + 1, 40), (w + 3, 200), (20, 200), (24, 150), (61, 90), (62, 300), (64, 64), (70, 255), (130, 200), (252, 255)):
+            dtype, _ = rd.output_dtype(kmax)
+            want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
+            plain, _, code = sim.min_unique(rec, len(rec), kmin, kmax, True, dtype)
+            assert code == 0 and np.array_equal(plain, want)
+            for d_cap in (0, 1, 5, 60):
+                for probes in (0, 1, 2):
+                    got, status, code, need, counters = sim.sites(rec, len(rec), kmin, kmax, d_cap, probes, dtype=dtype)
+                    assert code == 0 and got.dtype == want.dtype
+                    assert np.array_equal(got, want), (kmin, kmax, d_cap, probes, np.flatnonzero(got != want)[:10])
+                    assert int(status[0]) == n_amb and int(status[7]) == len(rec) - n_amb
+                    d = min(kmin - w, d_cap)
+                    assert int(counters[0]) <= -(-len(rec) // (d + 4))          # one entry per group of d + 4 positions
+                    if probes == 0:
+                        assert int(counters[2]) == 0 and int(counters[3]) == 0
+            # a prefix that ends inside a block and inside a group; a num_kmers that leaves lookahead behind
+            for cut in (1, 3, 517, len(rec) - kmin):
+                if cut <= 0 or cut > len(rec):
+                    continue
+                got, _, code, _, _ = sim.sites(rec, cut, kmin, kmax, 60, 1, dtype=dtype)
+                assert code == 0 and np.array_equal(got, want[:cut]), (kmin, kmax, cut)
+    # the probes really run on the tandem array and decide most of it; elsewhere (open bits sparse) none runs
+    rec = bytes(r1)
+    got, _, _, need, counters = sim.sites(rec, len(rec), 20, 60, 60, 1)
+    dense = np.array([bin(int(x)).count("1") >= 32 for x in need])
+    assert dense[600 // 64 + 1:(1800 - 60) // 64 - 1].all() and int(counters[2]) <= 2 * int(dense.sum()) + 2
+    assert int(counters[3]) > 600 and int(counters[1]) < len(rec) // 4
+    # list mode: several lengths, all >= the window
+    for ks in ([w, w + 5], [20, 36, 100], [36, 20, 50], [w + 2, 250], [100, 24]):
+        if min(ks) < w or ks[0] > 252:
+            continue
+        kmax = max(ks)
+        dtype, _ = rd.output_dtype(kmax)
+        for rec in (bytes(r1), r2):
+            if len(rec) < kmax:
+                continue
+            seg = rd.Segment(b"r", rec, True)
+            want, _ = rd.linear_search_segment(oracle, seg, ks, kmax, dtype, True)
+            head = len(rec) - kmax + 1                      # the caller keeps the truncated k-mers at the end out
+            for probes in (0, 1):
+                got, _, code, _, _ = sim.sites(rec, head, ks[0], kmax, 60, probes, ks=ks, dtype=dtype)
+                # (the lone R: list mode drops a position on any non-ACGT byte, the reference only on N -- DESIGN.md)
+                keep = np.ones(head, bool)
+                r_at = rec.find(b"R")
+                if r_at >= 0:
+                    keep[max(0, r_at - kmax + 1):r_at + 1] = False
+                assert code == 0 and np.array_equal(got[keep], want[:head][keep]), (ks, probes)
+
+
+def test_valid4_equals_per_position_scan():
+    """nm_valid4 (k_sites: four positions per lane and turn) against a plain scan of the ambiguity plane"""
+    from tests import hostsim
+    rng = np.random.default_rng(3)
+    for density in (0.0, 0.002, 0.02, 0.3):
+        seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 5000)].copy()
+        seq[rng.random(seq.size) < density] = ord("N")
+        amb = np.concatenate((seq == ord("N"), np.ones(600, bool)))
+        nxt = np.full(amb.size + 1, amb.size, dtype=np.int64)          # next ambiguous position at or after i
+        for i in range(amb.size - 1, -1, -1):
+            nxt[i] = i if amb[i] else nxt[i + 1]
+        for kmin in (1, 4, 19, 20, 60, 61, 62, 63, 64, 65, 100, 128, 129, 191, 192, 193, 252):
+            got = hostsim.valid_bits(seq.tobytes(), kmin)
+            want = (nxt[:seq.size] - np.arange(seq.size)) >= kmin
+            assert np.array_equal(got, want), (density, kmin, np.flatnonzero(got != want)[:5])
 
 
 def test_word_wide_base_classification_equals_the_bytewise_one():

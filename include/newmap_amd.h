@@ -148,9 +148,11 @@ enum {
     NM_OPT_LF_BLOCKS = 9,          /* LF steps on the 16-byte LF entries (default when built) or the packed rank blocks */
     NM_OPT_REPEAT_PROBES = 10,     /* both-strand range mode: one probe per 64 positions settles stretches that occur
                                       twice over more than kmax bases (default 1; 0 = every position searches for itself) */
-    NM_OPT_LIST_VIA_RANGE = 11     /* list mode on both strands runs on the range kernels (one length: kmin = kmax = k;
+    NM_OPT_LIST_VIA_RANGE = 11,    /* list mode on both strands runs on the range kernels (one length: kmin = kmax = k;
                                       several lengths >= the quad window: the sites + the list form of k_resolve);
                                       default 1, 0 = always the list kernel, for A/B */
+    NM_OPT_SITE_D = 12             /* measurement / tests: cap (0..60, default 60) on d = kmin - (core length + 3); a site
+                                      settles a group of d + 4 positions */
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 

@@ -1013,6 +1013,11 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         ix->repeat_probes = value != 0;
         return NM_OK;
     }
+    if (option == NM_OPT_SITE_D) {         // measurement / tests: cap on d = kmin - window of the sites (a group = d + 4 positions)
+        if (value < 0 || value > (int64_t)NM_SITE_MAX_D) { nm_set_error("site d cap must be 0..%u", NM_SITE_MAX_D); return NM_E_ARGUMENT; }
+        ix->site_d_cap = (uint32_t)value;
+        return NM_OK;
+    }
     if (option == NM_OPT_KERNEL) {
         if (value != 0 && value != 1 && value != 5) { nm_set_error("kernel version must be 0 (automatic), 1 (one lane per position) or 5 (sites)"); return NM_E_ARGUMENT; }
         ix->kernel_version = (int)value;

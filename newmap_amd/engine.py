@@ -123,6 +123,10 @@ class Index:
         """LF steps read one 16-byte LF entry (default) or the packed 32-byte rank block"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LF_BLOCKS, int(bool(on))))
 
+    def set_site_d(self, d_cap: int):
+        """measurement / tests: cap on d = kmin - (quad core length + 3); a site settles a group of d + 4 positions"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SITE_D, int(d_cap)))
+
     def set_force_big(self, on: bool):
         """tests: exercise the code path of indexes beyond 2^31 positions on a small index"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_FORCE_BIG, int(bool(on))))

@@ -233,7 +233,23 @@ def main():
     # The lookahead quirk: with batch 640 the N run 640-699 starts exactly at a
     # batch boundary, inside the unmasked lookahead of segment 0.  Kept as DOCUMENTATION of the
     # reference's batch-dependent output under the seam model; the engine implements A.2.
-    add("G9_ambiguous_6_40_b640_quirk", g9, range(6, 41), True, 640,
+    add("G9_ambiguous_6_40_b640", g9, range(6, 41), True, 640,
+        "N run 640-699 starts at a batch boundary, but every position before it is unique well before it reaches the "
+        "run: the unmasked lookahead (search.py:751-753) changes nothing here")
+
+    # G10: the lookahead quirk made visible (newmap/search.py:751-753).  The 40 bases in front of the N
+    # run are a copy of bases 100-139, so their k-mers stay repeated until they reach the run.  With batch 640 the run
+    # lies in the UNMASKED lookahead of segment 0: the reference's probes then contain N's, and under the seam model
+    # (every non-ACGT byte one letter) such a k-mer occurs once -- the reference reports a length there, and what it
+    # reports depends on --kmer-batch-size.  With one segment per record the mask covers the run and the same positions
+    # are 0 (what the engine implements).  Both outputs are kept; the test counts the difference.
+    rng = np.random.default_rng(20260607)
+    c = bytearray(random_dna(rng, 2500))
+    c[600:640] = c[100:140]
+    c[640:700] = b"N" * 60
+    g10 = fasta_text([("q1", bytes(c))])
+    add("G10_lookahead_6_40_whole", g10, range(6, 41), True, 10_000_000, "one segment: the closed form of Appendix A.2")
+    add("G10_lookahead_6_40_b640_quirk", g10, range(6, 41), True, 640,
         "reference output depends on --kmer-batch-size here (lookahead is not masked)")
 
     (HERE / "golden_search.json").write_text(json.dumps({"cases": cases}, indent=0))

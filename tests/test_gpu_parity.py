@@ -37,9 +37,8 @@ def _random_dna(rng, n):
 # ------------------------------------------------------------------ reference fixtures, end to end
 def test_write_unique_counts_reproduces_reference_fixtures(tmp_path, golden_search, eng):
     from newmap_amd.search import SearchConfig, write_unique_counts
+    whole = {c["name"]: c for c in golden_search}
     for i, c in enumerate(golden_search):
-        if "quirk" in c["name"]:
-            continue
         d = tmp_path / f"case{i}"
         d.mkdir()
         fa, idx = _build_index(d, c["fasta"].encode("latin-1"))
@@ -54,6 +53,15 @@ def test_write_unique_counts_reproduces_reference_fixtures(tmp_path, golden_sear
         assert files == sorted(f"{rid}.unique.{e['dtype']}" for rid, e in c["expected"].items()), c["name"]
         for rid, e in c["expected"].items():
             got = np.fromfile(out / f"{rid}.unique.{e['dtype']}", dtype=e["dtype"])
+            if "quirk" in c["name"]:
+                # DOCUMENTED DIVERGENCE: the reference does not mask the lookahead of a non-final
+                # batch (newmap/search.py:751-753), so 39 positions in front of an N run get a length that depends on
+                # --kmer-batch-size; the engine gives the batch-independent answer = the one-segment fixture
+                same = whole[c["name"].replace("_b640_quirk", "_whole")]["expected"][rid]["values"]
+                assert got.tolist() == same, (c["name"], rid)
+                diff = np.flatnonzero(got != np.array(e["values"], dtype=got.dtype))
+                assert diff.tolist() == list(range(601, 640)) and not got[diff].any() and np.array(e["values"])[diff].all()
+                continue
             assert got.tolist() == e["values"], (c["name"], rid)
     eng.close_all()
 
@@ -310,6 +318,10 @@ def test_large_random_genome_properties(tmp_path, eng):
     with eng.Index(idx, 0) as ix:                         # automatic tables: the quad kernel, as in bench.py
         whole, amb = ix.min_unique_segment(rec, len(rec), kmin, kmax)
         assert amb == 0 and ix.info()["last_range_kernel"] == 5
+        ix.set_force_big(True)                                # the > 2^31-row instantiations, at full size
+        big, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+        ix.set_force_big(False)
+        assert np.array_equal(big, whole)
         parts = [ix.min_unique_segment(s.data, rd.num_kmers_of(s, kmax), kmin, kmax)[0]
                  for s in rd.record_segments(b"c", rec, 10_000_000 + kmax - 1, kmax - 1)]
         assert np.array_equal(np.concatenate(parts), whole)
@@ -465,44 +477,47 @@ def test_config4_fixed_k(tmp_path, eng, k):
             assert np.array_equal(got, want), (name, k)
 
 
-def test_both_range_kernels_agree(mixed_genome, eng, monkeypatch):
-    """the range kernels (one lane per position, persistent lanes, several positions per lane, position pairs
-    on the pair table, position quads on the quad table) are schedules of the same arithmetic"""
+def test_both_range_kernels_agree(mixed_genome, eng):
+    """the two range paths -- one lane per position (k_min_unique) and the sites (k_sites + gated probes + k_resolve)
+    -- are schedules of the same arithmetic: identical elements and ambiguity counts for every window / group size,
+    with and without probes, on LF entries and on packed rank blocks, in the 32-bit and in the > 2^31-row
+    instantiations, and both equal the oracle"""
     g = mixed_genome
-    monkeypatch.setenv("NEWMAP_AMD_PAIR", "1")                      # both tables (the default builds only the quad table)
     with eng.Index(g["idx"], 0) as ix:
         info = ix.info()
-        assert 8 <= info["quad_core_length"] <= info["seed_length"] and info["pair_core_length"] == info["seed_length"] - 1
+        assert 8 <= info["quad_core_length"] <= info["seed_length"]
         w = info["quad_core_length"] + 3
         for rec in (g["r1"], g["r2"]):
-            for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (60, 90), (61, 90), (64, 64), (100, 300),
-                               (124, 200), (125, 200)):
-                ix.set_kernel(2)
-                a, amb_a = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+            for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (w + 1, 64), (60, 90), (61, 90), (62, 90),
+                               (64, 64), (100, 300), (124, 200), (125, 200), (252, 255), (253, 255)):
+                ix.set_force_big(False)
                 ix.set_kernel(1)
-                b, amb_b = ix.min_unique_segment(rec, len(rec), kmin, kmax)
-                assert np.array_equal(a, b) and amb_a == amb_b
-                # walks on the one-step rank blocks instead of the two-step ones
-                for kernel in (0, 1, 3, 4, 5):
-                    ix.set_kernel(kernel)
-                    ix.set_two_step(False)
-                    c, amb_c = ix.min_unique_segment(rec, len(rec), kmin, kmax)
-                    used = ix.info()["last_range_kernel"]
-                    pair_ok = kmin >= info["pair_core_length"] + 1
-                    quad_ok = w <= kmin <= 124                    # NM_QUAD_MAX_KMIN
-                    if kernel in (0, 5):
-                        assert used == (5 if quad_ok else (4 if kernel == 0 and pair_ok else 1)), (kernel, kmin, used)
-                    if kernel == 4:
-                        assert used == (4 if pair_ok else 1), (kmin, used)
-                    ix.set_two_step(True)
-                    d, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
-                    assert np.array_equal(a, c) and np.array_equal(a, d) and amb_c == amb_a, (kernel, kmin, kmax)
+                ix.set_repeat_probes(False)
+                a, amb_a = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                if (kmin, kmax) in ((20, 200), (w, 64), (252, 255)):
+                    assert np.array_equal(a, rd.closed_form_min_unique(rec, g["oracle"], kmin, kmax))
+                sites_ok = w <= kmin <= 252                       # NM_SITE_MAX_KMIN
+                for big in (False, True):
+                    ix.set_force_big(big)
+                    for kernel in (0, 1, 5):
+                        ix.set_kernel(kernel)
+                        for probes in (True, False):
+                            ix.set_repeat_probes(probes)
+                            for d_cap in ((60, 0, 2) if kernel == 5 and probes else (60,)):
+                                ix.set_site_d(d_cap)
+                                c, amb_c = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                                used = ix.info()["last_range_kernel"]
+                                assert used == (5 if sites_ok and kernel != 1 else 1), (kernel, kmin, used)
+                                assert np.array_equal(a, c) and amb_c == amb_a, (kernel, big, probes, d_cap, kmin, kmax)
+                ix.set_site_d(60)
+                ix.set_force_big(False)
                 ix.set_kernel(0)
+                ix.set_repeat_probes(True)
                 ix.set_lf_blocks(False)                           # packed 32-byte rank blocks instead of LF entries
                 e, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                 ix.set_lf_blocks(True)
                 assert np.array_equal(a, e)
-        # unaligned output pointer and 2-byte elements take the quad kernel's element-wise stores
+        # unaligned output pointer and 2-byte elements take the element-wise stores of k_sites
         rec = g["r1"][:70_001]
         ix.set_kernel(5)
         a16, _ = ix.min_unique_segment(rec, len(rec), 20, 300)
@@ -512,22 +527,102 @@ def test_both_range_kernels_agree(mixed_genome, eng, monkeypatch):
 
 
 def test_big_index_code_path(mixed_genome, eng):
-    """kernels templated for > 2^31 BWT positions (64-bit superblock table) on a small index"""
+    """every kernel templated for > 2^31 BWT rows (64-bit superblock table: the instantiations a 3 Gbp genome runs) on a
+    small index, against the oracle: k_resolve / k_repeat_probe / k_repeat_probe_coarse / k_min_unique / k_fixed_k /
+    k_count <true>, range and list mode, probes on and off, coarse probes forced"""
     g = mixed_genome
     with eng.Index(g["idx"], 0) as ix:
         rec = g["r1"]
-        a, amb = ix.min_unique_segment(rec, len(rec), 20, 200)
-        f, _ = ix.fixed_k_segment(rec[:100_000], 100_000, [36])
-        c = ix.count_from_sequence(rec, [0, 77, 50_000], [30, 12, 400])
-        n, _ = ix.min_unique_segment(rec, len(rec), 20, 200, use_revcomp=False)
+        want = rd.closed_form_min_unique(rec, g["oracle"], 20, 200)
+        want_n = rd.closed_form_min_unique(rec, g["oracle"], 20, 200, False)
+        c = g["oracle"].count_from_sequence(rec, [0, 77, 50_000], [30, 12, 400])
+        seg = rd.Segment(b"r", rec[:100_000], True)
+        f36, _ = rd.linear_search_segment(g["oracle"], seg, [36], 36, np.uint8, True)
+        f3, _ = rd.linear_search_segment(g["oracle"], seg, [24, 36, 100], 100, np.uint8, True)
+        r_at = rec.find(b"R")
+        assert r_at < 0 or r_at >= 100_000                   # (list mode and the lone R: test_list_mode_iupac_divergence)
         ix.set_force_big(True)
-        for kernel in (1, 2):
+        for kernel in (0, 1, 5):
             ix.set_kernel(kernel)
-            b, amb_b = ix.min_unique_segment(rec, len(rec), 20, 200)
-            assert np.array_equal(a, b) and amb == amb_b
-        assert np.array_equal(f, ix.fixed_k_segment(rec[:100_000], 100_000, [36])[0])
+            for probes in (True, False):
+                ix.set_repeat_probes(probes)
+                b, amb_b = ix.min_unique_segment(rec, len(rec), 20, 200)
+                assert np.array_equal(want, b) and amb_b == sum(ch not in b"ACGTacgt" for ch in rec), (kernel, probes)
+                assert np.array_equal(f36, ix.fixed_k_segment(rec[:100_000], 100_000, [36])[0]), (kernel, probes)
+                assert np.array_equal(f3, ix.fixed_k_segment(rec[:100_000], 100_000, [24, 36, 100])[0]), (kernel, probes)
+        ix.set_kernel(0)
+        ix.set_repeat_probes(True)
         assert np.array_equal(c, ix.count_from_sequence(rec, [0, 77, 50_000], [30, 12, 400]))
-        assert np.array_equal(n, ix.min_unique_segment(rec, len(rec), 20, 200, use_revcomp=False)[0])
+        assert np.array_equal(want_n, ix.min_unique_segment(rec, len(rec), 20, 200, use_revcomp=False)[0])
+
+
+def test_coarse_probes_forced_big_and_small(mixed_genome, eng, monkeypatch):
+    """k_repeat_probe_coarse in both instantiations (forced on: NEWMAP_AMD_COARSE=2 with a launch threshold of 0), on the
+    genome with the 30 kb tandem array, against the oracle"""
+    g = mixed_genome
+    monkeypatch.setenv("NEWMAP_AMD_COARSE", "2")
+    monkeypatch.setenv("NEWMAP_AMD_COARSE_MIN", "0")
+    rec = g["r1"]
+    want = rd.closed_form_min_unique(rec, g["oracle"], 20, 100)
+    with eng.Index(g["idx"], 0) as ix:
+        ix.set_count_steps(True)
+        for big in (False, True):
+            ix.set_force_big(big)
+            for kernel in (0, 1):
+                ix.set_kernel(kernel)
+                got, _ = ix.min_unique_segment(rec, len(rec), 20, 100)
+                assert np.array_equal(got, want), (big, kernel)
+                assert ix.probe_tally()["settled"] > 20_000     # the tandem array is settled by the probes
+
+
+def test_device_built_index_searched_against_oracle(tmp_path, mixed_genome, eng):
+    """nm_index_build_device (suffix sort on the GPU, both the 32-bit and the bucketed 64-bit variant): the index it
+    writes is SEARCHED against the oracle, not only compared with the host builder's file"""
+    from newmap_amd._c_newmap_generate_index import generate_fm_index
+    g = mixed_genome
+    want = {kk: rd.closed_form_min_unique(g["r1"], g["oracle"], *kk) for kk in ((20, 200), (24, 150))}
+    for variant in ("", "large"):
+        if variant:
+            os.environ["NEWMAP_AMD_DEVICE_SA"] = variant
+        try:
+            idx = tmp_path / f"dev{variant}.awfmi"
+            generate_fm_index(str(g["fa"]), str(idx), 8, 12, device=0)
+        finally:
+            os.environ.pop("NEWMAP_AMD_DEVICE_SA", None)
+        with eng.Index(idx, 0) as ix:
+            for kk, w in want.items():
+                got, _ = ix.min_unique_segment(g["r1"], len(g["r1"]), *kk)
+                assert np.array_equal(got, w), (variant, kk)
+            starts = np.arange(0, 60_000, 997)
+            lens = (starts % 90) + 1
+            assert np.array_equal(ix.count_from_sequence(g["r2"], starts, lens),
+                                  g["oracle"].count_from_sequence(g["r2"], starts, lens))
+
+
+def test_list_mode_iupac_divergence(mixed_genome, eng):
+    """DOCUMENTED DIVERGENCE: list mode in the reference drops a position only when its k-mer
+    contains an upper-case N (newmap/search.py:593); any other non-ACGT byte stays in the query and is counted by
+    AwFmIndex's ambiguity letter (unpinned: the library is absent).  The engine drops a position on ANY non-ACGT byte
+    inside its k-mer.  r1 holds one lone 'R': the two differ exactly on the k positions whose k-mer covers it -- there
+    the oracle's restatement of the reference (R matches R literally, so the k-mer is found once) reports k, the
+    engine 0 -- and nowhere else."""
+    g = mixed_genome
+    rec = g["r1"]
+    r_at = rec.find(b"R")
+    assert r_at == 250_000
+    k = 36
+    lo, hi = r_at - 2000, r_at + 2000
+    piece = rec[lo:hi]
+    seg = rd.Segment(b"r", piece, True)
+    want, _ = rd.linear_search_segment(g["oracle"], seg, [k], k, np.uint8, True)
+    with eng.Index(g["idx"], 0) as ix:
+        got, _ = ix.fixed_k_segment(piece, len(piece), [k])
+    differ = np.flatnonzero(got != want)
+    covers = np.arange(r_at - lo - k + 1, r_at - lo + 1)
+    assert set(differ.tolist()) <= set(covers.tolist())
+    assert (got[covers] == 0).all()
+    # (the restated reference: positions covering the R but not starting on it may be reported k -- the engine never does)
+    assert differ.size == int(np.count_nonzero(want[covers] != 0))
 
 
 def test_native_driver_equals_python_driver(tmp_path, golden_search, eng, monkeypatch):
@@ -544,8 +639,6 @@ def test_native_driver_equals_python_driver(tmp_path, golden_search, eng, monkey
         return {p.name: p.read_bytes() for p in sorted(out.iterdir())}
 
     for i, c in enumerate(golden_search):
-        if "quirk" in c["name"]:
-            continue
         d = tmp_path / f"n{i}"
         d.mkdir()
         fa, idx = _build_index(d, c["fasta"].encode("latin-1"))
@@ -554,6 +647,8 @@ def test_native_driver_equals_python_driver(tmp_path, golden_search, eng, monkey
         a = run(fa, idx, d / "native", False, **kw)
         b = run(fa, idx, d / "python", True, **kw)
         assert a == b, c["name"]
+        if "quirk" in c["name"]:                           # (the documented divergence: asserted in the fixture test above)
+            continue
         for rid, e in c["expected"].items():
             assert np.frombuffer(a[f"{rid}.unique.{e['dtype']}"], dtype=e["dtype"]).tolist() == e["values"]
     # odd FASTA shapes

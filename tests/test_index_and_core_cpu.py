@@ -41,9 +41,8 @@ def _engine_unique(sim, text, lengths, is_binary, batch, use_rc):
 
 @pytest.mark.parametrize("seed_len,force_big", [(0, False), (3, False), (6, True)])
 def test_core_reproduces_reference_fixtures(tmp_path, golden_search, seed_len, force_big):
+    whole = {c["name"]: c for c in golden_search}
     for c in golden_search:
-        if "quirk" in c["name"]:
-            continue
         text = c["fasta"].encode("latin-1")
         fa = _write(tmp_path, text)
         idx = tmp_path / "x.awfmi"
@@ -54,6 +53,12 @@ def test_core_reproduces_reference_fixtures(tmp_path, golden_search, seed_len, f
         for rid, exp in c["expected"].items():
             arr = got[rid.encode()]
             assert arr.dtype == np.dtype(exp["dtype"])
+            if "quirk" in c["name"]:
+                # documented divergence: the engine masks the lookahead; the reference's output at
+                # this batch size differs from the batch-independent answer in exactly the 39 positions 601..639
+                assert arr.tolist() == whole[c["name"].replace("_b640_quirk", "_whole")]["expected"][rid]["values"]
+                assert np.flatnonzero(arr != np.array(exp["values"])).tolist() == list(range(601, 640))
+                continue
             assert arr.tolist() == exp["values"], (c["name"], rid, seed_len)
 
 
@@ -233,7 +238,7 @@ def test_lf_blocks_equal_packed_rank_blocks(tmp_path, golden_search):
         sim.enable_lfb()
         assert sim.check_lfb() == 0
     for c in golden_search:
-        if not c["is_binary"] or not c["use_reverse_complement"]:
+        if not c["is_binary"] or not c["use_reverse_complement"] or "quirk" in c["name"]:
             continue
         t = c["fasta"].encode("latin-1")
         fa = _write(tmp_path, t)

@@ -1,5 +1,6 @@
-"""Randomised A/B soak on the GPU: the default range path (quad table + repeat probes, list modes routed through
-it) against the plain one-lane-per-position kernels without probes, on genomes with tandem arrays, dispersed and
+"""Randomised A/B soak on the GPU: the default range path (sites on the quad table + gated repeat probes + resolve,
+list modes routed through it; random cap of the group size; the > 2^31-row instantiations on every other index)
+against the plain one-lane-per-position kernels without probes, on genomes with tandem arrays, dispersed and
 reverse-complement copies, N runs and soft-masked stretches, cut into segments at random batch sizes.
 
     python tools/fuzz_gpu.py [--rounds 40] [--seed 1]
@@ -73,9 +74,12 @@ def main():
                 plain.set_kernel(1)
                 plain.set_repeat_probes(False)
                 plain.set_list_via_range(False)
+                fast.set_force_big(bool(rng.random() < 0.5))
                 w = fast.info()["quad_core_length"] + 3
                 for _ in range(6):
-                    kmin = int(rng.choice([w, w + 1, 20, 24, 36, 60, 61, 100, 124, int(rng.integers(1, 200))]))
+                    fast.set_site_d(int(rng.choice([60, 60, 60, 0, 1, 3, 17])))
+                    fast.set_repeat_probes(bool(rng.random() < 0.8))
+                    kmin = int(rng.choice([w, w + 1, 20, 24, 36, 60, 61, 62, 64, 100, 124, 125, 190, 252, 253, int(rng.integers(1, 200))]))
                     kmax = int(kmin + rng.choice([0, 1, 5, 40, 130, 231, int(rng.integers(0, 3000))]))
                     batch = int(rng.choice([1 << 30, 10_007, 65_536, int(rng.integers(500, 200_000))]))
                     lists = [[kmin], [kmin, kmax], sorted({kmin, (kmin + kmax) // 2, kmax}), [kmax, kmin]]

@@ -80,7 +80,8 @@ void nm_index_close(nm_index *ix);
  * 11 LF blocks in use, 13 repeat probes enabled; of the last
  * range-mode launch's repeat probes (waits for the device; 14..16 need
  * NM_OPT_COUNT_STEPS): 14 LF steps, 15 rank blocks read, 16 seed entries read, 17 positions
- * settled without a search; 18 core length of the quad table (0 = none) */
+ * settled without a search; 18 core length of the quad table (0 = none), 19 core length of the second quad table with
+ * short cores (0 = none), 20 core length of the table the sites of the last launch read */
 uint64_t nm_index_info(const nm_index *ix, int what);
 
 /* ------------------------------------------------------------------------- compat seam ------
@@ -127,8 +128,10 @@ int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, u
  * call: [0] ambiguous positions, [1] 1 if some k-mer was absent, [2] first absent position
  * (UINT64_MAX if none); and, only after nm_set_option(ix, NM_OPT_COUNT_STEPS, 1) -- the
  * "counter build" of the kernel used for roofline accounting -- [3] LF steps executed,
- * [4] distinct 32-byte rank blocks those steps read (lo and hi in one block count once),
- * [5] seed-table lookups, [6] strand-block reads, [7] positions searched. */
+ * [4] distinct rank structures those steps read (lo and hi in one block count once),
+ * [5] 8-byte table words read by the dominant kernel (k_sites: 4 per quad entry; k_min_unique / k_fixed_k: seed entries),
+ * [6] strand-block reads (--norc, compat counts) or, after k_sites, the table words k_resolve read (4 per second-chance
+ * entry, 1 per seed entry), [7] positions searched. */
 #define NM_STATUS_WORDS 8
 int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
                               uint32_t kmin, uint32_t kmax, int use_revcomp, int elem_bytes,
@@ -151,6 +154,8 @@ enum {
     NM_OPT_LIST_VIA_RANGE = 11,    /* list mode on both strands runs on the range kernels (one length: kmin = kmax = k;
                                       several lengths >= the quad window: the sites + the list form of k_resolve);
                                       default 1, 0 = always the list kernel, for A/B */
+    NM_OPT_SITE_TABLE = 13,        /* measurement / tests: which quad table the sites read: 0 pick per launch (default), 1 the one
+                                      with long cores, 2 the one with short cores (the other backs it up in k_resolve) */
     NM_OPT_SITE_D = 12             /* measurement / tests: cap (0..60, default 60) on d = kmin - (core length + 3); a site
                                       settles a group of d + 4 positions */
 };

@@ -23,6 +23,7 @@ NM_OPT_LF_BLOCKS = 9
 NM_OPT_REPEAT_PROBES = 10
 NM_OPT_LIST_VIA_RANGE = 11
 NM_OPT_SITE_D = 12
+NM_OPT_SITE_TABLE = 13
 
 EXPORTS = [
     "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_close",

@@ -51,6 +51,8 @@ struct nm_view {                // the index as the kernels see it
     const nm_lf_entry *lfb;     // LF blocks: one 16-byte load per LF step (nullptr = use the packed rank blocks)
     const uint64_t *quad;       // quad table: 4^quad_m entries of 4 x u64 (nullptr = not built), see nm_quad_build_one
     uint32_t quad_m;            // its core length; it answers windows of quad_m + 3 bases
+    const uint64_t *quad2;      // a second quad table with longer cores (nullptr = none): k_resolve's second chance
+    uint32_t quad2_m;
 };
 
 struct nm_tally {               // counter build only
@@ -858,6 +860,21 @@ NM_HD uint32_t nm_valid4(AmbWord amb_word, uint64_t q, uint32_t kmin, uint32_t &
         valid |= (uint32_t)ok << t;
     }
     return valid;
+}
+
+// Second chance (k_resolve): the sites of a launch may read a table with SHORT cores -- large groups, few table lines,
+// but more windows that are repeated.  A position they leave open first asks the table with longer cores: the entry
+// at P = p holds the bits of the windows at p .. p + 3, and any of them that occurs once inside the position's kmin-mer
+// (i <= kmin - w2) settles it.  One line instead of the seed entry plus the rank lines of a walk.  `w` = the 64 bases
+// from p on.
+NM_HD bool nm_second_chance(const nm_view &ix, const nm_window &w, uint32_t kmin) {
+    const uint32_t m = ix.quad2_m, len = m + NM_QUAD_EXT;
+    if (!nm_site_core_valid(w, m)) return false;
+    const uint64_t *e = ix.quad2 + nm_quad_slot(w, m) * 4;
+    const uint64_t ee[4] = {e[0], e[1], e[2], e[3]};
+    const uint32_t reach = kmin - len;                     // windows p + i with i <= reach lie inside the kmin-mer
+    const uint32_t usable = reach >= 3 ? 0xFu : (1u << (reach + 1)) - 1u;
+    return (nm_site_bits(w, m, ee) & usable) != 0;
 }
 
 // Which strides get a repeat probe when the probes run AFTER the sites: a stretch that occurs twice over more than a

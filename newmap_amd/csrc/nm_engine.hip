@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -450,6 +451,10 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
         for (uint32_t i = tid; i < n_walk; i += NM_RES_BLOCK) {
             const uint64_t p = wbase * 64 + q_p[i];
             bool amb0 = false, err = false;
+            if (ix.quad2) {                                // (an open position has kmin unambiguous bases)
+                t.seeds += 4;
+                if (nm_second_chance(ix, nm_load_window(enc, p), kmin)) { nm_store(out, elem_bytes, p, kmin); continue; }
+            }
             const uint32_t v = LIST ? nm_fixed_k_one<BIG, true>(ix, enc, p, seq_len, list, n_list, amb0, err, t)
                                     : nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
             if (err) { any_err = true; if (p < err_pos) err_pos = p; }
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
         if ((tid & 63) == 0 && (a | b | c)) {
             atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
             atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
-            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);           // table words read HERE ([5]: by k_sites)
         }
     }
 }
@@ -581,7 +586,9 @@ struct nm_index {
     void *d_rank = nullptr, *d_strand = nullptr, *d_sep = nullptr, *d_seed = nullptr, *d_super = nullptr;
     void *d_seed2 = nullptr;              // small secondary seed table (nm_view_for)
     uint32_t seed2_len = 0;
-    void *d_quad = nullptr;               // quad table (k_sites)
+    void *d_quad = nullptr;               // quad table (k_sites), cores as long as the memory allows
+    void *d_quad_small = nullptr;         // a second one with shorter cores: larger groups per line on small genomes
+    uint32_t quad_small_m = 0;
     void *d_lfb = nullptr;                // LF blocks
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
@@ -596,6 +603,8 @@ struct nm_index {
     bool repeat_probes = true;            // k_repeat_probe before the both-strand range kernels (NM_OPT_REPEAT_PROBES)
     uint64_t enc_words = 0;               // words written by the last nm_encode
     int kernel_version = 0;               // 0 = automatic (sites when the quad table applies, else 1); 1 / 5 force a kernel
+    uint32_t last_site_m = 0;             // core length of the table the sites of the last launch read (nm_index_info 20)
+    int site_table = 0;                   // measurement knob (NM_OPT_SITE_TABLE): 0 = pick per launch, 1 = long cores, 2 = short cores
     uint32_t site_d_cap = NM_SITE_MAX_D;  // measurement knob (NEWMAP_AMD_SITE_D): cap on d = kmin - window of the sites
     bool count_steps = false;
     int last_kernel = 0;                  // which range kernel the last launch used (nm_index_info 8)
@@ -669,15 +678,16 @@ static double nm_now() { return std::chrono::duration<double>(std::chrono::stead
 
 // quad table for cores of m bases, from the seed table of that length (a level of the seed-table build):
 // 4^m entries x 32 bytes
-static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m) {
-    ix->view.quad = nullptr;
-    ix->view.quad_m = 0;
+static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m, bool small = false) {
+    if (!small) { ix->view.quad = nullptr; ix->view.quad_m = 0; }
+    else ix->quad_small_m = 0;
     if (!level_table || m < 3 || m > 16 || ix->h.n < 2) return NM_OK;
     const uint64_t n_cores = 1ULL << (2 * m);
     double tq = nm_now();
-    if (hipMalloc(&ix->d_quad, n_cores * 32) != hipSuccess) {     // (someone else holds the memory: go on without the table)
+    void **slot = small ? &ix->d_quad_small : &ix->d_quad;
+    if (hipMalloc(slot, n_cores * 32) != hipSuccess) {     // (someone else holds the memory: go on without the table)
         (void)hipGetLastError();
-        ix->d_quad = nullptr;
+        *slot = nullptr;
         if (nm_verbose()) fprintf(stderr, "[open] quad table of %llu GB does not fit: range mode runs on the seed table\n",
                                   (unsigned long long)(n_cores * 32 >> 30));
         return NM_OK;
@@ -690,19 +700,19 @@ static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m) 
     const uint64_t slice = 1ULL << 30;
     for (uint64_t first = 0; first < n_cores; first += slice) {
         const uint64_t cnt = n_cores - first < slice ? n_cores - first : slice;
-        if (ix->big) hipLaunchKernelGGL(k_quad_build<true>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_quad, first, n_cores, m);
-        else         hipLaunchKernelGGL(k_quad_build<false>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)ix->d_quad, first, n_cores, m);
+        if (ix->big) hipLaunchKernelGGL(k_quad_build<true>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)*slot, first, n_cores, m);
+        else         hipLaunchKernelGGL(k_quad_build<false>, dim3(nm_grid(cnt)), dim3(NM_BLOCK), 0, ix->stream, v, (uint64_t *)*slot, first, n_cores, m);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(ix->stream));
     NM_PHASE(tq, "quad table kernels");
-    ix->view.quad = (const uint64_t *)ix->d_quad;
-    ix->view.quad_m = m;
+    if (small) ix->quad_small_m = m;
+    else { ix->view.quad = (const uint64_t *)ix->d_quad; ix->view.quad_m = m; }
     return NM_OK;
 }
 
 // quad_m: also derive the quad table from the level of that length (0 = none)
-static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table, uint32_t quad_m = 0) {
+static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table, uint32_t quad_m = 0, uint32_t quad_small_m = 0) {
     const uint64_t n_slots = 1ULL << (2 * s);
     double ts = nm_now();
     HIP_TRY(hipMalloc(d_table, n_slots * sizeof(uint64_t)));
@@ -720,6 +730,7 @@ static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table, uint32_
         rc = nm_seed_launch(ix, v, level == s0 ? nullptr : (const uint64_t *)cur, (uint64_t *)dst, level);
         if (rc == NM_OK && hipStreamSynchronize(ix->stream) != hipSuccess) { nm_set_error("seed table kernel failed"); rc = NM_E_DEVICE; }
         if (rc == NM_OK && level == quad_m) rc = nm_build_quad(ix, (const uint64_t *)dst, level);
+        if (rc == NM_OK && level == quad_small_m && quad_small_m != quad_m) rc = nm_build_quad(ix, (const uint64_t *)dst, level, true);
         if (cur) (void)hipFree(cur);
         cur = level < s ? dst : nullptr;
     }
@@ -771,11 +782,11 @@ static int nm_build_lf_blocks(nm_index *ix) {
     return NM_OK;
 }
 
-static int nm_build_seed(nm_index *ix, uint32_t s, uint32_t quad_m = 0) {
+static int nm_build_seed(nm_index *ix, uint32_t s, uint32_t quad_m = 0, uint32_t quad_small_m = 0) {
     ix->view.seed = nullptr;
     ix->view.seed_len = 0;
     if (s == 0 || ix->h.n < 2) return NM_OK;
-    int rc = nm_build_seed_table(ix, s, &ix->d_seed, quad_m);
+    int rc = nm_build_seed_table(ix, s, &ix->d_seed, quad_m, quad_small_m);
     if (rc != NM_OK) return rc;
     ix->view.seed = (const uint64_t *)ix->d_seed;
     ix->view.seed_len = s;
@@ -895,6 +906,8 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.lfb = nullptr;
     v.quad = nullptr;
     v.quad_m = 0;
+    v.quad2 = nullptr;
+    v.quad2_m = 0;
 
     if (seed_len_override < -1 && h.n >= 2) {
         const char *off = getenv("NEWMAP_AMD_LF_BLOCKS");
@@ -922,7 +935,20 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         if (quad_m > s) quad_m = s;
         if (quad_m && quad_m < 8) quad_m = 8;              // the level-wise build starts at length 8
     }
-    rc = nm_build_seed(ix, s, quad_m);
+    // a second quad table with SHORT cores (larger groups per table line, nm_core.h "sites"): windows of
+    // ceil(log4(20 n)) bases -- about one in twenty repeated -- when that is shorter than the first table's and the
+    // table stays below 9 GB (cores <= 14); NEWMAP_AMD_QUAD_SMALL_M overrides (0 = none)
+    uint32_t quad_small_m = 0;
+    if (quad_m) {
+        uint32_t w1 = 1;
+        while (w1 < 32 && (double)(1ULL << (2 * w1)) < 20.0 * (double)h.n) w1++;
+        quad_small_m = w1 > NM_QUAD_EXT + 8 ? w1 - NM_QUAD_EXT : 8;
+        if (quad_small_m > 14) quad_small_m = 14;
+        if (const char *q = getenv("NEWMAP_AMD_QUAD_SMALL_M")) quad_small_m = (uint32_t)atoi(q);
+        if (quad_small_m && quad_small_m < 8) quad_small_m = 8;
+        if (quad_small_m >= quad_m) quad_small_m = 0;
+    }
+    rc = nm_build_seed(ix, s, quad_m, quad_small_m);
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     if (const char *cm = getenv("NEWMAP_AMD_COARSE_MIN")) ix->coarse_min = strtoull(cm, nullptr, 10);
     if (const char *cm = getenv("NEWMAP_AMD_COARSE")) ix->coarse_mode = atoi(cm);
@@ -949,7 +975,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
                     ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p, ix->settled.p, ix->coarse.p, ix->need.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -978,6 +1004,8 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 12: return 0;                                 // (two-step rank blocks: removed)
         case 13: return ix->repeat_probes ? 1 : 0;
         case 18: return ix->view.quad_m;
+        case 19: return ix->quad_small_m;
+        case 20: return ix->last_site_m;
         case 14: case 15: case 16: case 17: {              // probe tally of the last range-mode launch
             unsigned long long v = 0;
             if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
@@ -1016,6 +1044,11 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (option == NM_OPT_SITE_D) {         // measurement / tests: cap on d = kmin - window of the sites (a group = d + 4 positions)
         if (value < 0 || value > (int64_t)NM_SITE_MAX_D) { nm_set_error("site d cap must be 0..%u", NM_SITE_MAX_D); return NM_E_ARGUMENT; }
         ix->site_d_cap = (uint32_t)value;
+        return NM_OK;
+    }
+    if (option == NM_OPT_SITE_TABLE) {
+        if (value < 0 || value > 2) { nm_set_error("site table must be 0 (pick per launch), 1 (long cores) or 2 (short cores)"); return NM_E_ARGUMENT; }
+        ix->site_table = (int)value;
         return NM_OK;
     }
     if (option == NM_OPT_KERNEL) {
@@ -1111,19 +1144,59 @@ static int nm_launch_probes(nm_index *ix, const nm_view &view, uint64_t n, uint3
 
 // can the sites (k_sites + k_resolve) take a both-strand search whose shortest length is kmin?
 static bool nm_sites_apply(const nm_index *ix, const nm_view &view, uint32_t kmin) {
-    return (ix->kernel_version == 0 || ix->kernel_version == 5) && view.quad && kmin >= view.quad_m + NM_QUAD_EXT && kmin <= NM_SITE_MAX_KMIN;
+    if (!((ix->kernel_version == 0 || ix->kernel_version == 5) && view.quad && kmin <= NM_SITE_MAX_KMIN)) return false;
+    return kmin >= view.quad_m + NM_QUAD_EXT || (ix->d_quad_small && ix->quad_small_m && kmin >= ix->quad_small_m + NM_QUAD_EXT);
+}
+
+// Expected table lines per position when the sites read the table with cores of m bases (windows of w = m + 3): one line
+// per group of G = kmin - w + 4 positions, plus what the positions cost that no window settles.  f = share of repeated
+// windows among the w-mers of a text of n symbols (uniform model); the first and last position of a group lie in one
+// window, the others in at least two.
+static double nm_site_cost(uint64_t n, uint32_t m, uint32_t kmin, uint32_t d_cap, double next_cost) {
+    const uint32_t w = m + NM_QUAD_EXT;
+    uint32_t d = kmin - w;
+    if (d > d_cap) d = d_cap;
+    const double G = d + 4.0;
+    const double f = 1.0 - exp(-(double)n / pow(4.0, (double)w));
+    const double open = d == 0 ? f : (2.0 * f + (G - 2.0) * f * f) / G;
+    return 1.0 / G + open * next_cost;
+}
+
+// which quad table the sites of this launch read (view.quad) and which one backs them up in k_resolve (view.quad2)
+static void nm_pick_site_tables(nm_index *ix, nm_view &view, uint32_t kmin) {
+    const uint64_t *big = view.quad, *small = (const uint64_t *)ix->d_quad_small;
+    const uint32_t big_m = view.quad_m, small_m = ix->quad_small_m;
+    view.quad2 = nullptr;
+    view.quad2_m = 0;
+    const bool big_ok = big && kmin >= big_m + NM_QUAD_EXT, small_ok = small && small_m && kmin >= small_m + NM_QUAD_EXT;
+    if (!small_ok) return;
+    bool use_small;
+    if (ix->site_table == 1 && big_ok) use_small = false;
+    else if (ix->site_table == 2 || !big_ok) use_small = true;
+    else {
+        const double walk = 4.0;                                              // seed entry + rank lines of a short walk
+        const double f_big = 1.0 - exp(-(double)ix->h.n / pow(4.0, (double)(big_m + NM_QUAD_EXT)));
+        use_small = nm_site_cost(ix->h.n, small_m, kmin, ix->site_d_cap, 1.0 + f_big * walk) < nm_site_cost(ix->h.n, big_m, kmin, ix->site_d_cap, walk);
+    }
+    if (use_small) {
+        view.quad = small; view.quad_m = small_m;
+        if (big_ok) { view.quad2 = big; view.quad2_m = big_m; }
+    }
 }
 
 // k_sites -> repeat probes where the bitmap is dense -> k_resolve, over positions [0, n).  Range mode: kmin .. kmax.
 // List mode (d_list != nullptr): kmin = the first listed length, kmax = the longest.
 template <bool BIG>
-static int launch_sites(nm_index *ix, const nm_view &view, uint64_t n, uint32_t kmin, uint32_t kmax, void *d_out, int elem_bytes,
+static int launch_sites(nm_index *ix, const nm_view &view_in, uint64_t n, uint32_t kmin, uint32_t kmax, void *d_out, int elem_bytes,
                         uint64_t *d_status, hipStream_t st, uint64_t seq_len = 0, const uint32_t *d_list = nullptr, uint32_t n_list = 0) {
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
     const uint64_t n_need = (n + 63) / 64;
     int rc = nm_grow(ix->need, (n_need + 1) * sizeof(uint64_t));
     if (rc != NM_OK) return rc;
     uint64_t *need = (uint64_t *)ix->need.p;
+    nm_view view = view_in;
+    nm_pick_site_tables(ix, view, kmin);
+    ix->last_site_m = view.quad_m;
     uint32_t d = kmin - (view.quad_m + NM_QUAD_EXT);
     if (d > ix->site_d_cap) d = ix->site_d_cap;
     const uint32_t bp = nm_site_block_positions(d);
@@ -1240,10 +1313,10 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
             first = head;
         }
     }
-    // several lengths, all at least as long as the quad table's window: the sites with the FIRST length in the place
-    // of kmin (a position whose first-length k-mer contains a window that occurs once is unique at that length), the
-    // list form of k_resolve for the rest
-    if (nk > 1 && use_revcomp && ix->list_via_range && kshort >= view.quad_m + NM_QUAD_EXT && nm_sites_apply(ix, view, ks[0]) && seq_len >= kmax) {
+    // several lengths, the first one at least as long as a quad table's window: the sites with the FIRST length in the
+    // place of kmin (a position whose first-length k-mer contains a window that occurs once is unique at that length:
+    // the answer, whatever the other lengths are), the list form of k_resolve for the rest
+    if (nk > 1 && use_revcomp && ix->list_via_range && nm_sites_apply(ix, view, ks[0]) && seq_len >= kmax) {
         const uint64_t head = num_kmers < seq_len - kmax + 1 ? num_kmers : seq_len - kmax + 1;
         if (head) {
             rc = ix->big ? launch_sites<true>(ix, view, head, ks[0], kmax, d_out, elem_bytes, d_status, st, seq_len, d_ks, nk)

@@ -95,6 +95,8 @@ class Index:
                  "lf_blocks", "two_step_blocks", "repeat_probes"]
         d = {n: int(self._L.nm_index_info(self.handle, i)) for i, n in enumerate(names)}
         d["quad_core_length"] = int(self._L.nm_index_info(self.handle, 18))
+        d["quad_small_core_length"] = int(self._L.nm_index_info(self.handle, 19))
+        d["last_site_core_length"] = int(self._L.nm_index_info(self.handle, 20))
         return d
 
     def probe_tally(self) -> dict:
@@ -126,6 +128,10 @@ class Index:
     def set_site_d(self, d_cap: int):
         """measurement / tests: cap on d = kmin - (quad core length + 3); a site settles a group of d + 4 positions"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SITE_D, int(d_cap)))
+
+    def set_site_table(self, which: int):
+        """measurement / tests: the quad table the sites read: 0 = picked per launch, 1 = long cores, 2 = short cores"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SITE_TABLE, int(which)))
 
     def set_force_big(self, on: bool):
         """tests: exercise the code path of indexes beyond 2^31 positions on a small index"""

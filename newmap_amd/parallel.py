@@ -41,6 +41,31 @@ def shard_bounds(total: int, world: int) -> list[tuple[int, int]]:
     return [(min(r * per, total), min((r + 1) * per, total)) for r in range(world)]
 
 
+def interleaved_ranges(total: int, world: int, target: int = 64 << 20) -> list[list[tuple[int, int]]]:
+    """The global position space [0, total) cut into world x R equal chunks of about `target` positions, chunk c owned
+    by rank c % world: every rank gets the same number of positions (to within R), and a stretch that is expensive to
+    search -- a cluster of long repeats (BASELINE configs[4]) -- is spread over all ranks instead of landing on one
+    ("dealt round-robin rather than whole chromosomes").  Returns the ranges of every rank."""
+    if total <= 0:
+        return [[] for _ in range(world)]
+    rounds = max(1, -(-total // (world * max(int(target), 1))))
+    n_chunks = world * rounds
+    edges = [total * c // n_chunks for c in range(n_chunks + 1)]
+    out: list[list[tuple[int, int]]] = [[] for _ in range(world)]
+    for c in range(n_chunks):
+        if edges[c + 1] > edges[c]:
+            out[c % world].append((edges[c], edges[c + 1]))
+    return out
+
+
+def units_for_ranges(record_lengths: Sequence[int], ranges: Sequence[tuple[int, int]], batch: int, kmax: int) -> list[Unit]:
+    """work units covering the given ranges of global positions, in order"""
+    units: list[Unit] = []
+    for lo, hi in ranges:
+        units.extend(units_for_slice(record_lengths, lo, hi, batch, kmax))
+    return units
+
+
 def units_for_slice(record_lengths: Sequence[int], lo: int, hi: int, batch: int, kmax: int) -> list[Unit]:
     """work units covering global positions [lo, hi) (global = records laid end to end)"""
     units: list[Unit] = []

@@ -41,6 +41,8 @@ def lib():
     L.hs_min_unique.argtypes = [vp, vp, u64, u64, u32, u32, i32, i32, vp, vp]
     L.hs_repeat_probes.restype = u64
     L.hs_repeat_probes.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, vp, vp]
+    L.hs_build_quad2.restype = i32
+    L.hs_build_quad2.argtypes = [vp, u32]
     L.hs_valid_bits.argtypes = [vp, u64, u32, vp]
     L.hs_sites.restype = i32
     L.hs_sites.argtypes = [vp, vp, u64, u64, u32, u32, u32, i32, vp, u32, i32, vp, vp, vp, vp]
@@ -80,6 +82,10 @@ class HostSim:
         bit four neighbouring positions can read with a direct count; returns the number of wrong bits"""
         return int(self.L.hs_check_quad(self.h))
 
+    def build_quad2(self, m2):
+        """a second quad table with cores of m2 bases: k_resolve asks it before it walks (nm_second_chance)"""
+        assert self.L.hs_build_quad2(self.h, m2) == 0
+
     def info(self, what):
         return int(self.L.hs_info(self.h, what))
 
@@ -110,7 +116,7 @@ class HostSim:
         out = np.zeros(max(num_kmers, 1), dtype=dtype)
         status = np.zeros(8, dtype=np.uint64)
         need = np.zeros((num_kmers + 63) // 64 + 1, dtype=np.uint64)
-        counters = np.zeros(4, dtype=np.uint64)
+        counters = np.zeros(5, dtype=np.uint64)
         k = np.asarray(ks if ks is not None else [], dtype=np.uint32)
         rc = self.L.hs_sites(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, d_cap, probes,
                              k.ctypes.data if k.size else None, k.size, out.dtype.itemsize, out.ctypes.data,

@@ -18,7 +18,7 @@ struct hs_index {
     std::vector<nm_strand_block> strand;
     std::vector<uint64_t> sep, seed, superC;
     std::vector<nm_lf_entry> lfb;
-    std::vector<uint64_t> quad;
+    std::vector<uint64_t> quad, quad2;
     nm_view v;
     bool big;
 };
@@ -64,7 +64,7 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
     v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
     v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
-    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.lfb = nullptr; v.quad = nullptr; v.quad_m = 0;
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.lfb = nullptr; v.quad = nullptr; v.quad_m = 0; v.quad2 = nullptr; v.quad2_m = 0;
     uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
     if (s > 12) s = 12;                     // keep the simulated table small
     if (s && h.n >= 2) {
@@ -142,6 +142,25 @@ uint64_t hs_check_quad(hs_index *ix) {
         }
     }
     return bad;
+}
+// a second quad table with longer cores (k_resolve's second chance), from a temporary seed table of that length
+int hs_build_quad2(hs_index *ix, uint32_t m2) {
+    if (m2 < 3 || m2 > 9) return -1;
+    const uint64_t cores = 1ULL << (2 * m2);
+    std::vector<uint64_t> seed(cores);
+    nm_view v = ix->v;
+    for (uint64_t slot = 0; slot < cores; slot++)
+        seed[slot] = ix->big ? nm_seed_entry<true>(v, slot, m2) : nm_seed_entry<false>(v, slot, m2);
+    v.seed = seed.data();
+    v.seed_len = m2;
+    ix->quad2.assign(cores * 4, 0);
+    for (uint64_t Z = 0; Z < cores; Z++) {
+        if (ix->big) nm_quad_build_one<true>(v, Z, m2, ix->quad2.data());
+        else nm_quad_build_one<false>(v, Z, m2, ix->quad2.data());
+    }
+    ix->v.quad2 = ix->quad2.data();
+    ix->v.quad2_m = m2;
+    return 0;
 }
 // level-wise seed construction must reproduce the entry-by-entry one
 uint64_t hs_check_levels(hs_index *ix, uint32_t s) {
@@ -258,7 +277,7 @@ uint64_t hs_repeat_probes(hs_index *ix, const uint8_t *seq, uint64_t seq_len, ui
 // Needs the quad table (hs_check_quad builds it from the simulated seed table; core length = seed length).
 // probes: 0 none, 1 fine, 2 coarse + fine.  list / n_list: list mode (kmin = first length, kmax = the longest).
 // need_out (may be null): the bitmap k_sites leaves.  counters[0] = table entries read, [1] = positions walked,
-// [2] = fine probes run, [3] = positions the probes decided.  Returns 0 ok, 8 k-mer not found, -1 not applicable.
+// [2] = fine probes run, [3] = positions the probes decided, [4] = positions the second table settled.  Returns 0 ok, 8 k-mer not found, -1 not applicable.
 int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, uint32_t d_cap,
              int probes, const uint32_t *list, uint32_t n_list, int elem_bytes, void *out, uint64_t *status,
              uint64_t *need_out, uint64_t *counters) {
@@ -270,7 +289,7 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
     const uint64_t n_enc_words = enc.size();
     for (int i = 0; i < 8; i++) status[i] = 0;
     status[2] = ~0ULL;
-    for (int i = 0; i < 4; i++) counters[i] = 0;
+    for (int i = 0; i < 5; i++) counters[i] = 0;
     auto store = [&](uint64_t p, uint32_t val) {
         if (elem_bytes == 1) ((uint8_t *)out)[p] = (uint8_t)val;
         else if (elem_bytes == 2) ((uint16_t *)out)[p] = (uint16_t)val;
@@ -385,6 +404,10 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             bool amb0 = false, err = false;
             nm_tally t = {0, 0, 0, 0};
             uint32_t val;
+            if (v.quad2 && kmin >= v.quad2_m + NM_QUAD_EXT) {
+                status[5] += 4;
+                if (nm_second_chance(v, nm_load_window(enc.data(), p), kmin)) { store(p, kmin); counters[4]++; continue; }
+            }
             if (list) val = ix->big ? nm_fixed_k_one<true, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t)
                                     : nm_fixed_k_one<false, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t);
             else      val = ix->big ? nm_min_unique_one<true, true>(v, enc.data(), p, kmin, kmax, amb0, err, t)

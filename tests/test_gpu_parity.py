@@ -485,8 +485,8 @@ def test_both_range_kernels_agree(mixed_genome, eng):
     g = mixed_genome
     with eng.Index(g["idx"], 0) as ix:
         info = ix.info()
-        assert 8 <= info["quad_core_length"] <= info["seed_length"]
-        w = info["quad_core_length"] + 3
+        assert 8 <= info["quad_small_core_length"] < info["quad_core_length"] <= info["seed_length"]
+        w = info["quad_small_core_length"] + 3                # the shortest window the sites can use
         for rec in (g["r1"], g["r2"]):
             for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (w + 1, 64), (60, 90), (61, 90), (62, 90),
                                (64, 64), (100, 300), (124, 200), (125, 200), (252, 255), (253, 255)):
@@ -503,13 +503,17 @@ def test_both_range_kernels_agree(mixed_genome, eng):
                         ix.set_kernel(kernel)
                         for probes in (True, False):
                             ix.set_repeat_probes(probes)
-                            for d_cap in ((60, 0, 2) if kernel == 5 and probes else (60,)):
+                            for d_cap, table in (((60, 0), (0, 1), (2, 2), (60, 1), (60, 2)) if kernel == 5 and probes else ((60, 0),)):
                                 ix.set_site_d(d_cap)
+                                ix.set_site_table(table)          # picked per launch / long cores / short cores + second chance
                                 c, amb_c = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                                 used = ix.info()["last_range_kernel"]
                                 assert used == (5 if sites_ok and kernel != 1 else 1), (kernel, kmin, used)
-                                assert np.array_equal(a, c) and amb_c == amb_a, (kernel, big, probes, d_cap, kmin, kmax)
+                                assert np.array_equal(a, c) and amb_c == amb_a, (kernel, big, probes, d_cap, table, kmin, kmax)
+                                if used == 5 and table == 2:
+                                    assert ix.info()["last_site_core_length"] == info["quad_small_core_length"]
                 ix.set_site_d(60)
+                ix.set_site_table(0)
                 ix.set_force_big(False)
                 ix.set_kernel(0)
                 ix.set_repeat_probes(True)

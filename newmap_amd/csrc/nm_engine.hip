@@ -49,7 +49,8 @@ static __device__ __forceinline__ uint64_t nm_seed_load_policy(const nm_view &ix
 
 // ------------------------------------------------------------------------------ kernels ----
 
-#define NM_WORK_WORDS 8             /* handle-owned counters: [0] chunk counter of k_min_unique_v2, [1..4] probe tally */
+#define NM_WORK_WORDS 8             /* handle-owned counters: [1..4] probe tally, [5] NM_WORK_OPEN */
+#define NM_WORK_OPEN 5              /* some block of k_sites left positions open: k_repeat_probe / k_resolve have work (tally = work + 1) */
 
 // the status words of a launch (and the handle's counters) start from zero; folded into the encode
 // pass so that a segment costs one launch less (k_reset_status does the same on its own)
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe_coarse(nm_view ix, co
                                                                   uint32_t kmax, uint32_t *__restrict__ coarse,
                                                                   unsigned long long *__restrict__ probe_tally,
                                                                   const uint64_t *__restrict__ need, uint64_t n_need) {
+    if (need && probe_tally[NM_WORK_OPEN - 1] == 0) return;          // (after k_sites: nothing was left open, k_resolve returns at once too)
     const uint64_t c = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     nm_tally t = {0, 0, 0, 0};
     if (c < n_coarse) {
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe(nm_view ix, const nm_
                                                            const uint32_t *__restrict__ coarse, volatile uint32_t *repeats_seen,
                                                            uint32_t *__restrict__ seen_latch,
                                                            const uint64_t *__restrict__ need, uint64_t n_need) {
+    if (need && probe_tally[NM_WORK_OPEN - 1] == 0) return;          // (after k_sites: nothing was left open, k_resolve returns at once too)
     const uint64_t j = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     nm_tally t = {0, 0, 0, 0};
     uint32_t c = 0;
@@ -280,11 +283,17 @@ static inline size_t nm_site_lds_bytes(uint32_t d) {
     return (size_t)(bp / 64 + 5) * 24 + (size_t)bp / 8 * 2;
 }
 
-template <bool STATS>
+#define NM_SITE_WALK_MAX 64u        /* open positions a block finishes itself (seed table + walk); more: left to the probes and k_resolve */
+
+template <bool BIG, bool STATS, bool LIST>
 __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_enc_words,
-                                                         uint64_t num_kmers, uint32_t kmin, uint32_t d, void *__restrict__ out,
-                                                         int elem_bytes, uint64_t *__restrict__ status, uint64_t *__restrict__ need) {
+                                                         uint64_t num_kmers, uint32_t kmin, uint32_t kmax, uint32_t d, void *__restrict__ out,
+                                                         int elem_bytes, uint64_t *__restrict__ status, uint64_t *__restrict__ need,
+                                                         unsigned long long *__restrict__ work, uint64_t seq_len,
+                                                         const uint32_t *__restrict__ list, uint32_t n_list) {
     extern __shared__ uint64_t s_mem[];
+    __shared__ uint32_t s_open_total, s_qn;
+    __shared__ uint32_t s_q[NM_SITE_WALK_MAX];
     const uint32_t G = d + 4, m = ix.quad_m;
     const uint32_t BP = NM_SITE_BLOCK * NM_SITE_PER_LANE * G;          // a multiple of 512
     const uint32_t n_stage = BP / 64 + 5;
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
         s_amb[i] = enc[wi].amb;
     }
     for (uint32_t i = tid; i < BP / 16; i += NM_SITE_BLOCK) s_set[i] = 0;          // both bitmaps
+    if (tid == 0) { s_open_total = 0; s_qn = 0; }
     __syncthreads();
     auto lds_window = [&](uint32_t rel) -> nm_window {
         const uint32_t wi = rel >> 6, sh = rel & 63;
@@ -344,10 +354,12 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
         }
     }
     __syncthreads();
-    // ---- phase 2: elements and open bits, four positions per lane and turn, in position order
-    uint32_t n_amb = 0, n_searched = 0;
+    // ---- phase 2: elements and open bits, four positions per lane and turn, in position order.  A position no site
+    // settled asks the table with the longer cores first (nm_second_chance; its window is already in LDS)
+    uint32_t n_amb = 0, n_searched = 0, n_open = 0;
     auto amb_word = [&](uint64_t i) -> uint64_t { return s_amb[i]; };
     const bool wide = elem_bytes == 1 && (((uintptr_t)out) & 3u) == 0;
+    const bool chance = ix.quad2 != nullptr && kmin >= ix.quad2_m + NM_QUAD_EXT;
     for (uint32_t j = tid; j < BP / 4; j += NM_SITE_BLOCK) {
         const uint32_t rel = 4 * j;
         const uint64_t q = base + rel;
@@ -357,10 +369,18 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
         uint32_t own_amb;
         const uint32_t valid = nm_valid4(amb_word, rel, kmin, own_amb) & inb;
         const uint32_t set4 = (s_set[rel >> 5] >> (rel & 31)) & 0xFu;
-        const uint32_t hit = valid & set4, open = valid & ~set4;
+        uint32_t hit = valid & set4, open = valid & ~set4;
         n_amb += (uint32_t)__builtin_popcount(own_amb & inb);
         n_searched += (uint32_t)__builtin_popcount(~own_amb & inb);
-        if (open) atomicOr(&s_need[rel >> 5], open << (rel & 31));
+        if (open && chance) {
+#pragma unroll
+            for (uint32_t t = 0; t < 4; t++) {
+                if (!((open >> t) & 1u)) continue;
+                n_entries += 4;
+                if (nm_second_chance(ix, lds_window(rel + t), kmin)) { hit |= 1u << t; open &= ~(1u << t); }
+            }
+        }
+        if (open) { atomicOr(&s_need[rel >> 5], open << (rel & 31)); n_open += (uint32_t)__builtin_popcount(open); }
         if (wide && inb == 0xFu) {
             reinterpret_cast<uint32_t *>(out)[q >> 2] = (hit & 1u ? kmin : 0u) | (hit & 2u ? kmin << 8 : 0u) |
                                                          (hit & 4u ? kmin << 16 : 0u) | (hit & 8u ? kmin << 24 : 0u);
@@ -370,17 +390,54 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
                 if ((inb >> t) & 1u) nm_store(out, elem_bytes, q + t, (hit >> t) & 1u ? kmin : 0u);
         }
     }
+    if (n_open) atomicAdd(&s_open_total, n_open);
     __syncthreads();
+    // ---- phase 3: a few open positions (the rule outside long repeats): the block finishes them itself -- seed table +
+    // walk -- and hands an empty bitmap on.  Many: they stay for the repeat probes and k_resolve.
+    const uint32_t open_total = s_open_total;
+    nm_tally t = {0, 0, 0, 0};
+    bool any_err = false;
+    uint64_t err_pos = ~0ULL;
+    const bool self = open_total && open_total <= NM_SITE_WALK_MAX && !(ix.seed_policy & 0x100u);
+    if (self) {
+        for (uint32_t i = tid; i < BP / 32; i += NM_SITE_BLOCK) {
+            uint32_t bits = s_need[i];
+            if (!bits) continue;
+            s_need[i] = 0;
+            for (; bits; bits &= bits - 1) s_q[atomicAdd(&s_qn, 1u)] = i * 32 + (uint32_t)__builtin_ctz(bits);
+        }
+        __syncthreads();
+        if (tid < s_qn) {
+            const uint64_t p = base + s_q[tid];
+            bool amb0 = false, err = false;
+            const uint32_t v = LIST ? nm_fixed_k_one<BIG, true>(ix, enc, p, seq_len, list, n_list, amb0, err, t)
+                                    : nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
+            if (err) { any_err = true; err_pos = p; }
+            nm_store(out, elem_bytes, p, v);
+        }
+    } else if (open_total && tid == 0) {
+        atomicOr(&work[NM_WORK_OPEN], 1ULL);
+    }
     for (uint32_t i = tid; i < BP / 64; i += NM_SITE_BLOCK)
-        if (base + 64ull * i < num_kmers) need[w0 + i] = (uint64_t)s_need[2 * i] | ((uint64_t)s_need[2 * i + 1] << 32);
+        if (base + 64ull * i < num_kmers) need[w0 + i] = self ? 0ULL : ((uint64_t)s_need[2 * i] | ((uint64_t)s_need[2 * i + 1] << 32));
 
     const uint32_t amb_sum = wave_sum(n_amb);
     if ((tid & 63) == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
+    if (__ballot(any_err)) {
+        if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
+        if ((tid & 63) == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
+    }
     if (STATS) {
         const uint32_t c = wave_sum(n_entries), f = wave_sum(n_searched);
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), g = wave_sum(t.seeds);
         if ((tid & 63) == 0) {
-            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);           // 8-byte table words read
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)c);           // 8-byte table words read by the sites
             atomicAdd((unsigned long long *)&status[7], (unsigned long long)f);
+            if (a | b | g) {                                                                // the block's own walks
+                atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
+                atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
+                atomicAdd((unsigned long long *)&status[6], (unsigned long long)g);
+            }
         }
     }
 }
@@ -401,11 +458,23 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
                                                           uint32_t kmin, uint32_t kmax, void *__restrict__ out, int elem_bytes,
                                                           uint64_t *__restrict__ status, const uint64_t *__restrict__ need,
                                                           uint64_t n_need, const uint32_t *__restrict__ probe,
+                                                          const unsigned long long *__restrict__ work,
                                                           uint64_t seq_len, const uint32_t *__restrict__ list, uint32_t n_list) {
+    if (work[NM_WORK_OPEN] == 0) return;                   // every block of k_sites finished its own positions
     __shared__ uint32_t q_p[NM_RES_QCAP];
     __shared__ uint32_t q_n;
     const uint32_t tid = threadIdx.x;
     const uint64_t wbase = (uint64_t)blockIdx.x * NM_RES_WORDS;
+    constexpr uint32_t PER = NM_RES_WORDS / NM_RES_BLOCK;
+    uint64_t mine[PER];                                    // the lane's words, loaded together
+    uint64_t any = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) {
+        const uint64_t wi = wbase + tid + (uint64_t)NM_RES_BLOCK * r;
+        mine[r] = wi < n_need ? need[wi] : 0ULL;
+        any |= mine[r];
+    }
+    if (!__syncthreads_or(any != 0)) return;
     uint32_t r = 0;                                        // words of this lane taken so far
     uint64_t bits = 0, cur = 0;                            // open bits left in the current word, its index
     uint32_t wj = 0, wj1 = 0;                              // probe words of the current stride and of the next one
@@ -418,11 +487,10 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
         // ---- scan
         for (;;) {
             if (!bits) {
-                if (r >= NM_RES_WORDS / NM_RES_BLOCK) break;
+                if (r >= PER) break;
                 cur = wbase + tid + (uint64_t)NM_RES_BLOCK * r;
+                bits = r == 0 ? mine[0] : (r == 1 ? mine[1] : (r == 2 ? mine[2] : mine[3]));
                 r++;
-                if (cur >= n_need) { r = NM_RES_WORDS / NM_RES_BLOCK; break; }
-                bits = need[cur];
                 if (bits && probe) {
                     wj = probe[cur]; wj1 = probe[cur + 1];
                     const uint32_t zeros = wj & 0xFFu;     // positions repeated over more than kmax bases: element 0, as stored
@@ -447,20 +515,16 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
         }
         __syncthreads();
         // ---- walk
-        const uint32_t n_walk = q_n < NM_RES_QCAP ? q_n : NM_RES_QCAP;
+        const uint32_t n_walk = (ix.seed_policy & 0x100u) ? 0u : (q_n < NM_RES_QCAP ? q_n : NM_RES_QCAP);   // (0x100: timing experiment, wrong results)
         for (uint32_t i = tid; i < n_walk; i += NM_RES_BLOCK) {
             const uint64_t p = wbase * 64 + q_p[i];
             bool amb0 = false, err = false;
-            if (ix.quad2) {                                // (an open position has kmin unambiguous bases)
-                t.seeds += 4;
-                if (nm_second_chance(ix, nm_load_window(enc, p), kmin)) { nm_store(out, elem_bytes, p, kmin); continue; }
-            }
             const uint32_t v = LIST ? nm_fixed_k_one<BIG, true>(ix, enc, p, seq_len, list, n_list, amb0, err, t)
                                     : nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
             if (err) { any_err = true; if (p < err_pos) err_pos = p; }
             nm_store(out, elem_bytes, p, v);
         }
-        const bool done = !bits && r >= NM_RES_WORDS / NM_RES_BLOCK;
+        const bool done = !bits && r >= PER;
         if (__syncthreads_and(done)) break;
     }
     (void)num_kmers;
@@ -473,7 +537,7 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
         if ((tid & 63) == 0 && (a | b | c)) {
             atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
             atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
-            atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);           // table words read HERE ([5]: by k_sites)
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);           // table words read HERE ([5]: by the sites)
         }
     }
 }
@@ -1025,7 +1089,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_SEED_POLICY) {
-        if (value < 0 || (value & 0xFF) > 2 || value > 0x3FF) { nm_set_error("seed policy must be 0, 1 or 2 (+ 0x100 / 0x200 timing experiments)"); return NM_E_ARGUMENT; }
+        if (value < 0 || (value & 0xFF) > 2 || value > 0x7FF) { nm_set_error("seed policy must be 0, 1 or 2 (+ 0x100 / 0x200 timing experiments)"); return NM_E_ARGUMENT; }
         ix->view.seed_policy = (uint32_t)value;
         return NM_OK;
     }
@@ -1194,6 +1258,7 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, uint64_t n, uint32
     int rc = nm_grow(ix->need, (n_need + 1) * sizeof(uint64_t));
     if (rc != NM_OK) return rc;
     uint64_t *need = (uint64_t *)ix->need.p;
+    unsigned long long *work = (unsigned long long *)ix->work.p;
     nm_view view = view_in;
     nm_pick_site_tables(ix, view, kmin);
     ix->last_site_m = view.quad_m;
@@ -1205,14 +1270,17 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, uint64_t n, uint32
     ix->last_kernel = 5;
     {
         nm_timed timed(ix, st);
-        if (ix->count_steps) hipLaunchKernelGGL((k_sites<true>), sgrid, sblock, lds, st, view, enc, ix->enc_words, n, kmin, d, d_out, elem_bytes, d_status, need);
-        else                 hipLaunchKernelGGL((k_sites<false>), sgrid, sblock, lds, st, view, enc, ix->enc_words, n, kmin, d, d_out, elem_bytes, d_status, need);
+#define NM_LAUNCH_SITES(STATS_, LIST_) hipLaunchKernelGGL((k_sites<BIG, STATS_, LIST_>), sgrid, sblock, lds, st, view, enc, ix->enc_words, n, kmin, kmax, d, d_out, \
+                                                          elem_bytes, d_status, need, work, seq_len, d_list, n_list)
+        if (d_list) { if (ix->count_steps) NM_LAUNCH_SITES(true, true); else NM_LAUNCH_SITES(false, true); }
+        else        { if (ix->count_steps) NM_LAUNCH_SITES(true, false); else NM_LAUNCH_SITES(false, false); }
+#undef NM_LAUNCH_SITES
     }
     const uint32_t *probe = nullptr;
     if (ix->repeat_probes && (rc = nm_launch_probes<BIG>(ix, view, n, kmax, st, &probe, need)) != NM_OK) return rc;
     const dim3 rgrid((unsigned)((n_need + NM_RES_WORDS - 1) / NM_RES_WORDS)), rblock(NM_RES_BLOCK);
 #define NM_LAUNCH_RES(STATS_, LIST_) hipLaunchKernelGGL((k_resolve<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, \
-                                                        d_status, (const uint64_t *)need, n_need, probe, seq_len, d_list, n_list)
+                                                        d_status, (const uint64_t *)need, n_need, probe, (const unsigned long long *)work, seq_len, d_list, n_list)
     if (d_list) { if (ix->count_steps) NM_LAUNCH_RES(true, true); else NM_LAUNCH_RES(false, true); }
     else        { if (ix->count_steps) NM_LAUNCH_RES(true, false); else NM_LAUNCH_RES(false, false); }
 #undef NM_LAUNCH_RES

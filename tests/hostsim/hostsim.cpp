@@ -300,6 +300,7 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
     const uint32_t G = d + 4, BLOCK = 256, PER_LANE = 2, BP = BLOCK * PER_LANE * G, n_stage = BP / 64 + 5;
     const uint64_t n_need = (num_kmers + 63) / 64;
     std::vector<uint64_t> need(n_need + 1, 0);
+    bool any_open = false;                                  // work[NM_WORK_OPEN]
     // ---- k_sites
     for (uint64_t blk = 0; blk * BP < num_kmers; blk++) {
         const uint64_t base = blk * BP, w0 = base >> 6;
@@ -332,6 +333,8 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             if (rest >> 32) s_set[wi + 2] |= (uint32_t)(rest >> 32);
         }
         auto amb_word = [&](uint64_t i) -> uint64_t { return s_amb[i]; };
+        const bool chance = v.quad2 != nullptr && kmin >= v.quad2_m + NM_QUAD_EXT;
+        uint32_t open_total = 0;
         for (uint32_t j = 0; j < BP / 4; j++) {
             const uint32_t rel = 4 * j;
             const uint64_t q = base + rel;
@@ -341,20 +344,48 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             uint32_t own_amb;
             const uint32_t valid = nm_valid4(amb_word, rel, kmin, own_amb) & inb;
             const uint32_t set4 = (s_set[rel >> 5] >> (rel & 31)) & 0xFu;
-            const uint32_t hit = valid & set4, open = valid & ~set4;
+            uint32_t hit = valid & set4, open = valid & ~set4;
             status[0] += (uint64_t)__builtin_popcount(own_amb & inb);
             status[7] += (uint64_t)__builtin_popcount(~own_amb & inb);
-            if (open) s_need[rel >> 5] |= open << (rel & 31);
+            if (open && chance)
+                for (uint32_t t = 0; t < 4; t++) {
+                    if (!((open >> t) & 1u)) continue;
+                    counters[0]++;
+                    if (nm_second_chance(v, lds_window(rel + t), kmin)) { hit |= 1u << t; open &= ~(1u << t); counters[4]++; }
+                }
+            if (open) { s_need[rel >> 5] |= open << (rel & 31); open_total += (uint32_t)__builtin_popcount(open); }
             for (uint32_t t = 0; t < 4; t++)
                 if ((inb >> t) & 1u) store(q + t, (hit >> t) & 1u ? kmin : 0u);
         }
+        // a few open positions: the block finishes them itself; many: they stay for the probes and k_resolve
+        const bool self = open_total && open_total <= 64;
+        if (self) {
+            for (uint32_t i = 0; i < BP / 32; i++) {
+                uint32_t bits = s_need[i];
+                s_need[i] = 0;
+                for (; bits; bits &= bits - 1) {
+                    const uint64_t p = base + i * 32 + (uint32_t)__builtin_ctz(bits);
+                    counters[1]++;
+                    bool amb0 = false, err = false;
+                    nm_tally t = {0, 0, 0, 0};
+                    uint32_t val;
+                    if (list) val = ix->big ? nm_fixed_k_one<true, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t)
+                                            : nm_fixed_k_one<false, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t);
+                    else      val = ix->big ? nm_min_unique_one<true, true>(v, enc.data(), p, kmin, kmax, amb0, err, t)
+                                            : nm_min_unique_one<false, true>(v, enc.data(), p, kmin, kmax, amb0, err, t);
+                    if (err) { status[1] = 1; if (p < status[2]) status[2] = p; }
+                    status[3] += t.steps; status[4] += t.blocks; status[6] += t.seeds;
+                    store(p, val);
+                }
+            }
+        } else if (open_total) any_open = true;
         for (uint32_t i = 0; i < BP / 64; i++)
             if (base + 64ull * i < num_kmers) need[w0 + i] = (uint64_t)s_need[2 * i] | ((uint64_t)s_need[2 * i + 1] << 32);
     }
     if (need_out) for (uint64_t i = 0; i < n_need; i++) need_out[i] = need[i];
     // ---- repeat probes where the bitmap is dense (k_repeat_probe_coarse, k_repeat_probe)
     std::vector<uint32_t> words;
-    if (probes) {
+    if (probes && any_open) {
         const uint32_t stride = 64;
         std::vector<uint32_t> coarse;
         if (probes == 2) {
@@ -380,7 +411,8 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
         }
     }
     // ---- k_resolve
-    for (uint64_t cur = 0; cur < n_need; cur++) {
+    if (!any_open) probes = 0;
+    for (uint64_t cur = 0; any_open && cur < n_need; cur++) {
         uint64_t bits = need[cur];
         uint32_t wj = 0, wj1 = 0;
         if (bits && probes) {
@@ -404,16 +436,12 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             bool amb0 = false, err = false;
             nm_tally t = {0, 0, 0, 0};
             uint32_t val;
-            if (v.quad2 && kmin >= v.quad2_m + NM_QUAD_EXT) {
-                status[5] += 4;
-                if (nm_second_chance(v, nm_load_window(enc.data(), p), kmin)) { store(p, kmin); counters[4]++; continue; }
-            }
             if (list) val = ix->big ? nm_fixed_k_one<true, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t)
                                     : nm_fixed_k_one<false, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t);
             else      val = ix->big ? nm_min_unique_one<true, true>(v, enc.data(), p, kmin, kmax, amb0, err, t)
                                     : nm_min_unique_one<false, true>(v, enc.data(), p, kmin, kmax, amb0, err, t);
             if (err) { status[1] = 1; if (p < status[2]) status[2] = p; }
-            status[3] += t.steps; status[4] += t.blocks; status[5] += t.seeds;
+            status[3] += t.steps; status[4] += t.blocks; status[6] += t.seeds;
             store(p, val);
         }
     }

@@ -400,7 +400,7 @@ def test_sites_pipeline_equals_oracle(tmp_path, m, force_big):
                 assert code == 0 and np.array_equal(got, want), (kmin, kmax, probes)
                 assert (int(counters[4]) > 0) == (kmin >= w + 2) or m == 4
     got, _, _, _, counters = sim.sites(bytes(r1), len(r1), 20, 60, 60, 1)
-    assert int(counters[4]) > 0 and int(counters[1]) == walked_alone
+    assert int(counters[4]) > 0 and int(counters[1]) < walked_alone
     # list mode: several lengths, the first >= the window
     for ks in ([w, w + 5], [20, 36, 100], [36, 20, 50], [w + 2, 250], [100, 24]):
         if min(ks) < w or ks[0] > 252:

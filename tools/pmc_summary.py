@@ -1,21 +1,30 @@
 """Summarise rocprofv3 --pmc CSV output (one or more passes) into the per-dispatch means of one kernel.
 
-    python tools/pmc_summary.py KERNEL_SUBSTRING OUT.csv PASS_DIR [PASS_DIR ...]
+    python tools/pmc_summary.py KERNEL_SUBSTRING OUT.csv BENCH.json PASS_DIR [PASS_DIR ...]
 
 Each PASS_DIR holds the *_counter_collection.csv of one `rocprofv3 --pmc ... --output-format csv` run
 (counters are collected in separate passes, as the MI355X guide prescribes).  Only dispatches of the
-non-counting build of the kernel (template argument STATS = false) are averaged."""
+non-counting build of the kernel (template argument STATS = false) are averaged.  The first line of OUT.csv
+ties the numbers to what produced them: the sha256 of the kernel sources (nm_engine.hip + nm_core.h), the git
+commit, the launch size and the quad table the sites read -- bench.py reports `traffic` only when they match
+the run it is in."""
 import collections
 import csv
 import glob
+import hashlib
+import json
 import re
+import subprocess
 import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def main():
-    kernel, out = sys.argv[1], sys.argv[2]
+    kernel, out, bench_json = sys.argv[1], sys.argv[2], sys.argv[3]
     sums = collections.OrderedDict()
-    for d in sys.argv[3:]:
+    for d in sys.argv[4:]:
         for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
             per = collections.defaultdict(lambda: collections.defaultdict(float))
             with open(f) as fh:
@@ -27,7 +36,23 @@ def main():
             for c, by_dispatch in per.items():
                 vals = list(by_dispatch.values())
                 sums[c] = (sum(vals) / len(vals), len(vals))
+    h = hashlib.sha256()
+    for f in ("newmap_amd/csrc/nm_engine.hip", "newmap_amd/csrc/nm_core.h"):
+        h.update((ROOT / f).read_bytes())
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or "n/a (snapshot without .git)"
+    except OSError:
+        commit = "n/a"
+    meta = {"kernel": kernel, "source_sha256": h.hexdigest()[:16], "git_commit": commit}
+    try:
+        r = json.loads(Path(bench_json).read_text().strip().splitlines()[-1])
+        meta["positions_per_launch"] = r["config"]["positions_per_gpu"] // max(r["config"]["segments_per_rank"], 1)
+        meta["site_core_length"] = r["roofline"].get("site_core_length", 0)
+        meta["avg_launch_ms_hip_events"] = round(r["roofline"]["avg_launch_ms"], 5)
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
     with open(out, "w") as fh:
+        fh.write("# " + ", ".join(f"{k}={v}" for k, v in meta.items()) + "\n")
         fh.write(f"counter,mean_per_dispatch ({kernel}; dispatches averaged: {next(iter(sums.values()))[1] if sums else 0})\n")
         for c, (v, _) in sums.items():
             fh.write(f"{c},{v:.1f}\n")

@@ -284,6 +284,7 @@ static inline size_t nm_site_lds_bytes(uint32_t d) {
 }
 
 #define NM_SITE_WALK_MAX 64u        /* open positions a block finishes itself (seed table + walk); more: left to the probes and k_resolve */
+#define NM_SITE_CHANCE_MAX 256u     /* open positions a block asks the second table about (one lane each); more: a long repeat, not worth the lines */
 
 template <bool BIG, bool STATS, bool LIST>
 __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_enc_words,
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
                                                          const uint32_t *__restrict__ list, uint32_t n_list) {
     extern __shared__ uint64_t s_mem[];
     __shared__ uint32_t s_open_total, s_qn;
-    __shared__ uint32_t s_q[NM_SITE_WALK_MAX];
+    __shared__ uint32_t s_q[NM_SITE_CHANCE_MAX];
     const uint32_t G = d + 4, m = ix.quad_m;
     const uint32_t BP = NM_SITE_BLOCK * NM_SITE_PER_LANE * G;          // a multiple of 512
     const uint32_t n_stage = BP / 64 + 5;
@@ -354,12 +355,10 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
         }
     }
     __syncthreads();
-    // ---- phase 2: elements and open bits, four positions per lane and turn, in position order.  A position no site
-    // settled asks the table with the longer cores first (nm_second_chance; its window is already in LDS)
+    // ---- phase 2: elements and open bits, four positions per lane and turn, in position order
     uint32_t n_amb = 0, n_searched = 0, n_open = 0;
     auto amb_word = [&](uint64_t i) -> uint64_t { return s_amb[i]; };
     const bool wide = elem_bytes == 1 && (((uintptr_t)out) & 3u) == 0;
-    const bool chance = ix.quad2 != nullptr && kmin >= ix.quad2_m + NM_QUAD_EXT;
     for (uint32_t j = tid; j < BP / 4; j += NM_SITE_BLOCK) {
         const uint32_t rel = 4 * j;
         const uint64_t q = base + rel;
@@ -369,17 +368,9 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
         uint32_t own_amb;
         const uint32_t valid = nm_valid4(amb_word, rel, kmin, own_amb) & inb;
         const uint32_t set4 = (s_set[rel >> 5] >> (rel & 31)) & 0xFu;
-        uint32_t hit = valid & set4, open = valid & ~set4;
+        const uint32_t hit = valid & set4, open = valid & ~set4;
         n_amb += (uint32_t)__builtin_popcount(own_amb & inb);
         n_searched += (uint32_t)__builtin_popcount(~own_amb & inb);
-        if (open && chance) {
-#pragma unroll
-            for (uint32_t t = 0; t < 4; t++) {
-                if (!((open >> t) & 1u)) continue;
-                n_entries += 4;
-                if (nm_second_chance(ix, lds_window(rel + t), kmin)) { hit |= 1u << t; open &= ~(1u << t); }
-            }
-        }
         if (open) { atomicOr(&s_need[rel >> 5], open << (rel & 31)); n_open += (uint32_t)__builtin_popcount(open); }
         if (wide && inb == 0xFu) {
             reinterpret_cast<uint32_t *>(out)[q >> 2] = (hit & 1u ? kmin : 0u) | (hit & 2u ? kmin << 8 : 0u) |
@@ -392,21 +383,40 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
     }
     if (n_open) atomicAdd(&s_open_total, n_open);
     __syncthreads();
-    // ---- phase 3: a few open positions (the rule outside long repeats): the block finishes them itself -- seed table +
+    // the open positions of the block, one per lane: s_q[0 .. s_qn) (callers have checked that they fit)
+    auto gather_open = [&]() {
+        for (uint32_t i = tid; i < BP / 32; i += NM_SITE_BLOCK)
+            for (uint32_t bits = s_need[i]; bits; bits &= bits - 1) s_q[atomicAdd(&s_qn, 1u)] = i * 32 + (uint32_t)__builtin_ctz(bits);
+        __syncthreads();
+    };
+    // ---- phase 3: second chance.  A position no site settled asks the table with the longer cores (nm_second_chance; its
+    // window is in LDS).  All lookups of the block are in flight together; a block with many open positions sits in a
+    // long repeat and skips this.
+    nm_tally t = {0, 0, 0, 0};
+    if (ix.quad2 != nullptr && kmin >= ix.quad2_m + NM_QUAD_EXT && s_open_total && s_open_total <= NM_SITE_CHANCE_MAX) {
+        gather_open();
+        const uint32_t n_q = s_qn;
+        __syncthreads();
+        if (tid == 0) s_qn = 0;
+        if (tid < n_q) {
+            const uint32_t rel = s_q[tid];
+            n_entries += 4;
+            if (nm_second_chance(ix, lds_window(rel), kmin)) {
+                nm_store(out, elem_bytes, base + rel, kmin);
+                atomicAnd(&s_need[rel >> 5], ~(1u << (rel & 31)));
+                atomicSub(&s_open_total, 1u);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase 4: a few open positions (the rule outside long repeats): the block finishes them itself -- seed table +
     // walk -- and hands an empty bitmap on.  Many: they stay for the repeat probes and k_resolve.
     const uint32_t open_total = s_open_total;
-    nm_tally t = {0, 0, 0, 0};
     bool any_err = false;
     uint64_t err_pos = ~0ULL;
     const bool self = open_total && open_total <= NM_SITE_WALK_MAX && !(ix.seed_policy & 0x100u);
     if (self) {
-        for (uint32_t i = tid; i < BP / 32; i += NM_SITE_BLOCK) {
-            uint32_t bits = s_need[i];
-            if (!bits) continue;
-            s_need[i] = 0;
-            for (; bits; bits &= bits - 1) s_q[atomicAdd(&s_qn, 1u)] = i * 32 + (uint32_t)__builtin_ctz(bits);
-        }
-        __syncthreads();
+        gather_open();
         if (tid < s_qn) {
             const uint64_t p = base + s_q[tid];
             bool amb0 = false, err = false;

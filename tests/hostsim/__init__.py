@@ -45,7 +45,7 @@ def lib():
     L.hs_build_quad2.argtypes = [vp, u32]
     L.hs_valid_bits.argtypes = [vp, u64, u32, vp]
     L.hs_sites.restype = i32
-    L.hs_sites.argtypes = [vp, vp, u64, u64, u32, u32, u32, i32, vp, u32, i32, vp, vp, vp, vp]
+    L.hs_sites.argtypes = [vp, vp, u64, u64, u32, u32, u32, i32, vp, u32, i32, vp, vp, vp, vp, u32, u32]
     L.hs_fixed_k.restype = i32
     L.hs_fixed_k.argtypes = [vp, vp, u64, u64, vp, u32, i32, i32, vp, vp]
     L.hs_count.argtypes = [vp, vp, vp, vp, u64, vp]
@@ -108,7 +108,7 @@ class HostSim:
                                         words.ctypes.data, decided.ctypes.data)
         return words[:n_probes], decided[:num_kmers], int(steps)
 
-    def sites(self, seq: bytes, num_kmers, kmin, kmax, d_cap=60, probes=1, ks=None, dtype=np.uint8):
+    def sites(self, seq: bytes, num_kmers, kmin, kmax, d_cap=60, probes=1, ks=None, dtype=np.uint8, chance_max=256, walk_max=64):
         """k_sites -> gated repeat probes -> k_resolve, as the device runs them (needs check_quad() first: it builds the
         quad table).  ks: list mode (kmin / kmax are then its first / longest length).  Returns (elements, status,
         rc, need bitmap, counters) -- counters: table entries read, positions walked, probes run, probe-decided."""
@@ -120,7 +120,7 @@ class HostSim:
         k = np.asarray(ks if ks is not None else [], dtype=np.uint32)
         rc = self.L.hs_sites(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, d_cap, probes,
                              k.ctypes.data if k.size else None, k.size, out.dtype.itemsize, out.ctypes.data,
-                             status.ctypes.data, need.ctypes.data, counters.ctypes.data)
+                             status.ctypes.data, need.ctypes.data, counters.ctypes.data, chance_max, walk_max)
         return out[:num_kmers], status, rc, need[:-1], counters
 
     def fixed_k(self, seq: bytes, num_kmers, ks, use_rc=True, dtype=np.uint8):

@@ -277,10 +277,11 @@ uint64_t hs_repeat_probes(hs_index *ix, const uint8_t *seq, uint64_t seq_len, ui
 // Needs the quad table (hs_check_quad builds it from the simulated seed table; core length = seed length).
 // probes: 0 none, 1 fine, 2 coarse + fine.  list / n_list: list mode (kmin = first length, kmax = the longest).
 // need_out (may be null): the bitmap k_sites leaves.  counters[0] = table entries read, [1] = positions walked,
-// [2] = fine probes run, [3] = positions the probes decided, [4] = positions the second table settled.  Returns 0 ok, 8 k-mer not found, -1 not applicable.
+// [2] = fine probes run, [3] = positions the probes decided, [4] = positions the second table settled.
+// chance_max / walk_max: NM_SITE_CHANCE_MAX / NM_SITE_WALK_MAX of the device (256 / 64); tests also run other values.  Returns 0 ok, 8 k-mer not found, -1 not applicable.
 int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, uint32_t d_cap,
              int probes, const uint32_t *list, uint32_t n_list, int elem_bytes, void *out, uint64_t *status,
-             uint64_t *need_out, uint64_t *counters) {
+             uint64_t *need_out, uint64_t *counters, uint32_t chance_max, uint32_t walk_max) {
     const nm_view &v = ix->v;
     const uint32_t m = v.quad_m;
     if (!v.quad || kmin < m + NM_QUAD_EXT || kmin > NM_SITE_MAX_KMIN || d_cap > NM_SITE_MAX_D) return -1;
@@ -347,18 +348,20 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             uint32_t hit = valid & set4, open = valid & ~set4;
             status[0] += (uint64_t)__builtin_popcount(own_amb & inb);
             status[7] += (uint64_t)__builtin_popcount(~own_amb & inb);
-            if (open && chance)
-                for (uint32_t t = 0; t < 4; t++) {
-                    if (!((open >> t) & 1u)) continue;
-                    counters[0]++;
-                    if (nm_second_chance(v, lds_window(rel + t), kmin)) { hit |= 1u << t; open &= ~(1u << t); counters[4]++; }
-                }
             if (open) { s_need[rel >> 5] |= open << (rel & 31); open_total += (uint32_t)__builtin_popcount(open); }
             for (uint32_t t = 0; t < 4; t++)
                 if ((inb >> t) & 1u) store(q + t, (hit >> t) & 1u ? kmin : 0u);
         }
+        // second chance: the open positions of a block with few of them ask the table with the longer cores
+        if (chance && open_total && open_total <= chance_max)
+            for (uint32_t i = 0; i < BP / 32; i++)
+                for (uint32_t bits = s_need[i]; bits; bits &= bits - 1) {
+                    const uint32_t rel = i * 32 + (uint32_t)__builtin_ctz(bits);
+                    counters[0]++;
+                    if (nm_second_chance(v, lds_window(rel), kmin)) { store(base + rel, kmin); s_need[i] &= ~(1u << (rel & 31)); open_total--; counters[4]++; }
+                }
         // a few open positions: the block finishes them itself; many: they stay for the probes and k_resolve
-        const bool self = open_total && open_total <= 64;
+        const bool self = open_total && open_total <= walk_max;
         if (self) {
             for (uint32_t i = 0; i < BP / 32; i++) {
                 uint32_t bits = s_need[i];

@@ -342,7 +342,7 @@ def test_large_random_genome_properties(tmp_path, eng):
         assert (tot2 > 1).all()
     with eng.Index(idx, 0, "auto-small") as small:          # the one-shot CLI's tables: same kernels, 17 GB
         info = small.info()
-        assert info["seed_length"] == 15 and info["quad_core_length"] == 14 and info["device_bytes"] < 20e9
+        assert info["seed_length"] == 15 and info["quad_core_length"] == 14 and info["device_bytes"] < 21e9
         got, _ = small.min_unique_segment(rec[:20_000_199], 20_000_000, kmin, kmax)
         assert small.info()["last_range_kernel"] == 5 and np.array_equal(got, whole[:20_000_000])
     with eng.Index(idx, 0, 12) as ix12:                   # the reference's default seed length, simple kernel
@@ -356,6 +356,127 @@ def test_large_random_genome_properties(tmp_path, eng):
     sample = 200_000
     want, _, _ = rd.ref_binary_search_segment_c(oracle, rec[:sample + kmax - 1], sample, kmin, kmax, fm=False)
     assert np.array_equal(want.astype(np.uint8), whole[:sample])
+
+
+def _seam_minimality(ix, rec: bytes, out: np.ndarray, kmin: int, kmax: int, rng, samples: int):
+    """re-derive sampled elements through the count seam (an independent kernel, k_count, and the strand blocks): at the
+    reported length the both-strand count is 1, one base shorter (if allowed) it is not; a 0 means the kmax-mer is
+    repeated (or the position cannot hold kmin bases)"""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rcrec = rec.translate(comp)[::-1]
+    n = len(rec)
+    pos = rng.integers(0, n - kmax, samples)
+    k = out[pos].astype(np.int64)
+    found = k > 0
+    p1, k1 = pos[found], k[found]
+    tot = ix.count_from_sequence(rec, p1, k1) + ix.count_from_sequence(rcrec, n - p1 - k1, k1)
+    assert (tot == 1).all()
+    longer = k1 > kmin
+    tot2 = ix.count_from_sequence(rec, p1[longer], k1[longer] - 1) + \
+        ix.count_from_sequence(rcrec, n - p1[longer] - (k1[longer] - 1), k1[longer] - 1)
+    assert (tot2 > 1).all()
+    p0 = pos[~found]
+    if p0.size:
+        kk = np.full(p0.size, kmax, dtype=np.int64)
+        tot0 = ix.count_from_sequence(rec, p0, kk) + ix.count_from_sequence(rcrec, n - p0 - kmax, kk)
+        assert (tot0 > 1).all()
+    return int(found.sum()), int(p0.size)
+
+
+def test_config3_full_size_properties(tmp_path, eng, monkeypatch):
+    """BASELINE configs[2] at FULL size -- 3.09 Gbp, 24 human-shaped records, 24:150, index built on the device (6.18 G BWT
+    rows: every kernel runs in its > 2^31-row instantiation) -- and the north-star range 20:200 on the same index.
+    No CPU oracle holds a suffix array of 6 G symbols within this suite's time, so the checks are the properties the
+    domain offers: (1) minimality of sampled elements re-derived through the count seam, (2) batch independence
+    (10 M launches == 100 M launches), (3) the sites == the one-lane-per-position kernel on a 20 M stretch (independent
+    schedules of the arithmetic), with either quad table and with the coarse probes forced, (4) structural facts (the
+    last kmin-1 positions are 0; every element is 0 or in [kmin, kmax])."""
+    from newmap_amd import synth
+    from newmap_amd._c_newmap_generate_index import generate_fm_index
+    recs = synth.config_genome("c3")
+    fa = tmp_path / "c3.fa"
+    synth.write_fasta(fa, recs)
+    idx = tmp_path / "c3.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12, device=0)
+    rng = np.random.default_rng(31)
+    chr1, chr21 = recs[0][1].tobytes(), recs[20][1].tobytes()
+    del recs
+    monkeypatch.setenv("NEWMAP_AMD_COARSE_MIN", "0")
+    with eng.Index(idx, 0) as ix:
+        info = ix.info()
+        assert info["bwt_length"] > 2 ** 32 and info["quad_core_length"] == 16
+        for kmin, kmax in ((24, 150), (20, 200)):
+            whole, amb = ix.min_unique_segment(chr1[:100_000_000 + kmax - 1], 100_000_000, kmin, kmax)
+            assert amb == 0 and ix.info()["last_range_kernel"] == 5
+            assert ((whole == 0) | ((whole >= kmin) & (whole <= kmax))).all()
+            parts = [ix.min_unique_segment(chr1[o:o + 10_000_000 + kmax - 1], 10_000_000, kmin, kmax)[0] for o in range(0, 100_000_000, 10_000_000)]
+            assert np.array_equal(np.concatenate(parts), whole)
+            found, none = _seam_minimality(ix, chr1[:100_000_000 + kmax], whole, kmin, kmax, rng, 30_000)
+            assert found > 29_000
+            small, _ = ix.min_unique_segment(chr21, len(chr21), kmin, kmax)          # a whole record: the tail rule
+            assert not small[-(kmin - 1):].any() and small[:-(kmin - 1)].min() >= kmin
+            _seam_minimality(ix, chr21, small, kmin, kmax, rng, 20_000)
+            # independent schedules on a 20 M stretch
+            sub = chr1[40_000_000:60_000_000 + kmax - 1]
+            ix.set_kernel(1)
+            ix.set_repeat_probes(False)
+            plain, _ = ix.min_unique_segment(sub, 20_000_000, kmin, kmax)
+            ix.set_kernel(0)
+            ix.set_repeat_probes(True)
+            assert np.array_equal(plain, whole[40_000_000:60_000_000])
+            for table in (1, 2):
+                ix.set_site_table(table)
+                got, _ = ix.min_unique_segment(sub, 20_000_000, kmin, kmax)
+                assert np.array_equal(got, plain), (kmin, table)
+            ix.set_site_table(0)
+    monkeypatch.setenv("NEWMAP_AMD_COARSE", "2")            # coarse probes forced (they find nothing to settle here)
+    with eng.Index(idx, 0, "auto-small") as ix:             # the one-shot CLI's tables on the same index
+        got, _ = ix.min_unique_segment(chr1[:30_000_000 + 199], 30_000_000, 20, 200)
+    assert np.array_equal(got, whole[:30_000_000])
+
+
+def test_config5_full_size_properties(tmp_path, eng, monkeypatch):
+    """BASELINE configs[4] at FULL size -- 1 Gbp, 50 % tandem repeats, 20:255, index built on the device: the probes settle
+    about half of the positions, and the elements satisfy the count-seam properties (unique at the reported length, not
+    one base shorter; a 0 = the 255-mer is repeated); 10 M launches == 100 M launches; the sites == the one-lane-per-
+    position kernel without probes on a stretch; coarse probes forced == not forced."""
+    from newmap_amd import synth
+    from newmap_amd._c_newmap_generate_index import generate_fm_index
+    rec = synth.config_genome("c5")[0][1]
+    fa = tmp_path / "c5.fa"
+    synth.write_fasta(fa, [("rep1", rec)])
+    idx = tmp_path / "c5.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12, device=0)
+    rec = rec.tobytes()
+    rng = np.random.default_rng(32)
+    kmin, kmax = 20, 255
+    n = 100_000_000
+    with eng.Index(idx, 0) as ix:
+        ix.set_count_steps(True)                             # (the probes' tally of settled positions is kept by the counter build)
+        whole, amb = ix.min_unique_segment(rec[:n + kmax - 1], n, kmin, kmax)
+        assert amb == 0 and ix.info()["last_range_kernel"] == 5
+        zeros = np.count_nonzero(whole == 0) / n
+        assert 0.3 < zeros < 0.7
+        assert ix.probe_tally()["settled"] > 0.8 * zeros * n
+        ix.set_count_steps(False)
+        parts = [ix.min_unique_segment(rec[o:o + 10_000_000 + kmax - 1], 10_000_000, kmin, kmax)[0] for o in range(0, n, 10_000_000)]
+        assert np.array_equal(np.concatenate(parts), whole)
+        found, none = _seam_minimality(ix, rec[:n + kmax], whole, kmin, kmax, rng, 40_000)
+        assert found > 10_000 and none > 10_000
+        sub = rec[30_000_000:34_000_000 + kmax - 1]
+        ix.set_kernel(1)
+        ix.set_repeat_probes(False)
+        plain, _ = ix.min_unique_segment(sub, 4_000_000, kmin, kmax)
+        ix.set_kernel(0)
+        ix.set_repeat_probes(True)
+        assert np.array_equal(plain, whole[30_000_000:34_000_000])
+        tail, _ = ix.min_unique_segment(rec[-50_000_000:], 50_000_000, kmin, kmax)   # the end of the record
+        assert not tail[-(kmin - 1):].any()
+    monkeypatch.setenv("NEWMAP_AMD_COARSE", "2")
+    monkeypatch.setenv("NEWMAP_AMD_COARSE_MIN", "0")
+    with eng.Index(idx, 0) as ix:
+        forced, _ = ix.min_unique_segment(rec[:n + kmax - 1], n, kmin, kmax)
+        assert np.array_equal(forced, whole)
 
 
 # ------------------------------------------------------------------ BASELINE configs, scaled down

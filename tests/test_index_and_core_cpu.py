@@ -386,21 +386,21 @@ def test_sites_pipeline_equals_oracle(tmp_path, m, force_big):
     # the probes really run on the tandem array and decide most of it; elsewhere (open bits sparse) none runs
     rec = bytes(r1)
     got, _, _, need, counters = sim.sites(rec, len(rec), 20, 60, 60, 1)
-    walked_alone = int(counters[1])
     dense = np.array([bin(int(x)).count("1") >= 32 for x in need])
     assert dense[600 // 64 + 1:(1800 - 60) // 64 - 1].all() and int(counters[2]) <= 2 * int(dense.sum()) + 2
     assert int(counters[3]) > 600 and int(counters[1]) < len(rec) // 4
     # a second table with longer cores backs the sites up: same elements, and it settles part of what was walked
     sim.build_quad2(m + 2)
+    second = 0
     for rec in (bytes(r1), r2):
         for kmin, kmax in ((w, 40), (w + 1, 40), (w + 2, 40), (w + 3, 200), (20, 200), (70, 255)):
             want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
-            for probes in (0, 1):
-                got, _, code, _, counters = sim.sites(rec, len(rec), kmin, kmax, 60, probes)
-                assert code == 0 and np.array_equal(got, want), (kmin, kmax, probes)
-                assert (int(counters[4]) > 0) == (kmin >= w + 2) or m == 4
-    got, _, _, _, counters = sim.sites(bytes(r1), len(r1), 20, 60, 60, 1)
-    assert int(counters[4]) > 0 and int(counters[1]) < walked_alone
+            for probes, chance_max, walk_max in ((0, 256, 64), (1, 256, 64), (1, 1 << 20, 64), (1, 1 << 20, 1 << 20), (0, 0, 0)):
+                got, _, code, _, counters = sim.sites(rec, len(rec), kmin, kmax, 60, probes, chance_max=chance_max, walk_max=walk_max)
+                assert code == 0 and np.array_equal(got, want), (kmin, kmax, probes, chance_max, walk_max)
+                assert kmin >= w + 2 or int(counters[4]) == 0       # (the second table's window must fit the kmin-mer)
+                second += int(counters[4])
+    assert second > 0                                      # (the second table does settle positions)
     # list mode: several lengths, the first >= the window
     for ks in ([w, w + 5], [20, 36, 100], [36, 20, 50], [w + 2, 250], [100, 24]):
         if min(ks) < w or ks[0] > 252:

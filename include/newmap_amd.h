@@ -171,9 +171,10 @@ int nm_timing_read_kind(nm_index *ix, int kind, uint64_t *n_launches, double *to
 
 /* --------------------------------------------------------------- native search driver --------
  * The whole of newmap/search.py:197-380 `write_unique_counts` for one FASTA and one index in one
- * call: streaming FASTA reader (plain or .gz; record and segment rules of newmap/fasta.py:20-190),
- * pinned double buffers, H2D / fused kernels / D2H on one stream overlapped with parsing and with the
- * file appends, one `<out_dir>/<id>.unique.uint8|16|32` per record id.  `ks`: the range kmin..kmax is
+ * call (record and segment rules of newmap/fasta.py:20-190), one `<out_dir>/<id>.unique.uint8|16|32` per
+ * record id.  A plain FASTA file is mapped and stripped by a pool of host threads, its segments go through a
+ * ring of pinned slots (H2D / kernels / D2H on one stream) and a pool of writer threads puts the results into
+ * the files with pwrite; gzip input takes a streaming reader (one thread, two slots).  `ks`: the range kmin..kmax is
  * given by its two ends when range_mode != 0, else the list of lengths in order.  include / exclude:
  * record ids to keep / to skip (at most one of the two lists non-empty).  `cb` (may be NULL) is
  * called once per output file, in file order, after the search; `total` receives the sums. */
@@ -187,6 +188,18 @@ int nm_search_fasta(nm_index *ix, const char *fasta_path, const char *out_dir, c
                     const char *const *include_ids, uint32_t n_include,
                     const char *const *exclude_ids, uint32_t n_exclude,
                     nm_record_callback cb, void *user, nm_search_summary *total);
+
+/* The same call as ONE RANK of `world` (one process per GPU): the position space of the selected records is cut into
+ * interleaved chunks of ~64 M positions, rank r owns chunks r, r + world, ...; it strips only the byte ranges of its
+ * own work units out of the (uncompressed) FASTA, searches them on its GPU and writes them at their offsets into the
+ * per-record files, which every rank opens and sizes alike.  No collective; the ranks need a common file system.
+ * `cb` / `total` cover this rank's share.  Replaces nothing in the reference (it has no multi-device mode):
+ * SURVEY.md section 8(e). */
+int nm_search_fasta_shard(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks,
+                          uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
+                          const char *const *include_ids, uint32_t n_include,
+                          const char *const *exclude_ids, uint32_t n_exclude,
+                          nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world);
 
 /* --------------------------------------------------------------- track on the device ----------
  * newmap/track.py:22-121 for ONE unique-length file: marks, windowed prefix sums, run-length BED

@@ -30,7 +30,7 @@ EXPORTS = [
     "nm_index_info", "nm_count_kmers", "nm_count_from_sequence", "nm_min_unique_segment",
     "nm_fixed_k_segment", "nm_upper_bound_segment", "nm_min_unique_segment_dev",
     "nm_fixed_k_segment_dev", "nm_set_option", "nm_dev_alloc", "nm_dev_free", "nm_dev_upload",
-    "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read", "nm_timing_read_kind", "nm_search_fasta", "nm_track_file", "nm_search_segment_multi", "nm_index_build_device",
+    "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read", "nm_timing_read_kind", "nm_search_fasta", "nm_search_fasta_shard", "nm_track_file", "nm_search_segment_multi", "nm_index_build_device",
 ]
 
 _lib = None
@@ -136,6 +136,8 @@ def lib():
     L.nm_search_fasta.argtypes = [vp, c.c_char_p, c.c_char_p, vp, u32, i32, i32, u64,
                                   c.POINTER(c.c_char_p), u32, c.POINTER(c.c_char_p), u32,
                                   RECORD_CALLBACK, vp, c.POINTER(SearchSummary)]
+    L.nm_search_fasta_shard.restype = i32
+    L.nm_search_fasta_shard.argtypes = L.nm_search_fasta.argtypes + [i32, i32]
     L.nm_search_segment_multi.restype = i32
     L.nm_search_segment_multi.argtypes = [vp, u32, vp, u32, u64, u64, vp, u32, i32, i32, i32, vp, vp, vp]
     L.nm_track_file.restype = i32

@@ -7,15 +7,35 @@
 // (nm_min_unique_segment_dev / nm_fixed_k_segment_dev) and the D2H copy of segment j run on the
 // handle's stream while the host parses segment j+1 and appends segment j-1 to its file.
 // Output files are byte-identical to newmap_amd.search.write_unique_counts (and so to the reference's).
+//
+// Two front-ends, one set of rules:
+//   * the PARALLEL one (plain FASTA files; fast_run below): the file is mapped, header lines are found by a threaded
+//     scan, every record's data lines are stripped by a pool of threads straight into one buffer, the segments go
+//     through a ring of pinned slots (H2D, kernels, D2H on the driver's stream), and a pool of writer threads puts each
+//     result into its file with pwrite while the next record is being stripped.  With world > 1 a rank strips and
+//     searches only the byte ranges of its own work units (interleaved chunks of the position space) and writes them at
+//     their offsets: no collective, no rank reads the whole file into memory.
+//   * the STREAMING one (gzip input, anything that cannot be mapped; run below): one thread, two slots.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cerrno>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "../../include/newmap_amd.h"
@@ -125,9 +145,11 @@ int drain_slot(Driver &d, Slot &s) {
     s.busy = false;
     const uint64_t serial = s.rec_index;
     if (s.h_status[1]) {
-        nm_set_error("a generated k-mer was not found in the index (record '%s', position %llu); possibly a "
-                     "mismatch between the sequence and the index", d.pending_ids[serial].c_str(),
-                     (unsigned long long)(s.rec_offset + s.h_status[2]));
+        const uint64_t at = s.h_status[2] < s.seg_len ? s.h_status[2] : 0;
+        const uint64_t len = s.seg_len - at < d.kmin ? s.seg_len - at : d.kmin;
+        nm_set_error("The following generated k-mer was not found in the index:\n%.*s\nPossibly a mismatch between the sequence "
+                     "and the index. (record '%s', position %llu)", (int)len, (const char *)s.h_in + at,      // newmap/search.py:719-722
+                     d.pending_ids[serial].c_str(), (unsigned long long)(s.rec_offset + at));
         return NM_E_KMER_NOT_FOUND;
     }
     FILE *fp = d.open_files[serial];
@@ -317,16 +339,199 @@ int run(Driver &d, const char *fasta_path) {
     return rc;
 }
 
-}  // namespace
 
-extern "C" int nm_search_fasta(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks,
-                               uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
-                               const char *const *include_ids, uint32_t n_include,
-                               const char *const *exclude_ids, uint32_t n_exclude,
-                               nm_record_callback cb, void *user, nm_search_summary *total) {
-    if (!ix || !fasta_path || !out_dir || !ks || nk == 0) { nm_set_error("null argument"); return NM_E_ARGUMENT; }
-    if (batch == 0) { nm_set_error("batch must be positive"); return NM_E_ARGUMENT; }
-    Driver d;
+// ------------------------------------------------------------------------------ parallel front-end
+
+// run fn(i) for i in [0, n) on up to `threads` threads (dynamic distribution)
+void parallel_for(size_t n, unsigned threads, const std::function<void(size_t)> &fn) {
+    if (n == 0) return;
+    if (threads <= 1 || n == 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); };
+    std::vector<std::thread> pool;
+    const unsigned t = threads < n ? threads : (unsigned)n;
+    for (unsigned k = 1; k < t; k++) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+}
+
+unsigned host_threads() {
+    if (const char *e = getenv("NEWMAP_AMD_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)v; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw == 0 ? 4 : (hw > 32 ? 32 : hw);
+}
+
+struct FastRecord {
+    std::string id;
+    const unsigned char *data = nullptr, *end = nullptr;   // its data lines in the mapped file
+    std::vector<const unsigned char *> chunk;             // line starts that cut the data into pieces of ~FAST_CHUNK bytes
+    std::vector<uint64_t> before;                          // bases (stripped bytes) in front of each piece; back() = all of them
+    uint64_t n_bases = 0;
+    int file = -1;                                         // output file (run of adjacent records with one id), -1 = none
+    uint64_t file_offset = 0;                              // first element of this record inside that file
+    uint64_t global = 0;                                   // first position of this record in the position space of the job
+};
+
+struct FastFile {
+    std::string id, path;
+    int fd = -1;
+    uint64_t n_elems = 0;
+    nm_search_summary sum;
+    std::atomic<long> outstanding{0};
+    bool reported = false;
+};
+
+const size_t FAST_CHUNK = 4u << 20;
+
+// bases of the lines in [p, e): every line without its trailing whitespace (bytes.rstrip(), newmap/fasta.py:47);
+// dst != nullptr: copy them there.  p is a line start.
+uint64_t strip_lines(const unsigned char *p, const unsigned char *e, uint8_t *dst) {
+    uint64_t n = 0;
+    while (p < e) {
+        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(e - p));
+        const unsigned char *le = nl ? nl : e;
+        const unsigned char *q = le;
+        while (q > p && is_space(q[-1])) q--;
+        const size_t len = (size_t)(q - p);
+        if (dst && len) memcpy(dst + n, p, len);
+        n += len;
+        p = nl ? nl + 1 : e;
+    }
+    return n;
+}
+
+struct FastSlot {
+    uint8_t *h_in = nullptr, *h_out = nullptr;
+    uint64_t *h_status = nullptr, *h_sum = nullptr;        // pinned: NM_STATUS_WORDS, 3 (non-zero elements, largest, smallest non-zero)
+    void *d_in = nullptr, *d_out = nullptr;
+    uint64_t *d_status = nullptr, *d_sum = nullptr;
+    hipEvent_t done = nullptr;
+    uint64_t seg_len = 0, count = 0, rec_start = 0;
+    int rec = -1;
+};
+
+// non-zero elements, the largest and the smallest non-zero one (newmap/search.py:331-347), on the device
+template <typename T>
+__global__ void k_out_summary(const T *__restrict__ out, uint64_t n, unsigned long long *__restrict__ sum) {
+    unsigned long long cnt = 0, mx = 0, mn = ~0ULL;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long v = out[i];
+        if (v) { cnt++; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 64);
+        const unsigned long long a = __shfl_down(mx, off, 64), b = __shfl_down(mn, off, 64);
+        mx = a > mx ? a : mx; mn = b < mn ? b : mn;
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd(&sum[0], cnt);
+        atomicMax(&sum[1], mx);
+        atomicMin(&sum[2], mn);
+    }
+}
+
+struct FastDriver {
+    nm_index *ix = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<uint32_t> ks;
+    bool range_mode = true, use_rc = true;
+    uint32_t kmin = 0, kmax = 0;
+    int elem_bytes = 1;
+    uint64_t batch = 0, lookahead = 0;
+    std::vector<FastRecord> recs;
+    std::deque<FastFile> files;
+    std::vector<FastSlot> slots;
+    // slot hand-over: main -> writers (jobs), writers -> main (free)
+    std::mutex mu;
+    std::condition_variable cv_job, cv_free;
+    std::deque<int> jobs, free_slots;
+    bool closing = false;
+    std::atomic<int> error{NM_OK};
+    std::string error_text;
+    std::mutex sum_mu;
+
+    void fail(int code, const std::string &text) {
+        int expect = NM_OK;
+        if (error.compare_exchange_strong(expect, code)) { std::lock_guard<std::mutex> g(sum_mu); error_text = text; }
+    }
+};
+
+void fast_writer(FastDriver *d) {
+    (void)hipSetDevice(d->device);
+    for (;;) {
+        int si;
+        {
+            std::unique_lock<std::mutex> lk(d->mu);
+            d->cv_job.wait(lk, [&] { return !d->jobs.empty() || d->closing; });
+            if (d->jobs.empty()) return;
+            si = d->jobs.front();
+            d->jobs.pop_front();
+        }
+        FastSlot &s = d->slots[si];
+        const FastRecord &r = d->recs[s.rec];
+        FastFile &f = d->files[r.file];
+        if (hipEventSynchronize(s.done) != hipSuccess) d->fail(NM_E_DEVICE, "waiting for a segment failed");
+        else if (d->error.load() == NM_OK) {
+            if (s.h_status[1]) {
+                const uint64_t at = s.h_status[2] < s.seg_len ? s.h_status[2] : 0;
+                const uint64_t len = s.seg_len - at < d->kmin ? s.seg_len - at : d->kmin;
+                char buf[1024];
+                snprintf(buf, sizeof buf, "The following generated k-mer was not found in the index:\n%.*s\nPossibly a mismatch between the "
+                         "sequence and the index. (record '%s', position %llu)", (int)len, (const char *)s.h_in + at,   // newmap/search.py:719-722
+                         r.id.c_str(), (unsigned long long)(s.rec_start + at));
+                d->fail(NM_E_KMER_NOT_FOUND, buf);
+            } else {
+                const uint64_t bytes = s.count * (uint64_t)d->elem_bytes;
+                uint64_t off = (r.file_offset + s.rec_start) * (uint64_t)d->elem_bytes, done = 0;
+                while (done < bytes) {
+                    const ssize_t w = pwrite(f.fd, s.h_out + done, bytes - done, (off_t)(off + done));
+                    if (w < 0) { if (errno == EINTR) continue; d->fail(NM_E_FILE_WRITE, "could not write " + f.path + ": " + strerror(errno)); break; }
+                    done += (uint64_t)w;
+                }
+                std::lock_guard<std::mutex> g(d->sum_mu);
+                nm_search_summary &rs = f.sum;                 // newmap/search.py:331-347
+                const uint64_t uniq = s.h_sum[0];
+                rs.positions += s.count;
+                rs.ambiguous += s.h_status[0];
+                rs.unique += uniq;
+                rs.no_unique += s.count - uniq - s.h_status[0];
+                if (uniq) {
+                    if ((uint32_t)s.h_sum[1] > rs.max_len) rs.max_len = (uint32_t)s.h_sum[1];
+                    if ((uint32_t)s.h_sum[2] < rs.min_len) rs.min_len = (uint32_t)s.h_sum[2];
+                }
+            }
+        }
+        --f.outstanding;
+        {
+            std::lock_guard<std::mutex> g(d->mu);
+            d->free_slots.push_back(si);
+        }
+        d->cv_free.notify_one();
+    }
+}
+
+// returns NM_OK, an error, or -1 when this front-end does not apply (gzip input, a file that cannot be mapped)
+int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks, uint32_t nk, int range_mode,
+             int use_revcomp, uint64_t batch, const std::vector<std::string> &include, const std::vector<std::string> &exclude,
+             nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world) {
+    const int fd = open(fasta_path, O_RDONLY);
+    if (fd < 0) { nm_set_error("could not open %s: %s", fasta_path, strerror(errno)); return NM_E_FILE_OPEN; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return -1; }
+    const size_t size = (size_t)st.st_size;
+    unsigned char magic[2] = {0, 0};
+    if (size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { close(fd); return -1; }
+    const unsigned char *base = nullptr;
+    if (size) {
+        void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); return -1; }
+        (void)madvise(m, size, MADV_WILLNEED);
+        base = (const unsigned char *)m;
+    }
+    close(fd);
+    const unsigned threads = host_threads();
+    FastDriver d;
     d.ix = ix;
     d.device = (int)nm_index_info(ix, 10);
     d.ks.assign(ks, ks + nk);
@@ -334,15 +539,343 @@ extern "C" int nm_search_fasta(nm_index *ix, const char *fasta_path, const char 
     d.use_rc = use_revcomp != 0;
     d.kmin = d.kmax = ks[0];
     for (uint32_t i = 1; i < nk; i++) { if (ks[i] < d.kmin) d.kmin = ks[i]; if (ks[i] > d.kmax) d.kmax = ks[i]; }
-    if (d.kmin < 1) { nm_set_error("k-mer lengths must be >= 1"); return NM_E_ARGUMENT; }
-    if (d.range_mode && d.kmin == d.kmax) { nm_set_error("math domain error: a k-mer range needs two different lengths"); return NM_E_ARGUMENT; }
+    d.elem_bytes = d.kmax <= 0xFF ? 1 : (d.kmax <= 0xFFFF ? 2 : 4);      // newmap/search.py:204-212
+    const char *suffix = d.elem_bytes == 1 ? "uint8" : (d.elem_bytes == 2 ? "uint16" : "uint32");
+    d.batch = batch;
+    d.lookahead = d.kmax - 1;                                            // newmap/search.py:229
+    auto unmap = [&]() { if (base) munmap((void *)base, size); };
+
+    // ---- header lines: '>' or ';' at a line start (newmap/fasta.py:59), found by a threaded scan
+    std::vector<size_t> heads;
+    {
+        const size_t slab = 32u << 20;
+        const size_t n_slabs = (size + slab - 1) / slab;
+        std::vector<std::vector<size_t>> found(n_slabs);
+        parallel_for(n_slabs, threads, [&](size_t k) {
+            const size_t lo = k * slab, hi = lo + slab < size ? lo + slab : size;
+            for (const char c : {'>', ';'}) {
+                const unsigned char *p = base + lo;
+                while (p < base + hi) {
+                    p = (const unsigned char *)memchr(p, c, (size_t)(base + hi - p));
+                    if (!p) break;
+                    const size_t i = (size_t)(p - base);
+                    if (i == 0 || base[i - 1] == '\n') found[k].push_back(i);
+                    p++;
+                }
+            }
+        });
+        for (auto &v : found) heads.insert(heads.end(), v.begin(), v.end());
+        std::sort(heads.begin(), heads.end());
+    }
+    // ---- records (ids: first whitespace-delimited token minus its first byte, newmap/fasta.py:75; data in front of any
+    // header has the id "")
+    auto add_record = [&](const std::string &id, size_t lo, size_t hi) {
+        FastRecord r;
+        r.id = id;
+        r.data = base + lo;
+        r.end = base + hi;
+        d.recs.push_back(std::move(r));
+    };
+    if (heads.empty() || heads[0] > 0) add_record("", 0, heads.empty() ? size : heads[0]);
+    for (size_t h = 0; h < heads.size(); h++) {
+        const unsigned char *p = base + heads[h];
+        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', size - heads[h]);
+        size_t len = nl ? (size_t)(nl - p) : size - heads[h];
+        while (len && is_space(p[len - 1])) len--;
+        size_t e = 0;
+        while (e < len && !is_space(p[e])) e++;
+        const size_t data_lo = nl ? (size_t)(nl - base) + 1 : size;
+        add_record(std::string((const char *)p + 1, e ? e - 1 : 0), data_lo, h + 1 < heads.size() ? heads[h + 1] : size);
+    }
+    // ---- pass 1: pieces of every record and the bases in front of each (threaded count)
+    struct Piece { size_t rec, idx; };
+    std::vector<Piece> pieces;
+    for (size_t r = 0; r < d.recs.size(); r++) {
+        FastRecord &rec = d.recs[r];
+        const unsigned char *p = rec.data;
+        while (p < rec.end) {
+            rec.chunk.push_back(p);
+            const unsigned char *q = p + FAST_CHUNK < rec.end ? p + FAST_CHUNK : rec.end;
+            if (q < rec.end) {                                  // cut at the next line start
+                const unsigned char *nl = (const unsigned char *)memchr(q, '\n', (size_t)(rec.end - q));
+                q = nl ? nl + 1 : rec.end;
+            }
+            p = q;
+        }
+        rec.chunk.push_back(rec.end);
+        rec.before.assign(rec.chunk.size(), 0);
+        for (size_t i = 0; i + 1 < rec.chunk.size(); i++) pieces.push_back({r, i});
+    }
+    parallel_for(pieces.size(), threads, [&](size_t k) {
+        FastRecord &rec = d.recs[pieces[k].rec];
+        rec.before[pieces[k].idx + 1] = strip_lines(rec.chunk[pieces[k].idx], rec.chunk[pieces[k].idx + 1], nullptr);
+    });
+    for (FastRecord &rec : d.recs) {
+        for (size_t i = 1; i < rec.before.size(); i++) rec.before[i] += rec.before[i - 1];
+        rec.n_bases = rec.before.empty() ? 0 : rec.before.back();
+    }
+    // ---- output files: one per run of adjacent records (that hold data and are wanted) with one id; an id that
+    // comes back later truncates the file again (newmap/search.py:268-305), so only its LAST run is searched
+    auto wanted = [&](const std::string &id) {
+        if (!include.empty()) { for (const auto &s : include) if (s == id) return true; return false; }
+        for (const auto &s : exclude) if (s == id) return false;
+        return true;
+    };
+    {
+        int cur = -1;
+        std::string cur_id;
+        for (FastRecord &rec : d.recs) {
+            if (rec.n_bases == 0) continue;                     // a record without data yields nothing (newmap/fasta.py:173-188)
+            if (!wanted(rec.id)) { cur = -1; continue; }
+            if (cur < 0 || rec.id != cur_id) {
+                d.files.emplace_back();
+                cur = (int)d.files.size() - 1;
+                cur_id = rec.id;
+                d.files[cur].id = rec.id;
+                d.files[cur].path = std::string(out_dir) + "/" + rec.id + ".unique." + suffix;
+                memset(&d.files[cur].sum, 0, sizeof(nm_search_summary));
+                d.files[cur].sum.max_len = d.kmin;               // newmap/search.py:242-243
+                d.files[cur].sum.min_len = d.kmax;
+            }
+            rec.file = cur;
+            rec.file_offset = d.files[cur].n_elems;
+            d.files[cur].n_elems += rec.n_bases;
+        }
+        for (size_t a = 0; a < d.files.size(); a++)
+            for (size_t b = a + 1; b < d.files.size(); b++)
+                if (d.files[b].id == d.files[a].id) { d.files[a].n_elems = 0; break; }     // superseded by a later run
+        for (FastRecord &rec : d.recs) if (rec.file >= 0 && d.files[rec.file].n_elems == 0) rec.file = -1;
+    }
+    uint64_t total_positions = 0;
+    for (FastRecord &rec : d.recs) if (rec.file >= 0) { rec.global = total_positions; total_positions += rec.n_bases; }
+    bool any = false;
+    for (const FastFile &f : d.files) any = any || f.n_elems;
+    int rc = NM_OK;
+    if (!any) {
+        unmap();
+        if (total) { memset(total, 0, sizeof *total); total->max_len = d.kmin; total->min_len = d.kmax; }
+        if (!include.empty() || !exclude.empty()) {
+            nm_set_error(include.empty() ? "The excluded sequences were too strict and nothing was processed" : "None of the included sequences were found");
+            return NM_E_ARGUMENT;
+        }
+        return NM_OK;
+    }
+    for (FastFile &f : d.files) {
+        if (!f.n_elems) continue;
+        // (every rank sets the same length: the ranks write disjoint ranges of one file)
+        f.fd = open(f.path.c_str(), O_WRONLY | O_CREAT | (world == 1 ? O_TRUNC : 0), 0666);
+        if (f.fd < 0 || ftruncate(f.fd, (off_t)(f.n_elems * (uint64_t)d.elem_bytes)) != 0) {
+            nm_set_error("could not open %s: %s", f.path.c_str(), strerror(errno));
+            rc = NM_E_FILE_WRITE;
+            break;
+        }
+    }
+    // ---- this rank's ranges of the position space: interleaved chunks of ~64 M positions (newmap_amd/parallel.py)
+    std::vector<std::pair<uint64_t, uint64_t>> ranges;
+    if (world <= 1) ranges.push_back({0, total_positions});
+    else {
+        uint64_t target = 64ull << 20;
+        if (const char *e = getenv("NEWMAP_AMD_SHARD_CHUNK")) { const long long v = atoll(e); if (v > 0) target = (uint64_t)v; }   // (tests)
+        const uint64_t rounds = (total_positions + (uint64_t)world * target - 1) / ((uint64_t)world * target);
+        const uint64_t n_chunks = (uint64_t)world * (rounds ? rounds : 1);
+        for (uint64_t c = (uint64_t)rank; c < n_chunks; c += (uint64_t)world) {
+            const uint64_t lo = (uint64_t)((unsigned __int128)total_positions * c / n_chunks), hi = (uint64_t)((unsigned __int128)total_positions * (c + 1) / n_chunks);
+            if (hi > lo) ranges.push_back({lo, hi});
+        }
+    }
+    // ---- device side
+    const int n_slots = 4, n_writers = 4;
+    int n_ready = 0;                                          // slots that were fully allocated
+    const uint64_t in_bytes = d.batch + d.lookahead + 64, out_bytes = d.batch * (uint64_t)d.elem_bytes + 64;
+    std::vector<std::thread> writers;
+    std::vector<uint8_t> rec_buf;
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return true;
+        nm_set_error("HIP error %d (%s): %s", (int)e, hipGetErrorString(e), what);
+        rc = NM_E_DEVICE;
+        return false;
+    };
+    if (rc == NM_OK && hip_ok(hipSetDevice(d.device), "hipSetDevice") && hip_ok(hipStreamCreate(&d.stream), "hipStreamCreate")) {
+        d.slots.resize(n_slots);
+        for (int i = 0; i < n_slots && rc == NM_OK; i++) {
+            FastSlot &s = d.slots[i];
+            if (!hip_ok(hipHostMalloc((void **)&s.h_in, in_bytes, hipHostMallocDefault), "pinned input") ||
+                !hip_ok(hipHostMalloc((void **)&s.h_out, out_bytes, hipHostMallocDefault), "pinned output") ||
+                !hip_ok(hipHostMalloc((void **)&s.h_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t), hipHostMallocDefault), "pinned status") ||
+                !hip_ok(hipMalloc(&s.d_in, in_bytes), "device input") || !hip_ok(hipMalloc(&s.d_out, out_bytes), "device output") ||
+                !hip_ok(hipMalloc((void **)&s.d_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t)), "device status") ||
+                !hip_ok(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "event")) break;
+            s.h_sum = s.h_status + NM_STATUS_WORDS;
+            s.d_sum = s.d_status + NM_STATUS_WORDS;
+            d.free_slots.push_back(i);
+            n_ready++;
+        }
+    }
+    if (rc == NM_OK) for (int i = 0; i < n_writers; i++) writers.emplace_back(fast_writer, &d);
+
+    // ---- the units of my ranges, record by record
+    std::vector<long> file_units(d.files.size(), 0);
+    for (size_t ri = 0; ri < d.recs.size() && rc == NM_OK && d.error.load() == NM_OK; ri++) {
+        FastRecord &rec = d.recs[ri];
+        if (rec.file < 0) continue;
+        // the parts of my ranges inside this record
+        std::vector<std::pair<uint64_t, uint64_t>> mine;
+        for (auto &rg : ranges) {
+            const uint64_t lo = rg.first > rec.global ? rg.first : rec.global;
+            const uint64_t hi = rg.second < rec.global + rec.n_bases ? rg.second : rec.global + rec.n_bases;
+            if (hi > lo) mine.push_back({lo - rec.global, hi - rec.global});
+        }
+        for (auto &part : mine) {
+            // strip the pieces that hold [part.first, part.second + lookahead) into rec_buf
+            const uint64_t need_hi = part.second + d.lookahead < rec.n_bases ? part.second + d.lookahead : rec.n_bases;
+            size_t c_lo = (size_t)(std::upper_bound(rec.before.begin(), rec.before.end(), part.first) - rec.before.begin()) - 1;
+            size_t c_hi = (size_t)(std::lower_bound(rec.before.begin(), rec.before.end(), need_hi) - rec.before.begin());
+            if (c_hi > rec.chunk.size() - 1) c_hi = rec.chunk.size() - 1;
+            const uint64_t buf_base = rec.before[c_lo];
+            rec_buf.resize((size_t)(rec.before[c_hi] - buf_base));
+            parallel_for(c_hi - c_lo, threads, [&](size_t k) {
+                const size_t c = c_lo + k;
+                strip_lines(rec.chunk[c], rec.chunk[c + 1], rec_buf.data() + (rec.before[c] - buf_base));
+            });
+            for (uint64_t p = part.first; p < part.second && rc == NM_OK && d.error.load() == NM_OK; p += d.batch) {
+                const uint64_t count = part.second - p < d.batch ? part.second - p : d.batch;
+                const uint64_t seg_len = (p + count + d.lookahead < rec.n_bases ? p + count + d.lookahead : rec.n_bases) - p;
+                int si;
+                {
+                    std::unique_lock<std::mutex> lk(d.mu);
+                    d.cv_free.wait(lk, [&] { return !d.free_slots.empty(); });
+                    si = d.free_slots.front();
+                    d.free_slots.pop_front();
+                }
+                FastSlot &s = d.slots[si];
+                s.rec = (int)ri; s.rec_start = p; s.count = count; s.seg_len = seg_len;
+                const uint8_t *src = rec_buf.data() + (p - buf_base);
+                const size_t cp = 8u << 20;
+                parallel_for((seg_len + cp - 1) / cp, seg_len > (32u << 20) ? 8 : 1, [&](size_t k) {
+                    const size_t o = k * cp, m = seg_len - o < cp ? seg_len - o : cp;
+                    memcpy(s.h_in + o, src + o, m);
+                });
+                bool ok = hip_ok(hipMemcpyAsync(s.d_in, s.h_in, seg_len, hipMemcpyHostToDevice, d.stream), "copy to device");
+                if (ok) {
+                    const int e = d.range_mode
+                        ? nm_min_unique_segment_dev(d.ix, s.d_in, seg_len, count, d.kmin, d.kmax, d.use_rc, d.elem_bytes, s.d_out, s.d_status, d.stream)
+                        : nm_fixed_k_segment_dev(d.ix, s.d_in, seg_len, count, d.ks.data(), (uint32_t)d.ks.size(), d.use_rc, d.elem_bytes, s.d_out, s.d_status, d.stream);
+                    if (e != NM_OK) { rc = e; ok = false; }
+                }
+                if (ok) {
+                    ok = hip_ok(hipMemsetAsync(s.d_sum, 0, 16, d.stream), "summary reset") &&             // count, largest
+                         hip_ok(hipMemsetAsync(s.d_sum + 2, 0xFF, 8, d.stream), "summary reset");        // smallest non-zero
+                    const unsigned grid = (unsigned)((count + 256 * 16 - 1) / (256 * 16) < 2048 ? (count + 256 * 16 - 1) / (256 * 16) : 2048);
+                    if (d.elem_bytes == 1) hipLaunchKernelGGL(k_out_summary<uint8_t>, dim3(grid ? grid : 1), dim3(256), 0, d.stream, (const uint8_t *)s.d_out, count, (unsigned long long *)s.d_sum);
+                    else if (d.elem_bytes == 2) hipLaunchKernelGGL(k_out_summary<uint16_t>, dim3(grid ? grid : 1), dim3(256), 0, d.stream, (const uint16_t *)s.d_out, count, (unsigned long long *)s.d_sum);
+                    else hipLaunchKernelGGL(k_out_summary<uint32_t>, dim3(grid ? grid : 1), dim3(256), 0, d.stream, (const uint32_t *)s.d_out, count, (unsigned long long *)s.d_sum);
+                    ok = ok && hip_ok(hipMemcpyAsync(s.h_out, s.d_out, count * (uint64_t)d.elem_bytes, hipMemcpyDeviceToHost, d.stream), "copy from device") &&
+                         hip_ok(hipMemcpyAsync(s.h_status, s.d_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t), hipMemcpyDeviceToHost, d.stream), "status copy") &&
+                         hip_ok(hipEventRecord(s.done, d.stream), "event record");
+                }
+                if (!ok) {                                         // give the slot back, stop
+                    std::lock_guard<std::mutex> g(d.mu);
+                    d.free_slots.push_back(si);
+                    break;
+                }
+                d.files[rec.file].outstanding++;
+                file_units[rec.file]++;
+                {
+                    std::lock_guard<std::mutex> g(d.mu);
+                    d.jobs.push_back(si);
+                }
+                d.cv_job.notify_one();
+            }
+        }
+    }
+    // ---- drain
+    {
+        std::unique_lock<std::mutex> lk(d.mu);
+        d.cv_free.wait(lk, [&] { return (int)d.free_slots.size() == n_ready; });
+        d.closing = true;
+    }
+    d.cv_job.notify_all();
+    for (auto &w : writers) w.join();
+    if (rc == NM_OK && d.error.load() != NM_OK) { rc = d.error.load(); nm_set_error("%s", d.error_text.c_str()); }
+    for (FastFile &f : d.files) if (f.fd >= 0) { if (close(f.fd) != 0 && rc == NM_OK) { nm_set_error("could not close %s: %s", f.path.c_str(), strerror(errno)); rc = NM_E_FILE_WRITE; } f.fd = -1; }
+    for (FastSlot &s : d.slots) {
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        if (s.h_status) (void)hipHostFree(s.h_status);
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_status) (void)hipFree(s.d_status);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+    unmap();
+    if (rc != NM_OK) return rc;
+    // ---- summaries in file order (this rank's share when world > 1), then the totals
+    nm_search_summary tot;
+    memset(&tot, 0, sizeof tot);
+    tot.max_len = d.kmin;
+    tot.min_len = d.kmax;
+    for (size_t fi = 0; fi < d.files.size(); fi++) {
+        FastFile &f = d.files[fi];
+        if (!f.n_elems) continue;
+        nm_search_summary &rs = f.sum;
+        rs.records = 1;
+        tot.records++;
+        tot.positions += rs.positions;
+        tot.ambiguous += rs.ambiguous;
+        tot.unique += rs.unique;
+        tot.no_unique += rs.no_unique;
+        if (rs.unique) {
+            if (rs.max_len > tot.max_len) tot.max_len = rs.max_len;
+            if (rs.min_len < tot.min_len) tot.min_len = rs.min_len;
+        }
+        if (cb && (world <= 1 || file_units[fi])) cb(f.id.c_str(), &rs, user);
+    }
+    if (total) *total = tot;
+    return NM_OK;
+}
+
+}  // namespace
+
+static int search_fasta_impl(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks,
+                             uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
+                             const char *const *include_ids, uint32_t n_include,
+                             const char *const *exclude_ids, uint32_t n_exclude,
+                             nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world) {
+    if (!ix || !fasta_path || !out_dir || !ks || nk == 0) { nm_set_error("null argument"); return NM_E_ARGUMENT; }
+    if (batch == 0) { nm_set_error("batch must be positive"); return NM_E_ARGUMENT; }
+    if (world < 1 || rank < 0 || rank >= world) { nm_set_error("rank %d of %d", rank, world); return NM_E_ARGUMENT; }
+    uint32_t kmin = ks[0], kmax = ks[0];
+    for (uint32_t i = 1; i < nk; i++) { if (ks[i] < kmin) kmin = ks[i]; if (ks[i] > kmax) kmax = ks[i]; }
+    if (kmin < 1) { nm_set_error("k-mer lengths must be >= 1"); return NM_E_ARGUMENT; }
+    if (range_mode && kmin == kmax) { nm_set_error("math domain error: a k-mer range needs two different lengths"); return NM_E_ARGUMENT; }
+    std::vector<std::string> include, exclude;
+    for (uint32_t i = 0; i < n_include; i++) include.emplace_back(include_ids[i]);
+    for (uint32_t i = 0; i < n_exclude; i++) exclude.emplace_back(exclude_ids[i]);
+    const char *stream_only = getenv("NEWMAP_AMD_STREAMING_DRIVER");
+    if (!(stream_only && stream_only[0] == '1')) {
+        const int rc = fast_run(ix, fasta_path, out_dir, ks, nk, range_mode, use_revcomp, batch, include, exclude, cb, user, total, rank, world);
+        if (rc != -1) return rc;
+    }
+    if (world > 1) {
+        nm_set_error("the sharded native driver reads byte ranges of an uncompressed FASTA file: decompress %s first", fasta_path);
+        return NM_E_ARGUMENT;
+    }
+    Driver d;
+    d.ix = ix;
+    d.device = (int)nm_index_info(ix, 10);
+    d.ks.assign(ks, ks + nk);
+    d.range_mode = range_mode != 0;
+    d.use_rc = use_revcomp != 0;
+    d.kmin = kmin;
+    d.kmax = kmax;
     d.elem_bytes = d.kmax <= 0xFF ? 1 : (d.kmax <= 0xFFFF ? 2 : 4);      // newmap/search.py:204-212
     d.suffix = d.elem_bytes == 1 ? "uint8" : (d.elem_bytes == 2 ? "uint16" : "uint32");
     d.batch = batch;
     d.lookahead = d.kmax - 1;                                            // newmap/search.py:229
     d.out_dir = out_dir;
-    for (uint32_t i = 0; i < n_include; i++) d.include.emplace_back(include_ids[i]);
-    for (uint32_t i = 0; i < n_exclude; i++) d.exclude.emplace_back(exclude_ids[i]);
+    d.include = include;
+    d.exclude = exclude;
     d.cb = cb;
     d.user = user;
     Driver::reset(d.total, d.kmin, d.kmax);
@@ -384,4 +917,22 @@ extern "C" int nm_search_fasta(nm_index *ix, const char *fasta_path, const char 
     for (auto &s : d.slots) free_slot(s);
     (void)hipStreamDestroy(d.stream);
     return rc;
+}
+
+extern "C" int nm_search_fasta(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks,
+                               uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
+                               const char *const *include_ids, uint32_t n_include,
+                               const char *const *exclude_ids, uint32_t n_exclude,
+                               nm_record_callback cb, void *user, nm_search_summary *total) {
+    return search_fasta_impl(ix, fasta_path, out_dir, ks, nk, range_mode, use_revcomp, batch, include_ids, n_include, exclude_ids, n_exclude,
+                             cb, user, total, 0, 1);
+}
+
+extern "C" int nm_search_fasta_shard(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks,
+                                     uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
+                                     const char *const *include_ids, uint32_t n_include,
+                                     const char *const *exclude_ids, uint32_t n_exclude,
+                                     nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world) {
+    return search_fasta_impl(ix, fasta_path, out_dir, ks, nk, range_mode, use_revcomp, batch, include_ids, n_include, exclude_ids, n_exclude,
+                             cb, user, total, rank, world);
 }

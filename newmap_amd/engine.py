@@ -230,9 +230,10 @@ class Index:
 
     # native driver ------------------------------------------------------------------------------
     def search_fasta(self, fasta_path, out_dir, kmer_lengths, is_range: bool, use_revcomp: bool = True,
-                     batch: int = 10_000_000, include=(), exclude=(), on_record=None):
-        """nm_search_fasta: FASTA in -> `<id>.unique.<dtype>` files out, natively.  `on_record(id: bytes,
-        summary: dict)` is called once per output file.  Returns the totals as a dict."""
+                     batch: int = 10_000_000, include=(), exclude=(), on_record=None, rank: int = 0, world: int = 1):
+        """nm_search_fasta(_shard): FASTA in -> `<id>.unique.<dtype>` files out, natively.  `on_record(id: bytes,
+        summary: dict)` is called once per output file.  world > 1: this process is one rank of a job with one
+        process per GPU and searches / writes only its own interleaved share.  Returns the totals as a dict."""
         ks = np.ascontiguousarray([min(kmer_lengths), max(kmer_lengths)] if is_range else list(kmer_lengths),
                                   dtype=np.uint32)
         fields = [f[0] for f in _lib.SearchSummary._fields_]
@@ -246,9 +247,10 @@ class Index:
         exc = (ctypes.c_char_p * max(len(exclude), 1))(*[bytes(x) for x in exclude])
         total = _lib.SearchSummary()
         with self._lock:
-            rc = self._L.nm_search_fasta(self.handle, os.fsencode(fasta_path), os.fsencode(out_dir), ks.ctypes.data,
-                                         ks.size, int(bool(is_range)), int(bool(use_revcomp)), int(batch),
-                                         inc, len(include), exc, len(exclude), cb, None, ctypes.byref(total))
+            rc = self._L.nm_search_fasta_shard(self.handle, os.fsencode(fasta_path), os.fsencode(out_dir), ks.ctypes.data,
+                                               ks.size, int(bool(is_range)), int(bool(use_revcomp)), int(batch),
+                                               inc, len(include), exc, len(exclude), cb, None, ctypes.byref(total),
+                                               int(rank), int(world))
         if rc == _lib.NM_E_ARGUMENT:
             msg = _lib.last_error()
             if "nothing was processed" in msg or "included sequences" in msg:

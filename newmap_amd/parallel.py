@@ -4,16 +4,18 @@ A position's result depends only on the bytes [p, p+kmax) of its own record and 
 index, so positions shard with no data-path collective:
 
   * the index is replicated -- every rank opens the same index file and uploads it to its own HBM;
-  * the concatenated position space of all selected records is cut into `world` contiguous slices;
-    a slice is cut into work units of at most `kmer_batch_size` positions plus kmax-1 bytes of
+  * the concatenated position space of all selected records is cut into world x R equal chunks of ~64 M positions,
+    chunk c owned by rank c % world (`interleaved_ranges`: equal shares, and a cluster of long repeats is spread over
+    all ranks); a chunk is cut into work units of at most `kmer_batch_size` positions plus kmax-1 bytes of
     lookahead taken from the same record (the reference's own segment rule,
     newmap/search.py:229-235, newmap/fasta.py:109-150);
-  * each rank runs its units on its GPU and keeps the uintN results of its slice;
-  * output: every rank writes its slice straight into the per-record `<id>.unique.<dtype>` files at the
-    slice's byte offsets (rank 0 creates the files at full length first) -- each GPU drains over its own PCIe
-    link and nothing crosses xGMI.  For jobs whose ranks do not share a file system
-    (NEWMAP_AMD_GATHER=1) ONE collective at the end gathers the padded per-rank slices on rank 0 (RCCL),
-    which writes the files.
+  * default: every rank runs the native driver on its own share (`nm_search_fasta_shard`): it strips only the byte
+    ranges of its units out of the FASTA, searches them on its GPU and writes them straight into the per-record
+    `<id>.unique.<dtype>` files at their offsets -- each GPU drains over its own PCIe link, nothing crosses xGMI and no
+    rank holds the whole FASTA;
+  * gzip input: the ranks read the records in Python and write their shares the same way (`write_ranges_direct`);
+    jobs whose ranks do not share a file system (NEWMAP_AMD_GATHER=1): ONE collective at the end gathers the padded
+    per-rank results on rank 0 (RCCL), which writes the files.
 
 The same code runs on CPU tensors with the "gloo" backend (tests/test_parallel_gloo.py), with the
 per-unit compute injected.
@@ -121,37 +123,74 @@ def gather_to_root(local: np.ndarray, total: int, world: int, rank: int, device=
     return None
 
 
-def write_slice_direct(records: Sequence[tuple[bytes, bytes]], local: np.ndarray, lo: int, hi: int,
-                       path_of: Callable[[bytes], Path], rank: int, barrier: Callable[[], None]) -> None:
-    """No collective: rank 0 creates every output file at its full length, then each rank writes the part of
-    its slice [lo, hi) (global positions, records laid end to end) that falls into each record at that
-    record's byte offset.  Duplicate ids: the later record wins, like the reference's truncate-on-new-id
-    (search.py:304-305)."""
+def file_layout(records: Sequence[tuple[bytes, bytes]]) -> list[tuple[bool, int, int]]:
+    """Which file bytes a record owns, the reference's way (newmap/search.py:268-305): adjacent records with one id
+    append to one file; an id that comes back later truncates the file again, so only its LAST run of records is kept.
+    Returns per record (owns output, first element of the record inside its file, elements in the whole file)."""
+    runs: list[list[int]] = []
+    for i, (rid, _) in enumerate(records):
+        if runs and records[runs[-1][0]][0] == rid:
+            runs[-1].append(i)
+        else:
+            runs.append([i])
+    last_run = {records[r[0]][0]: k for k, r in enumerate(runs)}
+    out: list[tuple[bool, int, int]] = [(False, 0, 0)] * len(records)
+    for k, r in enumerate(runs):
+        owns = last_run[records[r[0]][0]] == k
+        total = sum(len(records[i][1]) for i in r)
+        off = 0
+        for i in r:
+            out[i] = (owns, off, total)
+            off += len(records[i][1])
+    return out
+
+
+def write_ranges_direct(records: Sequence[tuple[bytes, bytes]], parts: Sequence[tuple[int, np.ndarray]],
+                        path_of: Callable[[bytes], Path], rank: int, barrier: Callable[[], None]) -> None:
+    """No collective: rank 0 creates every output file at its full length, then each rank writes its results --
+    `parts` = (first global position, elements), global = records laid end to end -- at their byte offsets.  Records
+    with one id: see `file_layout`."""
     import os
-    item = local.dtype.itemsize
-    last = {rid: i for i, (rid, _) in enumerate(records)}             # the record that owns each file
+    layout = file_layout(records)
     if rank == 0:
-        for i, (rid, data) in enumerate(records):
-            if last[rid] == i:
+        done = set()
+        for (rid, _), (owns, _, total) in zip(records, layout):
+            if owns and rid not in done:
+                done.add(rid)
                 with open(path_of(rid), "wb") as fh:
-                    fh.truncate(len(data) * item)
+                    fh.truncate(total * (parts[0][1].dtype.itemsize if parts else 1))
     barrier()
-    base = 0
-    for i, (rid, data) in enumerate(records):
-        n = len(data)
-        a, b = max(lo, base), min(hi, base + n)
-        if a < b and last[rid] == i:
+    starts = np.concatenate(([0], np.cumsum([len(d) for _, d in records]))).astype(np.int64)
+    for lo, arr in parts:
+        item = arr.dtype.itemsize
+        hi = lo + arr.size
+        for i, (rid, data) in enumerate(records):
+            a, b = max(lo, int(starts[i])), min(hi, int(starts[i + 1]))
+            owns, off0, _ = layout[i]
+            if a >= b or not owns:
+                continue
             fd = os.open(path_of(rid), os.O_WRONLY)
             try:
-                buf = memoryview(np.ascontiguousarray(local[a - lo:b - lo])).cast("B")
-                off = (a - base) * item
+                buf = memoryview(np.ascontiguousarray(arr[a - lo:b - lo])).cast("B")
+                off = (off0 + a - int(starts[i])) * item
                 while len(buf):
                     w = os.pwrite(fd, buf, off)
                     buf, off = buf[w:], off + w
             finally:
                 os.close(fd)
-        base += n
     barrier()
+
+
+def write_slice_direct(records: Sequence[tuple[bytes, bytes]], local: np.ndarray, lo: int, hi: int,
+                       path_of: Callable[[bytes], Path], rank: int, barrier: Callable[[], None]) -> None:
+    """one contiguous slice [lo, hi) of the position space (kept for callers with contiguous shares)"""
+    if rank == 0 and local.size == 0:
+        local = np.zeros(0, dtype=local.dtype)
+    # (an empty share still takes part in the file creation and the barriers)
+    parts = [(lo, local)] if hi > lo else []
+    if rank == 0 and not parts:
+        parts = [(0, np.zeros(0, dtype=local.dtype))]
+    write_ranges_direct(records, parts, path_of, rank, barrier)
 
 
 def search_records_sharded(records: Sequence[tuple[bytes, bytes]], compute: Callable[[bytes, int], np.ndarray],
@@ -166,9 +205,13 @@ def search_records_sharded(records: Sequence[tuple[bytes, bytes]], compute: Call
     if full is None:
         return None
     out, base = {}, 0
-    for (rid, _), n in zip(records, lengths):
-        out[rid] = full[base:base + n]        # duplicate ids: the later record wins, like the
-        base += n                             # reference's truncate-on-new-id (search.py:304-305)
+    layout = file_layout(records)             # adjacent records with one id append; a later run of an id wins
+    for (rid, _), n, (owns, off, total) in zip(records, lengths, layout):
+        if owns:
+            if off == 0:
+                out[rid] = np.zeros(total, dtype=full.dtype)
+            out[rid][off:off + n] = full[base:base + n]
+        base += n
     return out
 
 
@@ -199,13 +242,35 @@ def write_unique_counts_distributed(config) -> None:
     dtype, suffix = S.output_type(kmax)
     if len(config.fasta_filepaths) != 1 or len(config.fmindex_filepaths) != 1:
         raise NotImplementedError("the sharded search takes exactly one FASTA and one index")
-    with optional_gzip_open(config.fasta_filepaths[0], "rb") as fh:
-        records = [(rid, data) for rid, data in fasta_records(fh) if S._wanted(config, rid)]
-    if not records:
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def nothing_found():
         if config.include_sequence_ids:
             raise ValueError(f"None of the included sequences were found: {config.include_sequence_ids}")
         raise ValueError("The excluded sequences were too strict and nothing was processed: "
                          f"{config.exclude_sequence_ids}")
+
+    gather = world > 1 and os.environ.get("NEWMAP_AMD_GATHER", "0") == "1"
+    with open(config.fasta_filepaths[0], "rb") as fh:
+        gzipped = fh.read(2) == b"\x1f\x8b"
+    if not gather and not gzipped and os.environ.get("NEWMAP_AMD_PYTHON_DRIVER", "") != "1":
+        # every rank runs the native driver on its own interleaved share of the position space
+        index = cached_index(config.fmindex_filepaths[0], local_rank if config.device is None else config.device)
+        total = index.search_fasta(config.fasta_filepaths[0], config.output_directory, config.kmer_lengths,
+                                   config.is_binary_search, config.use_reverse_complement, config.kmer_batch_size,
+                                   config.include_sequence_ids, config.exclude_sequence_ids, None, rank, world)
+        barrier()
+        if total["records"] == 0 and (config.include_sequence_ids or config.exclude_sequence_ids):
+            nothing_found()
+        return
+    with optional_gzip_open(config.fasta_filepaths[0], "rb") as fh:
+        records = [(rid, data) for rid, data in fasta_records(fh) if S._wanted(config, rid)]
+    if not records:
+        nothing_found()
     index = cached_index(config.fmindex_filepaths[0], local_rank if config.device is None else config.device)
 
     def compute(seg: bytes, count: int) -> np.ndarray:
@@ -216,12 +281,7 @@ def write_unique_counts_distributed(config) -> None:
     def path_of(rid: bytes) -> Path:
         return Path(config.output_directory) / S.UNIQUE_COUNT_FILENAME_FORMAT.format(rid.decode(), suffix)
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-
-    if world > 1 and os.environ.get("NEWMAP_AMD_GATHER", "0") == "1":   # ranks without a shared file system
+    if gather:                                                          # ranks without a shared file system
         result = search_records_sharded(records, compute, kmax, config.kmer_batch_size, dtype, world, rank, device)
         if result is not None:
             for rid, arr in result.items():
@@ -230,6 +290,9 @@ def write_unique_counts_distributed(config) -> None:
         barrier()
         return
     lengths = [len(d) for _, d in records]
-    lo, hi = shard_bounds(int(sum(lengths)), world)[rank]
-    local = run_slice(records, units_for_slice(lengths, lo, hi, config.kmer_batch_size, kmax), compute, dtype)
-    write_slice_direct(records, local, lo, hi, path_of, rank, barrier)
+    parts = []
+    for lo, hi in interleaved_ranges(int(sum(lengths)), world)[rank]:
+        parts.append((lo, run_slice(records, units_for_slice(lengths, lo, hi, config.kmer_batch_size, kmax), compute, dtype)))
+    if not parts:
+        parts = [(0, np.zeros(0, dtype=dtype))]
+    write_ranges_direct(records, parts, path_of, rank, barrier)

@@ -750,6 +750,56 @@ def test_list_mode_iupac_divergence(mixed_genome, eng):
     assert differ.size == int(np.count_nonzero(want[covers] != 0))
 
 
+def test_native_driver_front_ends_and_shards(tmp_path, mixed_genome, eng, monkeypatch):
+    """csrc/nm_driver.hip: the parallel front-end (mapped file, threaded strip, slot ring, writer pool) == the streaming
+    one (forced) on an odd FASTA and on the mixed genome; and the shares of a 3-rank job (nm_search_fasta_shard, called
+    rank by rank here; small interleaved chunks) add up to the single-process files, for range and list mode."""
+    rng = np.random.default_rng(78)
+    body = _random_dna(rng, 9000)
+    odd = (b"ACGTACGTTTGACCA" + body[:200] + b"\n>r1 first\n" + body[200:1500] + b"\n" + body[1500:1700] + b"  \n"
+           b">r1 again\n" + body[1700:2500] + b"\n;r2\r\n" + body[2500:3300] + b"\r\n>empty\n>r3\n" + body[3300:6000] +
+           b"\n>r1\n" + body[6000:6100] + b"\n\n>r4 x\n" + b"\n".join(body[6100 + i:6100 + i + 61] for i in range(0, 2900, 61)) + b"\nNNNN")
+    fa_odd, idx_odd = _build_index(tmp_path, odd, "odd")
+    g = mixed_genome
+
+    def run(ix, fa, out, ks, is_range, batch, rank=0, world=1):
+        out.mkdir(exist_ok=True)
+        return ix.search_fasta(fa, out, ks, is_range, True, batch, rank=rank, world=world)
+
+    def files(d):
+        return {p.name: p.read_bytes() for p in sorted(d.iterdir())}
+
+    for fa, idx, tag in ((fa_odd, idx_odd, "odd"), (g["fa"], g["idx"], "mixed")):
+        with eng.Index(idx, 0) as ix:
+            for ks, is_range, batch in (([12, 60], True, 700), ([20, 200], True, 100_000), ([24], False, 50_000), ([30, 16, 40], False, 1300)):
+                name = f"{tag}_{ks[0]}_{int(is_range)}_{batch}"
+                monkeypatch.setenv("NEWMAP_AMD_STREAMING_DRIVER", "1")
+                t_stream = run(ix, fa, tmp_path / (name + "_s"), ks, is_range, batch)
+                monkeypatch.setenv("NEWMAP_AMD_STREAMING_DRIVER", "0")
+                t_fast = run(ix, fa, tmp_path / (name + "_f"), ks, is_range, batch)
+                a, b = files(tmp_path / (name + "_s")), files(tmp_path / (name + "_f"))
+                assert a == b and a, name
+                for k in ("positions", "ambiguous", "unique", "no_unique", "max_len", "min_len"):
+                    # (the streaming reader also counts the earlier run of an id that comes back: "r1" in the odd file)
+                    assert tag == "odd" or t_stream[k] == t_fast[k], (name, k)
+                monkeypatch.setenv("NEWMAP_AMD_SHARD_CHUNK", "997")
+                parts = [run(ix, fa, tmp_path / (name + "_w3"), ks, is_range, batch, rank=r, world=3) for r in range(3)]
+                monkeypatch.delenv("NEWMAP_AMD_SHARD_CHUNK")
+                assert files(tmp_path / (name + "_w3")) == b, name
+                assert sum(p["positions"] for p in parts) == t_fast["positions"] and sum(p["unique"] for p in parts) == t_fast["unique"]
+    with eng.Index(idx_odd, 0) as ix:                       # include / exclude and a mismatching FASTA through the parallel front-end
+        t = run(ix, fa_odd, tmp_path / "inc", [12, 60], True, 700)
+        assert t["records"] == 5                            # "", r1 (its last run), r2, r3, r4
+        out = tmp_path / "inc2"
+        out.mkdir()
+        assert ix.search_fasta(fa_odd, out, [12, 60], True, True, 700, include=[b"r3"])["records"] == 1
+        assert sorted(p.name for p in out.iterdir()) == ["r3.unique.uint8"]
+        other = tmp_path / "other.fa"
+        other.write_bytes(b">zz\n" + _random_dna(rng, 3000) + b"\n")
+        with pytest.raises(RuntimeError, match="The following generated k-mer was not found in the index:\n[ACGT]+\n"):
+            run(ix, other, tmp_path / "bad", [12, 60], True, 700)
+
+
 def test_native_driver_equals_python_driver(tmp_path, golden_search, eng, monkeypatch):
     """csrc/nm_driver.hip (streaming FASTA reader + pipelined launches) writes the same files as the
     segment-by-segment Python loop and as the reference fixtures; also .gz input, include / exclude,

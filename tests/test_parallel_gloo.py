@@ -28,6 +28,26 @@ def _make_records():
     return [(b"a", bytes(a)), (b"b", b), (b"c", c)]
 
 
+def _records_with_duplicates():
+    r = _make_records()
+    # (every record is a substring of an indexed one: the injected oracle raises on k-mers it has never seen)
+    return [r[0], r[1], (b"b", r[0][1][2000:2700]), r[2], (b"a", r[1][1][:900])]
+
+
+def _single_process_files(records, compute, dtype):
+    """what newmap_amd.search.write_unique_counts (and the reference, search.py:268-305) leaves on disk"""
+    files = {}
+    prev = None
+    for rid, data in records:
+        arr = np.asarray(compute(data), dtype=dtype)
+        if rid == prev:
+            files[rid] = np.concatenate((files[rid], arr))
+        else:
+            files[rid] = arr                      # truncate on a new id
+        prev = rid
+    return files
+
+
 def _worker(rank, world, port, outdir):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -50,15 +70,20 @@ def _worker(rank, world, port, outdir):
     else:
         assert res is None
     dist.barrier()
-    # the default output path: no collective, every rank writes its slice into the shared files (uint16 here, so
-    # that byte offsets differ from positions); records "a" twice: the later one owns the file
-    records2 = records + [(b"a", records[1][1][:900])]
+    # the direct output path: no collective, every rank writes its interleaved ranges into the shared files (uint16
+    # here, so that byte offsets differ from positions).  Record ids the reference's way (search.py:268-305): "b" twice
+    # in a row appends, "a" comes back later and its last run owns the file
+    records2 = _records_with_duplicates()
     lengths = [len(d) for _, d in records2]
-    lo, hi = parallel.shard_bounds(sum(lengths), world)[rank]
-    local = parallel.run_slice(records2, parallel.units_for_slice(lengths, lo, hi, batch, kmax),
-                               lambda seg, count: rd.closed_form_min_unique(seg, oracle, kmin, kmax)[:count], np.uint16)
-    parallel.write_slice_direct(records2, local, lo, hi, lambda rid: Path(outdir) / f"w{world}.{rid.decode()}.uint16",
-                                rank, dist.barrier)
+    parts = []
+    for lo, hi in parallel.interleaved_ranges(sum(lengths), world, 1000)[rank]:
+        parts.append((lo, parallel.run_slice(records2, parallel.units_for_slice(lengths, lo, hi, batch, kmax),
+                                             lambda seg, count: rd.closed_form_min_unique(seg, oracle, kmin, kmax)[:count], np.uint16)))
+    parallel.write_ranges_direct(records2, parts or [(0, np.zeros(0, np.uint16))], lambda rid: Path(outdir) / f"w{world}.{rid.decode()}.uint16",
+                                 rank, dist.barrier)
+    res2 = parallel.search_records_sharded(records2, compute, kmax, batch, np.uint8, world, rank)
+    if rank == 0:
+        np.savez(os.path.join(outdir, f"w{world}_dup.npz"), **{k.decode(): v for k, v in res2.items()})
     dist.destroy_process_group()
 
 
@@ -74,9 +99,13 @@ def test_sharded_search_equals_single_process(tmp_path, world):
     for rid, data in records:
         want = rd.closed_form_min_unique(data, oracle, 8, 40)
         assert np.array_equal(got[rid.decode()], want), rid
-    for rid, data in [records[1], records[2], (b"a", records[1][1][:900])]:        # files written without a collective
-        want = rd.closed_form_min_unique(data, oracle, 8, 40).astype(np.uint16)
+    # files written without a collective, and the gathered result, for records that share ids
+    want_files = _single_process_files(_records_with_duplicates(), lambda d: rd.closed_form_min_unique(d, oracle, 8, 40), np.uint16)
+    dup = np.load(tmp_path / f"w{world}_dup.npz")
+    assert sorted(dup.files) == sorted(k.decode() for k in want_files)
+    for rid, want in want_files.items():
         assert np.array_equal(np.fromfile(tmp_path / f"w{world}.{rid.decode()}.uint16", dtype=np.uint16), want), rid
+        assert np.array_equal(dup[rid.decode()], want.astype(np.uint8)), rid
 
 
 def test_plan_covers_every_position_once():
@@ -95,40 +124,69 @@ def test_plan_covers_every_position_once():
         assert (seen == 1).all()
 
 
-def _gather_worker(rank, world, port, outdir):
-    """the double-buffered asynchronous gather of bench.py's N>1 step, on CPU tensors"""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    n, steps = 1003, 5
-    per = -(-n // world)
-    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
-    gather_bufs = [torch.empty(per * world, dtype=torch.uint8) for _ in range(2)] if rank == 0 else None
-    pads = [torch.zeros(per, dtype=torch.uint8) for _ in range(2)]
-    pending, seen = None, []
-    for i in range(steps):
-        d_out = ((torch.arange(n) * 7 + i) % 251).to(torch.uint8)          # this pass's full result
-        b = i & 1
-        pads[b][:hi - lo].copy_(d_out[lo:hi])
-        if pending is not None:
-            pending.wait()
-            if rank == 0:
-                seen.append(gather_bufs[(i - 1) & 1].clone())
-        pending = dist.gather(pads[b], list(gather_bufs[b].split(per)) if rank == 0 else None, dst=0, async_op=True)
-    pending.wait()
-    if rank == 0:
-        seen.append(gather_bufs[(steps - 1) & 1].clone())
-        for i, g in enumerate(seen):
-            want = ((torch.arange(n) * 7 + i) % 251).to(torch.uint8)
-            got = torch.cat([g[r * per: r * per + (min((r + 1) * per, n) - min(r * per, n))] for r in range(world)])
-            assert torch.equal(got, want), i
-        Path(outdir, "gather_ok").write_text("ok")
-    dist.barrier()
-    dist.destroy_process_group()
+def test_interleaved_ranges_cover_and_balance():
+    """the plan of the N > 1 jobs: every position exactly once, equal shares, chunks dealt round-robin"""
+    from newmap_amd import parallel
+    for total, world, target in ((3_088_269_832, 8, 64 << 20), (100_000_000, 8, 64 << 20), (1003, 3, 100), (5, 8, 64), (0, 4, 10)):
+        per_rank = parallel.interleaved_ranges(total, world, target)
+        assert len(per_rank) == world
+        flat = sorted(r for rs in per_rank for r in rs)
+        assert sum(hi - lo for lo, hi in flat) == total
+        assert all(flat[i][1] == flat[i + 1][0] for i in range(len(flat) - 1)) and (not flat or (flat[0][0] == 0 and flat[-1][1] == total))
+        sizes = [sum(hi - lo for lo, hi in rs) for rs in per_rank]
+        if total >= world:
+            assert max(sizes) - min(sizes) <= max(len(rs) for rs in per_rank)
+        if total > world * target:
+            assert all(len(rs) >= 2 for rs in per_rank)          # several chunks per rank: interleaved
 
 
-def test_async_double_buffered_gather_pattern(tmp_path):
-    import torch.multiprocessing as mp
-    mp.spawn(_gather_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
-    assert (tmp_path / "gather_ok").exists()
+def _tandem_spans(n: int, seed: int, frac: float = 0.5):
+    """the tandem arrays newmap_amd.synth.tandem_dna(n, seed) lays down: same control flow, same draws from the
+    generator (the bases are drawn and thrown away), no sequence kept"""
+    rng = np.random.default_rng(seed)
+    spans, pos, in_arrays = [], 0, 0
+    while pos < n:
+        m = min(int(rng.integers(50, 5001)), n - pos)
+        rng.integers(0, 4, m, dtype=np.uint8)
+        pos += m
+        if pos >= n:
+            break
+        if in_arrays < frac * pos:
+            rng.integers(0, 4, int(rng.integers(2, 201)), dtype=np.uint8)
+            m = min(int(rng.integers(200, 50001)), n - pos)
+            spans.append((pos, pos + m))
+            pos += m
+            in_arrays += m
+    return np.array(spans, dtype=np.int64)
+
+
+def test_interleaved_plan_spreads_repeat_clusters():
+    """BASELINE configs[4] at full size (1 Gbp, 50 % tandem repeats, seed 20260517): a position inside an array costs a
+    multiple of one outside (open after the sites, probe walks of up to kmax + 63 steps).  With the interleaved chunks of
+    the N > 1 plan the per-rank cost differs by less than 10 %."""
+    from newmap_amd import parallel, synth
+    n = 1_000_000_000
+    small = synth.tandem_dna(200_000, 20260517)               # the span model follows the generator exactly
+    sp = _tandem_spans(200_000, 20260517)
+    for a, b in sp[:5]:
+        unit = None
+        for period in range(2, 201):
+            if b - a > 2 * period and (small[a + period:b] == small[a:b - period]).all():
+                unit = period
+                break
+        assert unit is not None
+    spans = _tandem_spans(n, 20260517)
+    covered = np.concatenate(([0], np.cumsum(spans[:, 1] - spans[:, 0])))
+    assert 0.45 < covered[-1] / n < 0.55
+
+    def repeat_positions(lo, hi):                            # positions of [lo, hi) inside arrays
+        def upto(x):
+            k = int(np.searchsorted(spans[:, 0], x, side="right"))
+            return int(covered[k]) - (max(int(spans[k - 1, 1]) - x, 0) if k else 0)
+        return upto(hi) - upto(lo)
+
+    for world in (2, 4, 8):
+        per_rank = parallel.interleaved_ranges(n, world)
+        loads = np.array([sum((hi - lo) + 20.0 * repeat_positions(lo, hi) for lo, hi in rs) for rs in per_rank])
+        assert (loads.max() - loads.min()) / loads.mean() < 0.10, (world, loads)
+        assert sum(repeat_positions(lo, hi) for rs in per_rank for lo, hi in rs) == covered[-1]

@@ -431,7 +431,7 @@ def end_to_end(args, wl: Workload, fa, idx, dev_index, gpu_run: Run):
     with Index(idx, dev_index, "auto-small") as ix:
         t_open = time.time() - t0
         t0 = time.time()
-        total = ix.search_fasta(fa, out, [wl.krange[0], wl.krange[1]], True, True, args.batch)
+        total = ix.search_fasta(fa, out, [wl.krange[0], wl.krange[1]], True, True, REFERENCE_BATCH)   # the CLI's default --kmer-batch-size
         t_search = time.time() - t0
     checked = 0
     for (so, seg_len, cnt, oo, i) in gpu_run.segs[:2]:

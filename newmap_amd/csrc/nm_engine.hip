@@ -666,6 +666,8 @@ struct nm_index {
     void *d_lfb = nullptr;                // LF blocks
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;           // repeat probes of repeat-rich input run here, beside k_sites (launch_sites)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // scratch owned by the handle (grown on demand)
     nm_buffer enc, seq, out, status, ks, starts, lens, work, settled, coarse, need;
     uint64_t coarse_min = 32ull << 20;    // launches of at least this many positions also run the coarse probes (NEWMAP_AMD_COARSE_MIN) ...
@@ -678,6 +680,7 @@ struct nm_index {
     uint64_t enc_words = 0;               // words written by the last nm_encode
     int kernel_version = 0;               // 0 = automatic (sites when the quad table applies, else 1); 1 / 5 force a kernel
     uint32_t last_site_m = 0;             // core length of the table the sites of the last launch read (nm_index_info 20)
+    bool probes_beside = true;            // NEWMAP_AMD_PROBES_BESIDE=0: the probes always follow k_sites on its stream (A/B)
     int site_table = 0;                   // measurement knob (NM_OPT_SITE_TABLE): 0 = pick per launch, 1 = long cores, 2 = short cores
     uint32_t site_d_cap = NM_SITE_MAX_D;  // measurement knob (NEWMAP_AMD_SITE_D): cap on d = kmin - window of the sites
     bool count_steps = false;
@@ -926,6 +929,11 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     auto fail = [&](int code) { fclose(fp); nm_index_close(ix); return code; };
     if (hipSetDevice(device) != hipSuccess) { nm_set_error("hipSetDevice(%d) failed", device); return fail(NM_E_DEVICE); }
     if (hipStreamCreate(&ix->stream) != hipSuccess) { nm_set_error("hipStreamCreate failed"); return fail(NM_E_DEVICE); }
+    if (hipStreamCreateWithFlags(&ix->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();                               // (without them the probes simply follow k_sites on one stream)
+        ix->side = nullptr;
+    }
 
     const uint64_t rank_bytes = h.n_rank_blocks * sizeof(nm_rank_block);
     const uint64_t strand_bytes = h.n_strand_blocks * sizeof(nm_strand_block);
@@ -1026,6 +1034,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     if (const char *cm = getenv("NEWMAP_AMD_COARSE_MIN")) ix->coarse_min = strtoull(cm, nullptr, 10);
     if (const char *cm = getenv("NEWMAP_AMD_COARSE")) ix->coarse_mode = atoi(cm);
+    if (const char *pb = getenv("NEWMAP_AMD_PROBES_BESIDE")) ix->probes_beside = pb[0] != '0';
     if (const char *sd = getenv("NEWMAP_AMD_SITE_D")) { ix->site_d_cap = (uint32_t)atoi(sd); if (ix->site_d_cap > NM_SITE_MAX_D) ix->site_d_cap = NM_SITE_MAX_D; }
     if (hipHostMalloc((void **)&ix->h_repeats_seen, 64, hipHostMallocMapped) == hipSuccess) {
         *ix->h_repeats_seen = 0;
@@ -1056,6 +1065,9 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (ix->h_repeats_seen) (void)hipHostFree(ix->h_repeats_seen);
     if (ix->d_seen_latch) (void)hipFree(ix->d_seen_latch);
     for (auto &pool : ix->ev_pool) for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    if (ix->side) { (void)hipStreamSynchronize(ix->side); (void)hipStreamDestroy(ix->side); }
+    if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
+    if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -1278,6 +1290,19 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, uint64_t n, uint32
     const dim3 sgrid((unsigned)((n + bp - 1) / bp)), sblock(NM_SITE_BLOCK);
     const size_t lds = nm_site_lds_bytes(d);
     ix->last_kernel = 5;
+    // Input that has shown long repeats before (the latch the fine probes set): the probes are walks of up to kmax + 511
+    // dependent steps -- bound by latency, not by lines -- so they run on a second stream BESIDE k_sites (every stride:
+    // the bitmap that would gate them is not there yet) and k_resolve waits for both.  Otherwise they follow k_sites
+    // and look only at the strides it left mostly open -- on input without long repeats that is none at all.
+    const uint32_t *probe = nullptr;
+    const bool repeats_met = ix->h_repeats_seen && *(volatile uint32_t *)ix->h_repeats_seen != 0;
+    const bool beside = ix->repeat_probes && repeats_met && ix->side && ix->probes_beside && n >= (1u << 16);
+    if (beside) {
+        HIP_TRY(hipEventRecord(ix->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(ix->side, ix->ev_fork, 0));
+        if ((rc = nm_launch_probes<BIG>(ix, view, n, kmax, ix->side, &probe, nullptr)) != NM_OK) return rc;
+        HIP_TRY(hipEventRecord(ix->ev_join, ix->side));
+    }
     {
         nm_timed timed(ix, st);
 #define NM_LAUNCH_SITES(STATS_, LIST_) hipLaunchKernelGGL((k_sites<BIG, STATS_, LIST_>), sgrid, sblock, lds, st, view, enc, ix->enc_words, n, kmin, kmax, d, d_out, \
@@ -1286,8 +1311,8 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, uint64_t n, uint32
         else        { if (ix->count_steps) NM_LAUNCH_SITES(true, false); else NM_LAUNCH_SITES(false, false); }
 #undef NM_LAUNCH_SITES
     }
-    const uint32_t *probe = nullptr;
-    if (ix->repeat_probes && (rc = nm_launch_probes<BIG>(ix, view, n, kmax, st, &probe, need)) != NM_OK) return rc;
+    if (beside) HIP_TRY(hipStreamWaitEvent(st, ix->ev_join, 0));
+    else if (ix->repeat_probes && (rc = nm_launch_probes<BIG>(ix, view, n, kmax, st, &probe, need)) != NM_OK) return rc;
     const dim3 rgrid((unsigned)((n_need + NM_RES_WORDS - 1) / NM_RES_WORDS)), rblock(NM_RES_BLOCK);
 #define NM_LAUNCH_RES(STATS_, LIST_) hipLaunchKernelGGL((k_resolve<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, \
                                                         d_status, (const uint64_t *)need, n_need, probe, (const unsigned long long *)work, seq_len, d_list, n_list)

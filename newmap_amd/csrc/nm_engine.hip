@@ -453,7 +453,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
 }
 
 // ---- k_resolve: the positions k_sites left open -----------------------------------------------------
-// A block owns NM_RES_WORDS words of the need bitmap (64 positions each; four words per lane).  Scan: a lane goes
+// A block owns NM_RES_WORDS words of the need bitmap (64 positions each; one word per lane).  Scan: a lane goes
 // through the set bits of its words; what the repeat probes decide (nm_probe_kstar) is stored at once, everything else
 // is queued in LDS.  Walk: the queue is worked off densely by all lanes (seed table + walk, nm_min_unique_one; list
 // mode: nm_fixed_k_one).  A full queue ends the scan early; it resumes after the walks.  On input without long
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
 // LIST: list mode with several lengths (see nm_fixed_k_segment_dev): the probes only rule positions out (repeated
 // over more than the longest length -> 0); every other open position goes through nm_fixed_k_one.
 #define NM_RES_BLOCK 256
-#define NM_RES_WORDS 1024u
+#define NM_RES_WORDS 256u           /* one word per lane: the walks at the end of a repeat (up to kmax steps each) run side by side, not in turns */
 #define NM_RES_QCAP 2048u
 template <bool BIG, bool STATS, bool LIST>
 __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t num_kmers,
@@ -476,14 +476,9 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
     const uint32_t tid = threadIdx.x;
     const uint64_t wbase = (uint64_t)blockIdx.x * NM_RES_WORDS;
     constexpr uint32_t PER = NM_RES_WORDS / NM_RES_BLOCK;
-    uint64_t mine[PER];                                    // the lane's words, loaded together
-    uint64_t any = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < PER; r++) {
-        const uint64_t wi = wbase + tid + (uint64_t)NM_RES_BLOCK * r;
-        mine[r] = wi < n_need ? need[wi] : 0ULL;
-        any |= mine[r];
-    }
+    static_assert(PER == 1, "one word of the bitmap per lane");
+    const uint64_t my_word = wbase + tid < n_need ? need[wbase + tid] : 0ULL;
+    const uint64_t any = my_word;
     if (!__syncthreads_or(any != 0)) return;
     uint32_t r = 0;                                        // words of this lane taken so far
     uint64_t bits = 0, cur = 0;                            // open bits left in the current word, its index
@@ -499,7 +494,7 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
             if (!bits) {
                 if (r >= PER) break;
                 cur = wbase + tid + (uint64_t)NM_RES_BLOCK * r;
-                bits = r == 0 ? mine[0] : (r == 1 ? mine[1] : (r == 2 ? mine[2] : mine[3]));
+                bits = my_word;
                 r++;
                 if (bits && probe) {
                     wj = probe[cur]; wj1 = probe[cur + 1];

@@ -233,8 +233,12 @@ def write_unique_counts_distributed(config) -> None:
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            backend = os.environ.get("NEWMAP_AMD_DIST_BACKEND", "nccl")   # "gloo": rehearsals with several ranks on one GPU
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
         if dist.get_backend() == "nccl":
             device = torch.device("cuda", local_rank)
 

@@ -215,6 +215,27 @@ def test_zero_count_guard_raises(tmp_path, eng):
             ix.fixed_k_segment(b"G" * 64, 64, [6])
 
 
+def test_zero_count_guard_scope(tmp_path, eng):
+    """newmap/search.py:699-722 raises when ANY probe of its bisection schedule is absent from the index.  The engine asks
+    the index about far fewer k-mers (conscious divergence 4): it raises when a k-mer it walks or a
+    window its sites look up is absent -- which a FASTA that does not match the index trips at once: a different genome,
+    and a genome with a single substituted base at 20:200 (every window over the base is absent, and with groups of at
+    most 12 positions a site looks at one of them).  It does not re-derive the reference's longest probe per position."""
+    rng = np.random.default_rng(99)
+    genome = _random_dna(rng, 300_000)
+    fa, idx = _build_index(tmp_path, b">g\n" + genome + b"\n", "guard")
+    with eng.Index(idx, 0) as ix:
+        ok, _ = ix.min_unique_segment(genome, len(genome), 20, 200)
+        assert ok[:-19].min() >= 20
+        with pytest.raises(RuntimeError, match="not found in the index"):
+            ix.min_unique_segment(_random_dna(rng, 100_000), 100_000, 20, 200)
+        for at in (1234, 150_001, 299_000):
+            snp = bytearray(genome)
+            snp[at] = ord("A") if genome[at] != ord("A") else ord("C")
+            with pytest.raises(RuntimeError, match="not found in the index"):
+                ix.min_unique_segment(bytes(snp), len(snp), 20, 200)
+
+
 def test_open_errors(tmp_path, eng):
     with pytest.raises(FileNotFoundError):
         eng.Index(tmp_path / "nope.awfmi", 0)

@@ -370,7 +370,7 @@ def pipeline_block(run: Run, k1, tallies, probe):
     searched = max(int(tallies[7]), 1)
     rank_bytes = 16 if run.info["lf_blocks"] else 32
     alg_all = tallies[5] * 8 + tallies[6] * 8 + tallies[4] * rank_bytes + probe["seed_lookups"] * 8 + probe["rank_blocks"] * rank_bytes + run.my_positions * 2
-    return {"kernels": "k_encode16 + k_sites + k_repeat_probe(_coarse) + k_resolve", "avg_segment_ms": all_ms / max(n_seg_launch, 1),
+    return {"kernels": "k_reset_status + k_sites (encodes the raw bytes itself) + k_repeat_probe(_coarse) + k_resolve", "avg_segment_ms": all_ms / max(n_seg_launch, 1),
             "segments": n_seg_launch, "algorithmic_bytes_per_segment": alg_all / max(len(run.segs), 1),
             "resolve": {"lf_steps_per_position": float(tallies[3] / searched), "rank_blocks_per_position": float(tallies[4] / searched),
                         "table_words_per_position": float(tallies[6] / searched)},

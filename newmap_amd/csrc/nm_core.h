@@ -94,6 +94,47 @@ NM_HD void nm_base_codes4(uint32_t x, uint32_t &lo, uint32_t &hi, uint32_t &amb)
     amb = top_nibble(valid ^ 0x80808080u);
 }
 
+// 16 sequence bytes -> the 16-bit pieces of the three planes (k_encode16, and the encode stage of k_sites).  `off` is the
+// byte offset of the piece in the segment; bytes at or past seq_len are ambiguous.  aligned16: seq + off is 16-byte aligned.
+NM_HD void nm_encode_piece(const uint8_t *seq, uint64_t seq_len, uint64_t off, bool aligned16, uint32_t &lo, uint32_t &hi, uint32_t &amb) {
+    uint32_t b[4] = {0, 0, 0, 0};
+    if (off + 16 <= seq_len) {
+        if (aligned16) {
+            const uint32_t *p = (const uint32_t *)__builtin_assume_aligned(seq + off, 16);
+            b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; b[3] = p[3];
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) b[j >> 2] |= (uint32_t)seq[off + j] << (8 * (j & 3));
+        }
+    } else {
+        const uint32_t valid = off < seq_len ? (uint32_t)(seq_len - off) : 0;
+        for (uint32_t j = 0; j < valid; j++) b[j >> 2] |= (uint32_t)seq[off + j] << (8 * (j & 3));
+    }
+    lo = hi = amb = 0;                                     // bytes past the end of the data are 0 in b[]: ambiguous
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        uint32_t l4, h4, a4;
+        nm_base_codes4(b[j], l4, h4, a4);
+        lo |= l4 << (4 * j);
+        hi |= h4 << (4 * j);
+        amb |= a4 << (4 * j);
+    }
+}
+
+// one whole encoded word (64 bases from byte offset 64 * word) -- the few words a block of k_sites encodes alone
+NM_HD nm_enc_word nm_encode_word(const uint8_t *seq, uint64_t seq_len, uint64_t word, bool aligned16) {
+    nm_enc_word w = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t sub = 0; sub < 4; sub++) {
+        uint32_t lo, hi, amb;
+        nm_encode_piece(seq, seq_len, word * 64 + sub * 16, aligned16, lo, hi, amb);
+        w.lo |= (uint64_t)lo << (16 * sub);
+        w.hi |= (uint64_t)hi << (16 * sub);
+        w.amb |= (uint64_t)amb << (16 * sub);
+    }
+    return w;
+}
+
 NM_HD uint32_t nm_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
 
 // number of separator positions s with a <= s < b (b - a <= 64); only reached for the rare
@@ -805,6 +846,10 @@ NM_HD uint32_t nm_quad_bits(const nm_window &w, uint32_t m, const uint64_t e[4])
 // position on its own (newmap/search.py:383-548); results are identical.
 #define NM_SITE_MAX_D 60u           /* G <= 64: a group's settled bits fit one word */
 #define NM_SITE_MAX_KMIN 252u       /* the kmin bases of a block's last position lie inside the words the block stages */
+#define NM_SITE_LA_MAX 448u         /* kmax up to here: a block stages the lookahead of its own walks too (else they go to k_resolve) */
+// words a block of BP positions stages: its own, the lookahead of the validity test (kmin <= 252) and -- for
+// kmax <= NM_SITE_LA_MAX -- of the walks it finishes itself (a walk reads the two words at p + k, k < kmax)
+#define NM_SITE_STAGE_WORDS(bp, kmax) ((bp) / 64 + ((kmax) <= NM_SITE_LA_MAX && ((kmax) + 64) / 64 + 2 > 5 ? ((kmax) + 64) / 64 + 2 : 5))
 
 // the core of the site whose 64-base window is `w` lies in unambiguous bases
 NM_HD bool nm_site_core_valid(const nm_window &w, uint32_t m) {

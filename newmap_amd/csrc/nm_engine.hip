@@ -88,25 +88,8 @@ __global__ __launch_bounds__(NM_BLOCK) void k_encode16(const uint8_t *__restrict
     nm_reset_words(status, work);
     const uint64_t t = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     if (t >= n_words * 4) return;                       // groups of 4 lanes stay whole
-    const uint64_t base = t * 16;
-    uint32_t b[4] = {0, 0, 0, 0};
-    uint32_t valid = 16;
-    if (base + 16 <= seq_len) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(seq + base);
-        b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
-    } else {
-        valid = base < seq_len ? (uint32_t)(seq_len - base) : 0;
-        for (uint32_t j = 0; j < valid; j++) b[j >> 2] |= (uint32_t)seq[base + j] << (8 * (j & 3));
-    }
-    uint32_t lo = 0, hi = 0, amb = 0;                    // bytes past the end of the data are 0 in b[]: ambiguous
-#pragma unroll
-    for (uint32_t j = 0; j < 4; j++) {
-        uint32_t l4, h4, a4;
-        nm_base_codes4(b[j], l4, h4, a4);
-        lo |= l4 << (4 * j);
-        hi |= h4 << (4 * j);
-        amb |= a4 << (4 * j);
-    }
+    uint32_t lo, hi, amb;
+    nm_encode_piece(seq, seq_len, t * 16, true, lo, hi, amb);
     const uint32_t sub = threadIdx.x & 3;
     uint64_t wlo = (uint64_t)lo << (16 * sub), whi = (uint64_t)hi << (16 * sub), wamb = (uint64_t)amb << (16 * sub);
     wlo |= __shfl_xor(wlo, 1, NM_WAVE);  whi |= __shfl_xor(whi, 1, NM_WAVE);  wamb |= __shfl_xor(wamb, 1, NM_WAVE);
@@ -274,53 +257,76 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique(nm_view ix, const nm_en
 // used), ORs the positions its entries settle into a bitmap in LDS, and the block then writes the elements four
 // at a time in position order -- kmin where settled and the kmin bases are unambiguous, else 0 -- together with the
 // bitmap of the positions that are still open (unambiguous over kmin bases, not settled): need[j] = positions
-// 64 j .. 64 j + 63 of the segment.  k_resolve finishes those.  The block's encoded words are staged in LDS once.
+// 64 j .. 64 j + 63 of the segment.  k_resolve finishes those.
+// The kernel starts from the raw sequence bytes: a block encodes its own stretch (plus lookahead) into LDS -- 16 bytes per
+// lane and turn, bit-sliced (nm_encode_piece), four lanes make one 64-base word -- and leaves its words in the segment's
+// encoded array for the kernels that may follow (repeat probes, k_resolve); there is no separate encode pass.
 #define NM_SITE_BLOCK 256
 #define NM_SITE_PER_LANE 2
 static inline uint32_t nm_site_block_positions(uint32_t d) { return NM_SITE_BLOCK * NM_SITE_PER_LANE * (d + 4); }
-static inline size_t nm_site_lds_bytes(uint32_t d) {
+static inline size_t nm_site_lds_bytes(uint32_t d, uint32_t kmax) {
     const uint32_t bp = nm_site_block_positions(d);
-    return (size_t)(bp / 64 + 5) * 24 + (size_t)bp / 8 * 2;
+    return (size_t)NM_SITE_STAGE_WORDS(bp, kmax) * sizeof(nm_enc_word) + (size_t)bp / 8 * 2;
 }
 
 #define NM_SITE_WALK_MAX 64u        /* open positions a block finishes itself (seed table + walk); more: left to the probes and k_resolve */
 #define NM_SITE_CHANCE_MAX 256u     /* open positions a block asks the second table about (one lane each); more: a long repeat, not worth the lines */
 
 template <bool BIG, bool STATS, bool LIST>
-__global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_enc_words,
+__global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8_t *__restrict__ seq, uint64_t seq_len,
+                                                         nm_enc_word *__restrict__ enc_out, uint64_t n_enc_words,
                                                          uint64_t num_kmers, uint32_t kmin, uint32_t kmax, uint32_t d, void *__restrict__ out,
                                                          int elem_bytes, uint64_t *__restrict__ status, uint64_t *__restrict__ need,
-                                                         unsigned long long *__restrict__ work, uint64_t seq_len,
+                                                         unsigned long long *__restrict__ work,
                                                          const uint32_t *__restrict__ list, uint32_t n_list) {
     extern __shared__ uint64_t s_mem[];
     __shared__ uint32_t s_open_total, s_qn;
     __shared__ uint32_t s_q[NM_SITE_CHANCE_MAX];
     const uint32_t G = d + 4, m = ix.quad_m;
     const uint32_t BP = NM_SITE_BLOCK * NM_SITE_PER_LANE * G;          // a multiple of 512
-    const uint32_t n_stage = BP / 64 + 5;
-    uint64_t *s_lo = s_mem, *s_hi = s_lo + n_stage, *s_amb = s_hi + n_stage;
-    uint32_t *s_set = reinterpret_cast<uint32_t *>(s_amb + n_stage);  // BP bits: settled by a site
+    const uint32_t n_stage = NM_SITE_STAGE_WORDS(BP, kmax);
+    nm_enc_word *s_enc = reinterpret_cast<nm_enc_word *>(s_mem);      // words w0 .. w0 + n_stage - 1 of the segment
+    uint32_t *s_set = reinterpret_cast<uint32_t *>(s_enc + n_stage);  // BP bits: settled by a site
     uint32_t *s_need = s_set + BP / 32;                               // BP bits: open
     const uint32_t tid = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * BP;
     const uint64_t w0 = base >> 6;
-    for (uint32_t i = tid; i < n_stage; i += NM_SITE_BLOCK) {
-        const uint64_t wi = w0 + i < n_enc_words ? w0 + i : n_enc_words - 1;      // (the last words are all-ambiguous padding)
-        const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(enc + wi)[0];
-        s_lo[i] = a.x; s_hi[i] = a.y;
-        s_amb[i] = enc[wi].amb;
+    // ---- phase 0: encode.  16 bytes per lane; lanes 4 j .. 4 j + 3 OR their pieces into word j
+    const bool aligned16 = (((uintptr_t)seq) & 15u) == 0;
+    for (uint32_t t = tid; t < n_stage * 4; t += NM_SITE_BLOCK) {
+        uint32_t lo, hi, amb;
+        nm_encode_piece(seq, seq_len, (w0 + (t >> 2)) * 64 + (t & 3) * 16, aligned16, lo, hi, amb);
+        const uint32_t sub = t & 3;
+        uint64_t wlo = (uint64_t)lo << (16 * sub), whi = (uint64_t)hi << (16 * sub), wamb = (uint64_t)amb << (16 * sub);
+        wlo |= __shfl_xor(wlo, 1, NM_WAVE);  whi |= __shfl_xor(whi, 1, NM_WAVE);  wamb |= __shfl_xor(wamb, 1, NM_WAVE);
+        wlo |= __shfl_xor(wlo, 2, NM_WAVE);  whi |= __shfl_xor(whi, 2, NM_WAVE);  wamb |= __shfl_xor(wamb, 2, NM_WAVE);
+        if (sub == 0) {
+            nm_enc_word w;
+            w.lo = wlo; w.hi = whi; w.amb = wamb; w.pad = 0;
+            s_enc[t >> 2] = w;
+        }
     }
     for (uint32_t i = tid; i < BP / 16; i += NM_SITE_BLOCK) s_set[i] = 0;          // both bitmaps
     if (tid == 0) { s_open_total = 0; s_qn = 0; }
     __syncthreads();
+    // the block's own words go to the segment's encoded array; the last block also writes what follows its stretch
+    // (lookahead and padding words of the segment)
+    if (enc_out) {
+        const uint64_t own_end = w0 + BP / 64 < n_enc_words ? w0 + BP / 64 : n_enc_words;
+        const uint64_t end = blockIdx.x + 1 == gridDim.x ? n_enc_words : own_end;
+        for (uint64_t wi = w0 + tid; wi < end; wi += NM_SITE_BLOCK)
+            enc_out[wi] = wi - w0 < n_stage ? s_enc[wi - w0] : nm_encode_word(seq, seq_len, wi, aligned16);
+    }
     auto lds_window = [&](uint32_t rel) -> nm_window {
         const uint32_t wi = rel >> 6, sh = rel & 63;
+        const nm_enc_word a = s_enc[wi];
         nm_window w;
-        w.lo = s_lo[wi]; w.hi = s_hi[wi]; w.amb = s_amb[wi];
+        w.lo = a.lo; w.hi = a.hi; w.amb = a.amb;
         if (sh) {
-            w.lo = (w.lo >> sh) | (s_lo[wi + 1] << (64 - sh));
-            w.hi = (w.hi >> sh) | (s_hi[wi + 1] << (64 - sh));
-            w.amb = (w.amb >> sh) | (s_amb[wi + 1] << (64 - sh));
+            const nm_enc_word b = s_enc[wi + 1];
+            w.lo = (w.lo >> sh) | (b.lo << (64 - sh));
+            w.hi = (w.hi >> sh) | (b.hi << (64 - sh));
+            w.amb = (w.amb >> sh) | (b.amb << (64 - sh));
         }
         return w;
     };
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
     __syncthreads();
     // ---- phase 2: elements and open bits, four positions per lane and turn, in position order
     uint32_t n_amb = 0, n_searched = 0, n_open = 0;
-    auto amb_word = [&](uint64_t i) -> uint64_t { return s_amb[i]; };
+    auto amb_word = [&](uint64_t i) -> uint64_t { return s_enc[i].amb; };
     const bool wide = elem_bytes == 1 && (((uintptr_t)out) & 3u) == 0;
     for (uint32_t j = tid; j < BP / 4; j += NM_SITE_BLOCK) {
         const uint32_t rel = 4 * j;
@@ -414,16 +420,18 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const nm_en
     const uint32_t open_total = s_open_total;
     bool any_err = false;
     uint64_t err_pos = ~0ULL;
-    const bool self = open_total && open_total <= NM_SITE_WALK_MAX && !(ix.seed_policy & 0x100u);
+    // (the walks read the block's staged words -- positions relative to its first base -- so the lookahead of the
+    // longest walk must have been staged: kmax <= NM_SITE_LA_MAX)
+    const bool self = open_total && open_total <= NM_SITE_WALK_MAX && kmax <= NM_SITE_LA_MAX && !(ix.seed_policy & 0x100u);
     if (self) {
         gather_open();
         if (tid < s_qn) {
-            const uint64_t p = base + s_q[tid];
+            const uint64_t rel = s_q[tid];
             bool amb0 = false, err = false;
-            const uint32_t v = LIST ? nm_fixed_k_one<BIG, true>(ix, enc, p, seq_len, list, n_list, amb0, err, t)
-                                    : nm_min_unique_one<BIG, true>(ix, enc, p, kmin, kmax, amb0, err, t);
-            if (err) { any_err = true; err_pos = p; }
-            nm_store(out, elem_bytes, p, v);
+            const uint32_t v = LIST ? nm_fixed_k_one<BIG, true>(ix, s_enc, rel, seq_len - base, list, n_list, amb0, err, t)
+                                    : nm_min_unique_one<BIG, true>(ix, s_enc, rel, kmin, kmax, amb0, err, t);
+            if (err) { any_err = true; err_pos = base + rel; }
+            nm_store(out, elem_bytes, base + rel, v);
         }
     } else if (open_total && tid == 0) {
         atomicOr(&work[NM_WORK_OPEN], 1ULL);
@@ -1168,12 +1176,20 @@ extern "C" int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_
 // -------------------------------------------------------------------------- launch helpers --
 
 // d_status != nullptr: the pass also resets the launch's status words and the handle's counters
-static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStream_t st, uint64_t *d_status = nullptr) {
-    unsigned long long *work = d_status ? (unsigned long long *)ix->work.p : nullptr;
+// room for the encoded words of a segment (filled by the encode pass or by k_sites)
+static int nm_prepare_enc(nm_index *ix, uint64_t seq_len) {
     const uint64_t n_words = seq_len / 64 + 3;
     int rc = nm_grow(ix->enc, n_words * sizeof(nm_enc_word));
     if (rc != NM_OK) return rc;
     ix->enc_words = n_words;
+    return NM_OK;
+}
+
+static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStream_t st, uint64_t *d_status = nullptr) {
+    unsigned long long *work = d_status ? (unsigned long long *)ix->work.p : nullptr;
+    int rc = nm_prepare_enc(ix, seq_len);
+    if (rc != NM_OK) return rc;
+    const uint64_t n_words = ix->enc_words;
     if (((uintptr_t)d_seq & 15) == 0)
         hipLaunchKernelGGL(k_encode16, dim3(nm_grid(n_words * 4)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
                            (nm_enc_word *)ix->enc.p, n_words, d_status, work);
@@ -1268,12 +1284,14 @@ static void nm_pick_site_tables(nm_index *ix, nm_view &view, uint32_t kmin) {
 // k_sites -> repeat probes where the bitmap is dense -> k_resolve, over positions [0, n).  Range mode: kmin .. kmax.
 // List mode (d_list != nullptr): kmin = the first listed length, kmax = the longest.
 template <bool BIG>
-static int launch_sites(nm_index *ix, const nm_view &view_in, uint64_t n, uint32_t kmin, uint32_t kmax, void *d_out, int elem_bytes,
-                        uint64_t *d_status, hipStream_t st, uint64_t seq_len = 0, const uint32_t *d_list = nullptr, uint32_t n_list = 0) {
+static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq, uint64_t seq_len, uint64_t n, uint32_t kmin, uint32_t kmax,
+                        void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st, bool status_ready,
+                        const uint32_t *d_list = nullptr, uint32_t n_list = 0) {
+    int rc = nm_prepare_enc(ix, seq_len);
+    if (rc != NM_OK) return rc;
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
     const uint64_t n_need = (n + 63) / 64;
-    int rc = nm_grow(ix->need, (n_need + 1) * sizeof(uint64_t));
-    if (rc != NM_OK) return rc;
+    if ((rc = nm_grow(ix->need, (n_need + 1) * sizeof(uint64_t))) != NM_OK) return rc;
     uint64_t *need = (uint64_t *)ix->need.p;
     unsigned long long *work = (unsigned long long *)ix->work.p;
     nm_view view = view_in;
@@ -1283,7 +1301,7 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, uint64_t n, uint32
     if (d > ix->site_d_cap) d = ix->site_d_cap;
     const uint32_t bp = nm_site_block_positions(d);
     const dim3 sgrid((unsigned)((n + bp - 1) / bp)), sblock(NM_SITE_BLOCK);
-    const size_t lds = nm_site_lds_bytes(d);
+    const size_t lds = nm_site_lds_bytes(d, kmax);
     ix->last_kernel = 5;
     // Input that has shown long repeats before (the latch the fine probes set): the probes are walks of up to kmax + 511
     // dependent steps -- bound by latency, not by lines -- so they run on a second stream BESIDE k_sites (every stride:
@@ -1292,16 +1310,20 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, uint64_t n, uint32
     const uint32_t *probe = nullptr;
     const bool repeats_met = ix->h_repeats_seen && *(volatile uint32_t *)ix->h_repeats_seen != 0;
     const bool beside = ix->repeat_probes && repeats_met && ix->side && ix->probes_beside && n >= (1u << 16);
+    nm_enc_word *enc_out = (nm_enc_word *)ix->enc.p;      // k_sites leaves the encoded words for the probes and k_resolve
     if (beside) {
+        // (the probes start before k_sites has encoded anything: this launch takes the separate encode pass)
+        if ((rc = nm_encode(ix, d_seq, seq_len, st, status_ready ? nullptr : d_status)) != NM_OK) return rc;
+        enc_out = nullptr;
         HIP_TRY(hipEventRecord(ix->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(ix->side, ix->ev_fork, 0));
         if ((rc = nm_launch_probes<BIG>(ix, view, n, kmax, ix->side, &probe, nullptr)) != NM_OK) return rc;
         HIP_TRY(hipEventRecord(ix->ev_join, ix->side));
-    }
+    } else if (!status_ready && (rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
     {
         nm_timed timed(ix, st);
-#define NM_LAUNCH_SITES(STATS_, LIST_) hipLaunchKernelGGL((k_sites<BIG, STATS_, LIST_>), sgrid, sblock, lds, st, view, enc, ix->enc_words, n, kmin, kmax, d, d_out, \
-                                                          elem_bytes, d_status, need, work, seq_len, d_list, n_list)
+#define NM_LAUNCH_SITES(STATS_, LIST_) hipLaunchKernelGGL((k_sites<BIG, STATS_, LIST_>), sgrid, sblock, lds, st, view, (const uint8_t *)d_seq, seq_len, \
+                                                          enc_out, ix->enc_words, n, kmin, kmax, d, d_out, elem_bytes, d_status, need, work, d_list, n_list)
         if (d_list) { if (ix->count_steps) NM_LAUNCH_SITES(true, true); else NM_LAUNCH_SITES(false, true); }
         else        { if (ix->count_steps) NM_LAUNCH_SITES(true, false); else NM_LAUNCH_SITES(false, false); }
 #undef NM_LAUNCH_SITES
@@ -1317,16 +1339,21 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, uint64_t n, uint32
     return NM_OK;
 }
 
+// range mode over positions [0, num_kmers) of a segment: the sites, or (--norc, kmin outside the tables' windows, A/B)
+// the encode pass + one lane per position.  status_ready: the caller has reset the status words already.
 template <bool BIG, bool RC>
-static int launch_min_unique(nm_index *ix, const nm_view &view, uint64_t num_kmers, uint32_t kmin, uint32_t kmax, void *d_out,
-                              int elem_bytes, uint64_t *d_status, hipStream_t st) {
-    if (RC && nm_sites_apply(ix, view, kmin)) return launch_sites<BIG>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st);
+static int launch_min_unique(nm_index *ix, const nm_view &view, const void *d_seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin,
+                             uint32_t kmax, void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st, bool status_ready) {
+    if (RC && nm_sites_apply(ix, view, kmin))
+        return launch_sites<BIG>(ix, view, d_seq, seq_len, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st, status_ready);
+    int rc = nm_encode(ix, d_seq, seq_len, st, status_ready ? nullptr : d_status);
+    if (rc != NM_OK) return rc;
     const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
     // one lane per position; on both strands the repeat probes run first (every stride: there is no bitmap to gate them)
     const uint32_t *settled = nullptr;
     if (RC && ix->repeat_probes) {
-        const int rc = nm_launch_probes<BIG>(ix, view, num_kmers, kmax, st, &settled);
+        rc = nm_launch_probes<BIG>(ix, view, num_kmers, kmax, st, &settled);
         if (rc != NM_OK) return rc;
     }
     nm_timed timed(ix, st);
@@ -1351,11 +1378,10 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
     nm_view view;
     if ((rc = nm_view_for(ix, kmin, &view)) != NM_OK) return rc;
     nm_timed whole(ix, st, 1);
-    if ((rc = nm_encode(ix, d_seq, seq_len, st, d_status)) != NM_OK) return rc;
-    if (ix->big) rc = use_revcomp ? launch_min_unique<true, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st)
-                                  : launch_min_unique<true, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st);
-    else         rc = use_revcomp ? launch_min_unique<false, true>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st)
-                                  : launch_min_unique<false, false>(ix, view, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st);
+    if (ix->big) rc = use_revcomp ? launch_min_unique<true, true>(ix, view, d_seq, seq_len, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st, false)
+                                  : launch_min_unique<true, false>(ix, view, d_seq, seq_len, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st, false);
+    else         rc = use_revcomp ? launch_min_unique<false, true>(ix, view, d_seq, seq_len, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st, false)
+                                  : launch_min_unique<false, false>(ix, view, d_seq, seq_len, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st, false);
     if (rc != NM_OK) return rc;
     HIP_TRY(hipGetLastError());
     return NM_OK;
@@ -1391,7 +1417,7 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     nm_timed whole(ix, st, 1);
     if ((rc = nm_grow(ix->ks, (uint64_t)nk * sizeof(uint32_t))) != NM_OK) return rc;
     HIP_TRY(hipMemcpyAsync(ix->ks.p, ks, (uint64_t)nk * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
+    bool encoded = false;                                   // the range / sites launches below leave the segment's encoded words behind
     const uint32_t *d_ks = (const uint32_t *)ix->ks.p;
     uint32_t kshort = ks[0];
     for (uint32_t i = 1; i < nk; i++) if (ks[i] < kshort) kshort = ks[i];
@@ -1405,10 +1431,11 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     if (nk == 1 && use_revcomp && ix->list_via_range && view.quad && seq_len >= ks[0]) {
         const uint64_t head = num_kmers < seq_len - ks[0] + 1 ? num_kmers : seq_len - ks[0] + 1;
         if (head) {
-            rc = ix->big ? launch_min_unique<true, true>(ix, view, head, ks[0], ks[0], d_out, elem_bytes, d_status, st)
-                         : launch_min_unique<false, true>(ix, view, head, ks[0], ks[0], d_out, elem_bytes, d_status, st);
+            rc = ix->big ? launch_min_unique<true, true>(ix, view, d_seq, seq_len, head, ks[0], ks[0], d_out, elem_bytes, d_status, st, true)
+                         : launch_min_unique<false, true>(ix, view, d_seq, seq_len, head, ks[0], ks[0], d_out, elem_bytes, d_status, st, true);
             if (rc != NM_OK) return rc;
             first = head;
+            encoded = true;
         }
     }
     // several lengths, the first one at least as long as a quad table's window: the sites with the FIRST length in the
@@ -1417,13 +1444,15 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     if (nk > 1 && use_revcomp && ix->list_via_range && nm_sites_apply(ix, view, ks[0]) && seq_len >= kmax) {
         const uint64_t head = num_kmers < seq_len - kmax + 1 ? num_kmers : seq_len - kmax + 1;
         if (head) {
-            rc = ix->big ? launch_sites<true>(ix, view, head, ks[0], kmax, d_out, elem_bytes, d_status, st, seq_len, d_ks, nk)
-                         : launch_sites<false>(ix, view, head, ks[0], kmax, d_out, elem_bytes, d_status, st, seq_len, d_ks, nk);
+            rc = ix->big ? launch_sites<true>(ix, view, d_seq, seq_len, head, ks[0], kmax, d_out, elem_bytes, d_status, st, true, d_ks, nk)
+                         : launch_sites<false>(ix, view, d_seq, seq_len, head, ks[0], kmax, d_out, elem_bytes, d_status, st, true, d_ks, nk);
             if (rc != NM_OK) return rc;
             first = head;
+            encoded = true;
         }
     }
     if (first < num_kmers) {
+        if (!encoded && (rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
         if (ix->big) { if (use_revcomp) launch_fixed_k<true, true>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<true, false>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
         else         { if (use_revcomp) launch_fixed_k<false, true>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<false, false>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
     }

@@ -298,18 +298,31 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
     };
     uint32_t d = kmin - (m + NM_QUAD_EXT);
     if (d > d_cap) d = d_cap;
-    const uint32_t G = d + 4, BLOCK = 256, PER_LANE = 2, BP = BLOCK * PER_LANE * G, n_stage = BP / 64 + 5;
+    const uint32_t G = d + 4, BLOCK = 256, PER_LANE = 2, BP = BLOCK * PER_LANE * G, n_stage = NM_SITE_STAGE_WORDS(BP, kmax);
     const uint64_t n_need = (num_kmers + 63) / 64;
     std::vector<uint64_t> need(n_need + 1, 0);
     bool any_open = false;                                  // work[NM_WORK_OPEN]
+    std::vector<nm_enc_word> enc_out(n_enc_words, nm_enc_word{~0ULL, ~0ULL, 0, ~0ULL});   // what k_sites leaves for the later kernels
     // ---- k_sites
-    for (uint64_t blk = 0; blk * BP < num_kmers; blk++) {
+    const uint64_t n_blocks = (num_kmers + BP - 1) / BP;
+    for (uint64_t blk = 0; blk < n_blocks; blk++) {
         const uint64_t base = blk * BP, w0 = base >> 6;
-        std::vector<uint64_t> s_lo(n_stage), s_hi(n_stage), s_amb(n_stage);
-        for (uint32_t i = 0; i < n_stage; i++) {
-            const uint64_t wi = w0 + i < n_enc_words ? w0 + i : n_enc_words - 1;
-            s_lo[i] = enc[wi].lo; s_hi[i] = enc[wi].hi; s_amb[i] = enc[wi].amb;
+        // phase 0: the block encodes its own stretch + lookahead from the raw bytes, 16 bytes per lane
+        std::vector<nm_enc_word> s_enc(n_stage, nm_enc_word{0, 0, 0, 0});
+        for (uint32_t t = 0; t < n_stage * 4; t++) {
+            uint32_t lo, hi, amb;
+            nm_encode_piece(seq, seq_len, (w0 + (t >> 2)) * 64 + (t & 3) * 16, (t & 1) != 0 && (((uintptr_t)seq) & 15u) == 0, lo, hi, amb);   // (both load forms)
+            s_enc[t >> 2].lo |= (uint64_t)lo << (16 * (t & 3));
+            s_enc[t >> 2].hi |= (uint64_t)hi << (16 * (t & 3));
+            s_enc[t >> 2].amb |= (uint64_t)amb << (16 * (t & 3));
         }
+        {
+            const uint64_t own_end = w0 + BP / 64 < n_enc_words ? w0 + BP / 64 : n_enc_words;
+            const uint64_t end = blk + 1 == n_blocks ? n_enc_words : own_end;
+            for (uint64_t wi = w0; wi < end; wi++) enc_out[wi] = wi - w0 < n_stage ? s_enc[wi - w0] : nm_encode_word(seq, seq_len, wi, false);
+        }
+        std::vector<uint64_t> s_lo(n_stage), s_hi(n_stage), s_amb(n_stage);
+        for (uint32_t i = 0; i < n_stage; i++) { s_lo[i] = s_enc[i].lo; s_hi[i] = s_enc[i].hi; s_amb[i] = s_enc[i].amb; }
         std::vector<uint32_t> s_set(BP / 32 + 2, 0), s_need(BP / 32, 0);
         auto lds_window = [&](uint32_t rel) {
             const uint32_t wi = rel >> 6, sh = rel & 63;
@@ -361,21 +374,21 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
                     if (nm_second_chance(v, lds_window(rel), kmin)) { store(base + rel, kmin); s_need[i] &= ~(1u << (rel & 31)); open_total--; counters[4]++; }
                 }
         // a few open positions: the block finishes them itself; many: they stay for the probes and k_resolve
-        const bool self = open_total && open_total <= walk_max;
+        const bool self = open_total && open_total <= walk_max && kmax <= NM_SITE_LA_MAX;
         if (self) {
             for (uint32_t i = 0; i < BP / 32; i++) {
                 uint32_t bits = s_need[i];
                 s_need[i] = 0;
                 for (; bits; bits &= bits - 1) {
-                    const uint64_t p = base + i * 32 + (uint32_t)__builtin_ctz(bits);
+                    const uint64_t rel = i * 32 + (uint32_t)__builtin_ctz(bits), p = base + rel;
                     counters[1]++;
                     bool amb0 = false, err = false;
                     nm_tally t = {0, 0, 0, 0};
-                    uint32_t val;
-                    if (list) val = ix->big ? nm_fixed_k_one<true, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t)
-                                            : nm_fixed_k_one<false, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t);
-                    else      val = ix->big ? nm_min_unique_one<true, true>(v, enc.data(), p, kmin, kmax, amb0, err, t)
-                                            : nm_min_unique_one<false, true>(v, enc.data(), p, kmin, kmax, amb0, err, t);
+                    uint32_t val;                          // (on the block's staged words, positions relative to its first base)
+                    if (list) val = ix->big ? nm_fixed_k_one<true, true>(v, s_enc.data(), rel, seq_len - base, list, n_list, amb0, err, t)
+                                            : nm_fixed_k_one<false, true>(v, s_enc.data(), rel, seq_len - base, list, n_list, amb0, err, t);
+                    else      val = ix->big ? nm_min_unique_one<true, true>(v, s_enc.data(), rel, kmin, kmax, amb0, err, t)
+                                            : nm_min_unique_one<false, true>(v, s_enc.data(), rel, kmin, kmax, amb0, err, t);
                     if (err) { status[1] = 1; if (p < status[2]) status[2] = p; }
                     status[3] += t.steps; status[4] += t.blocks; status[6] += t.seeds;
                     store(p, val);
@@ -385,6 +398,8 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
         for (uint32_t i = 0; i < BP / 64; i++)
             if (base + 64ull * i < num_kmers) need[w0 + i] = (uint64_t)s_need[2 * i] | ((uint64_t)s_need[2 * i + 1] << 32);
     }
+    for (uint64_t i = 0; i < n_enc_words; i++)            // what k_sites left == the encode pass
+        if (enc_out[i].lo != enc[i].lo || enc_out[i].hi != enc[i].hi || enc_out[i].amb != enc[i].amb) return -2;
     if (need_out) for (uint64_t i = 0; i < n_need; i++) need_out[i] = need[i];
     // ---- repeat probes where the bitmap is dense (k_repeat_probe_coarse, k_repeat_probe)
     std::vector<uint32_t> words;

@@ -159,16 +159,16 @@ template <bool BIG, bool STATS>
 __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe_coarse(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_coarse,
                                                                   uint32_t kmax, uint32_t *__restrict__ coarse,
                                                                   unsigned long long *__restrict__ probe_tally,
-                                                                  const uint64_t *__restrict__ need, uint64_t n_need) {
+                                                                  const uint64_t *__restrict__ need, uint64_t n_need, uint32_t cstride) {
     if (need && probe_tally[NM_WORK_OPEN - 1] == 0) return;          // (after k_sites: nothing was left open, k_resolve returns at once too)
     const uint64_t c = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     nm_tally t = {0, 0, 0, 0};
     if (c < n_coarse) {
         uint32_t settled = 0, exact;
         // after k_sites (need != nullptr): only where the first fine stride is mostly open -- the start of a long repeat
-        const uint64_t j0 = c * (NM_COARSE_STRIDE / NM_PROBE_STRIDE);
+        const uint64_t j0 = c * (cstride / NM_PROBE_STRIDE);
         if (!need || (j0 < n_need && nm_popc64(need[j0]) >= NM_PROBE_GATE_BITS))
-            nm_repeat_probe_ex<BIG>(ix, enc, c * NM_COARSE_STRIDE, kmax, NM_COARSE_STRIDE, t, settled, exact);
+            nm_repeat_probe_ex<BIG>(ix, enc, c * cstride, kmax, cstride, t, settled, exact);
         coarse[c] = settled;
     }
     if (STATS) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe(nm_view ix, const nm_
                                                            unsigned long long *__restrict__ probe_tally,
                                                            const uint32_t *__restrict__ coarse, volatile uint32_t *repeats_seen,
                                                            uint32_t *__restrict__ seen_latch,
-                                                           const uint64_t *__restrict__ need, uint64_t n_need) {
+                                                           const uint64_t *__restrict__ need, uint64_t n_need, uint32_t cstride) {
     if (need && probe_tally[NM_WORK_OPEN - 1] == 0) return;          // (after k_sites: nothing was left open, k_resolve returns at once too)
     const uint64_t j = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
     nm_tally t = {0, 0, 0, 0};
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe(nm_view ix, const nm_
             const uint64_t P = j * NM_PROBE_STRIDE;
             // a stride the coarse probe settles completely: the word this probe would find after kmax + 63 steps
             if (need && !nm_probe_gate(need, j, n_need)) word = 0;      // (after k_sites: nothing open here, nothing to tell)
-            else if (coarse && nm_coarse_covers(coarse[P / NM_COARSE_STRIDE], (uint32_t)(P % NM_COARSE_STRIDE), NM_PROBE_STRIDE)) word = NM_PROBE_STRIDE;
+            else if (coarse && nm_coarse_covers(coarse[P / cstride], (uint32_t)(P % cstride), NM_PROBE_STRIDE)) word = NM_PROBE_STRIDE;
             else word = nm_repeat_probe<BIG>(ix, enc, P, kmax, NM_PROBE_STRIDE, t);
         }
         probe[j] = word;
@@ -674,6 +674,7 @@ struct nm_index {
     // scratch owned by the handle (grown on demand)
     nm_buffer enc, seq, out, status, ks, starts, lens, work, settled, coarse, need;
     uint64_t coarse_min = 32ull << 20;    // launches of at least this many positions also run the coarse probes (NEWMAP_AMD_COARSE_MIN) ...
+    uint32_t coarse_stride = NM_COARSE_STRIDE;   // positions per coarse probe (NEWMAP_AMD_COARSE_STRIDE: 128, 256, 512)
     int coarse_mode = 1;                  // ... 1: once an earlier launch has met long repeats, 2: always, 0: never (NEWMAP_AMD_COARSE)
     uint32_t *h_repeats_seen = nullptr;   // pinned word the fine probes set; d_repeats_seen = its device address
     uint32_t *d_repeats_seen = nullptr;
@@ -1037,6 +1038,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     if (const char *cm = getenv("NEWMAP_AMD_COARSE_MIN")) ix->coarse_min = strtoull(cm, nullptr, 10);
     if (const char *cm = getenv("NEWMAP_AMD_COARSE")) ix->coarse_mode = atoi(cm);
+    if (const char *cs = getenv("NEWMAP_AMD_COARSE_STRIDE")) { const int v = atoi(cs); if (v == 128 || v == 256 || v == 512) ix->coarse_stride = (uint32_t)v; }
     if (const char *pb = getenv("NEWMAP_AMD_PROBES_BESIDE")) ix->probes_beside = pb[0] != '0';
     if (const char *sd = getenv("NEWMAP_AMD_SITE_D")) { ix->site_d_cap = (uint32_t)atoi(sd); if (ix->site_d_cap > NM_SITE_MAX_D) ix->site_d_cap = NM_SITE_MAX_D; }
     if (hipHostMalloc((void **)&ix->h_repeats_seen, 64, hipHostMallocMapped) == hipSuccess) {
@@ -1227,14 +1229,15 @@ static int nm_launch_probes(nm_index *ix, const nm_view &view, uint64_t n, uint3
     const uint32_t *coarse = nullptr;
     const bool repeats_met = ix->h_repeats_seen && *(volatile uint32_t *)ix->h_repeats_seen != 0;
     if (n >= ix->coarse_min && (ix->coarse_mode == 2 || (ix->coarse_mode == 1 && repeats_met))) {
-        const uint64_t n_coarse = (n + NM_COARSE_STRIDE - 1) / NM_COARSE_STRIDE;
+        const uint32_t cstride = ix->coarse_stride;
+        const uint64_t n_coarse = (n + cstride - 1) / cstride;
         if ((rc = nm_grow(ix->coarse, n_coarse * sizeof(uint32_t))) != NM_OK) return rc;
-        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally, need, n_probes);
-        else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally, need, n_probes);
+        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally, need, n_probes, cstride);
+        else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally, need, n_probes, cstride);
         coarse = (const uint32_t *)ix->coarse.p;
     }
-    if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes);
-    else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes);
+    if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
+    else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
     *words = (const uint32_t *)ix->settled.p;
     return NM_OK;
 }

@@ -109,20 +109,8 @@ def get_num_kmers(sequence_segment: SequenceSegment, max_kmer_length: int) -> in
     return len(sequence_segment.data) - (max_kmer_length - 1)
 
 
-def _single_index(config: SearchConfig) -> Index:
-    if len(config.fmindex_filepaths) != 1:
-        raise NotImplementedError(
-            "searching several index files at once (newmap/search.py:656-697) is outside the "
-            "accelerated path of this build: pass exactly one index")
+def _index(config: SearchConfig) -> Index:
     return cached_index(config.fmindex_filepaths[0], config.device)
-
-
-def _first_segment(segments: Sequence[SequenceSegment]) -> SequenceSegment:
-    if len(segments) != 1:
-        raise NotImplementedError(
-            "searching several FASTA files in lock-step (newmap/search.py:251-265) is outside the "
-            "accelerated path of this build: pass exactly one FASTA file")
-    return segments[0]
 
 
 def binary_search(config: SearchConfig, sequence_segments: Sequence[SequenceSegment], min_kmer_length: int,
@@ -134,8 +122,8 @@ def binary_search(config: SearchConfig, sequence_segments: Sequence[SequenceSegm
         return search_segment_multi(indexes, [s.data for s in sequence_segments],
                                     get_num_kmers(sequence_segments[0], max_kmer_length),
                                     [min_kmer_length, max_kmer_length], True, config.use_reverse_complement, data_type)
-    seg = _first_segment(sequence_segments)
-    ix = _single_index(config)
+    seg = sequence_segments[0]
+    ix = _index(config)
     num_kmers = get_num_kmers(seg, max_kmer_length)
     unique, n_amb = ix.min_unique_segment(seg.data, num_kmers, min_kmer_length, max_kmer_length,
                                           config.use_reverse_complement, data_type,
@@ -151,8 +139,8 @@ def linear_search(config: SearchConfig, sequence_segments: Sequence[SequenceSegm
         indexes = [cached_index(p, config.device) for p in config.fmindex_filepaths]
         return search_segment_multi(indexes, [s.data for s in sequence_segments], num_kmers, config.kmer_lengths,
                                     False, config.use_reverse_complement, data_type)
-    seg = _first_segment(sequence_segments)
-    ix = _single_index(config)
+    seg = sequence_segments[0]
+    ix = _index(config)
     unique, n_amb = ix.fixed_k_segment(seg.data, num_kmers, config.kmer_lengths, config.use_reverse_complement,
                                        data_type)
     config.log(f"Skipping {n_amb} ambiguous positions")
@@ -232,7 +220,7 @@ def _nothing_processed(config: SearchConfig):
 def _write_unique_counts_native(config: SearchConfig):
     max_kmer_length, min_kmer_length = max(config.kmer_lengths), min(config.kmer_lengths)
     _check_range(config, min_kmer_length, max_kmer_length)
-    index = _single_index(config)
+    index = _index(config)
     running = _Summary(min_kmer_length, max_kmer_length)
 
     def on_record(rec_id: bytes, s: dict):
@@ -301,7 +289,7 @@ def _write_unique_counts_python(config: SearchConfig):
     min_kmer_length = min(config.kmer_lengths)
     data_type, suffix = output_type(max_kmer_length)
     _check_range(config, min_kmer_length, max_kmer_length)
-    index = _single_index(config)
+    index = _index(config)
 
     lookahead = max_kmer_length - 1                                   # :229
     requested = config.kmer_batch_size + lookahead                    # :235

@@ -561,7 +561,8 @@ def main():
         t_ns = time.time()
         nfa, nidx, nprep = prepare_index(args, ns, rank, barrier)
         nranges = parallel.interleaved_ranges(ns.total, world, 64 << 20)[rank] if world > 1 else [(0, ns.total)]
-        nunits = parallel.units_for_ranges(ns.lengths, nranges, args.batch, ns.krange[1])
+        # (one launch per record and range: the largest record has 249 M positions)
+        nunits = parallel.units_for_ranges(ns.lengths, nranges, max(args.batch, 1 << 28), ns.krange[1])
         nrun = Run(args, ns, nidx, nunits, rank, world, dev, barrier, dist, rehearse, args.seed_length)
         for i in range(len(ns.records)):           # the device holds the units now
             if ns.lengths[i] > 150_000_000:

@@ -145,7 +145,7 @@ enum {
     NM_OPT_TIMING = 3,
     NM_OPT_KERNEL = 4,             /* range-mode kernel: 0 automatic (default), 1 one lane per position (k_min_unique),
                                       5 the sites (k_sites + k_resolve: one 128-byte quad-table line per group of
-                                      kmin - core length + 1 positions; needs core length + 3 <= kmin <= 252) */
+                                      kmin - core length + 1 positions; needs core length + 4 <= kmin <= 252) */
     NM_OPT_FORCE_BIG = 6,          /* tests: use the kernels for indexes beyond 2^31 positions */
     NM_OPT_SEED_POLICY = 7,        /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */
     NM_OPT_LF_BLOCKS = 9,          /* LF steps on the 16-byte LF entries (default when built) or the packed rank blocks */
@@ -156,8 +156,8 @@ enum {
                                       default 1, 0 = always the list kernel, for A/B */
     NM_OPT_SITE_TABLE = 13,        /* measurement / tests: which quad table the sites read: 0 pick per launch (default), 1 the one
                                       with long cores, 2 the one with short cores (the other backs it up in k_resolve) */
-    NM_OPT_SITE_D = 12             /* measurement / tests: cap (0..60, default 60) on d = kmin - (core length + 3); a site
-                                      settles a group of d + 4 positions */
+    NM_OPT_SITE_D = 12             /* measurement / tests: cap (0..59, default 59) on d = kmin - (core length + 4); a site
+                                      settles a group of d + 5 positions */
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 

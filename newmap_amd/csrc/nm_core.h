@@ -49,8 +49,8 @@ struct nm_view {                // the index as the kernels see it
     uint32_t n_super;
     uint32_t seed_policy;       // experiment knob: cache policy of the seed-table load (0 = default)
     const nm_lf_entry *lfb;     // LF blocks: one 16-byte load per LF step (nullptr = use the packed rank blocks)
-    const uint64_t *quad;       // quad table: 4^quad_m entries of 4 x u64 (nullptr = not built), see nm_quad_build_one
-    uint32_t quad_m;            // its core length; it answers windows of quad_m + 3 bases
+    const uint64_t *quad;       // quad table: 4^quad_m entries of 16 x u64 (nullptr = not built), see nm_quad_build_one
+    uint32_t quad_m;            // its core length; it answers windows of quad_m + 4 bases
     const uint64_t *quad2;      // a second quad table with longer cores (nullptr = none): k_resolve's second chance
     uint32_t quad2_m;
 };
@@ -383,15 +383,15 @@ NM_HD uint32_t nm_min_unique_one(const nm_view &ix, const nm_enc_word *enc, uint
 // it (0 = not known).  Never changes a result -- positions the probes do not decide take the ordinary path.
 #define NM_PROBE_OPEN 0xFFFFFFFFu
 
-// quad-table bit of the FIRST position of a group (word 0 of the entry of the core three bases on, see the
-// quad table below): true when the (quad_m + 3)-mer at the start of `w` occurs exactly once
+// quad-table bit of the window that STARTS at the beginning of `w` (window 0 of the entry of the core four bases on,
+// see the quad table below): true when that (quad_m + 4)-mer occurs exactly once
 NM_HD bool nm_quad_once_first(const nm_view &ix, const nm_window &w, uint32_t kmax) {
-    const uint32_t m = ix.quad_m, len = m + 3;
+    const uint32_t m = ix.quad_m, len = m + 4;
     if (len > kmax || (w.amb & ((1ULL << len) - 1ULL)) != 0) return false;
     const uint64_t mask = (1ULL << m) - 1ULL;
-    const uint64_t slot = ((w.lo >> 3) & mask) | (((w.hi >> 3) & mask) << m);
-    const uint32_t i0 = nm_window_code(w, 0) | (nm_window_code(w, 1) << 2) | (nm_window_code(w, 2) << 4);
-    return ((ix.quad[slot * 4] >> i0) & 1ULL) != 0;
+    const uint64_t slot = ((w.lo >> 4) & mask) | (((w.hi >> 4) & mask) << m);
+    const uint32_t b0 = nm_window_code(w, 0) | (nm_window_code(w, 1) << 2) | (nm_window_code(w, 2) << 4) | (nm_window_code(w, 3) << 6);
+    return ((ix.quad[slot * 16 + (b0 >> 6)] >> (b0 & 63u)) & 1ULL) != 0;
 }
 
 // (settled <= stride and exact are returned separately: the coarse probes use strides that do not fit the word)
@@ -722,22 +722,26 @@ NM_HD uint64_t nm_seed_entry_from_parent(const nm_view &ix, uint64_t parent_entr
     return cnt ? ((lo & NM_SEED_LO_MASK) | (cnt << NM_SEED_LO_BITS)) : 0;
 }
 
-// ---- quad table: ONE 32-byte entry settles FOUR neighbouring positions ---------------------------
-// Range mode only asks "which is the least length with one occurrence", and when the window of
-// w = m + 3 bases at a position already occurs once and w <= kmin the answer is kmin -- one BIT per
-// w-mer is enough.  Positions p .. p+3 share the m-mer core Y = S[p+3 .. p+3+m): the window of
-// position p+i is  L.Y.R  with the 3-i bases L before the core and the i bases R after it, so the
-// 4 x 4^3 = 256 bits "L.Y.R occurs exactly once (both strands)" of one core fill one 32-byte entry
-// and a lane that owns four positions reads one 128-byte line for all of them (a plain seed
-// table needs four).  Word i of an entry belongs to position p+i; bit index:
-//      i = 0:  l0 | l1<<2 | l2<<4        i = 1:  l0 | l1<<2 | r0<<4
-//      i = 2:  r0 | r1<<2 | l0<<4        i = 3:  r0 | r1<<2 | r2<<4         (bases in text order)
+// ---- quad table: FOUR windows around one core in ONE 128-byte entry ---------------------------------
+// Range mode only asks "which is the least length with one occurrence", and when a window of
+// w = m + 4 bases already occurs once and w <= kmin the answer is kmin -- one BIT per w-mer is enough.
+// The five windows that start at P .. P+4 share the m-mer core Y = S[P+4 .. P+4+m): the window at P+i is
+// L.Y.R with the 4-i bases L before the core and the i bases R after it, 4^4 = 256 bits "L.Y.R occurs
+// exactly once (both strands)" per window.  An entry holds the windows i = 0, 1, 3, 4 (the sites do not
+// need i = 2, see below): 4 x 256 bits = one 128-byte line per core, nothing of the line is unused.
+// Words 4 g .. 4 g + 3 of an entry are window g = 0..3 (i = 0, 1, 3, 4); bit index b, word b >> 6, bit b & 63:
+//      i = 0:  l0 | l1<<2 | l2<<4 | l3<<6        i = 1:  l0 | l1<<2 | l2<<4 | r0<<6
+//      i = 3:  r0 | r1<<2 | r2<<4 | l0<<6        i = 4:  r0 | r1<<2 | r2<<4 | r3<<6     (bases in text order)
+// A lookup reads ONE word per window (which one: the flank base in the top two index bits).
 // The table is derived from the seed table of length m without atomics: the lane of m-mer Z walks the
-// (pruned) tree of its 64 three-base extensions; the leaves are word 3 of entry Z, and -- the index
-// holds both strands, so a string and its reverse complement have the same count -- also word 0 of
-// entry rc(Z).  The same leaves, read as Z[0] . (Z[1..m) b1) . b2 b3, are a 16-bit piece of word 2 of
-// four entries and, mirrored, of word 1 of four more.  Every 16-bit piece of the table is written once.
-#define NM_QUAD_EXT 3u
+// (pruned) tree of its 256 four-base extensions; the leaves are the four words of window i = 4 of entry Z,
+// and -- the index holds both strands, so a string and its reverse complement have the same count -- of
+// window i = 0 of entry rc(Z).  The same leaves, read as Z[0] . (Z[1..m) b1) . b2 b3 b4, are word Z[0] of
+// window i = 3 of four entries and, mirrored, word 3 - Z[0] of window i = 1 of four more.  Every word of the
+// table is written exactly once.
+#define NM_QUAD_EXT 4u
+#define NM_QUAD_WORDS 16u
+#define NM_QUAD_OFFSETS 0x1Bu       /* window offsets an entry holds: bits 0, 1, 3, 4 */
 
 NM_HD uint64_t nm_bit_reverse64(uint64_t x) {
     x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
@@ -776,7 +780,7 @@ NM_HD void nm_quad_children(const nm_view &ix, uint64_t lo, uint64_t hi, uint64_
     }
 }
 
-// all pieces of the quad table that the m-mer Z determines (ix.seed = seed table of length m)
+// all words of the quad table that the m-mer Z determines (ix.seed = seed table of length m)
 template <bool BIG>
 NM_HD void nm_quad_build_one(const nm_view &ix, uint64_t Z, uint32_t m, uint64_t *quad) {
     uint64_t lo = 0, hi = 0;
@@ -784,9 +788,8 @@ NM_HD void nm_quad_build_one(const nm_view &ix, uint64_t Z, uint32_t m, uint64_t
         lo = 0; hi = ix.n;
         for (uint32_t j = 0; j < m && lo < hi; j++) nm_lf_interval<BIG>(ix, 3u - nm_seed_slot_code(Z, m, j), lo, hi);
     }
-    uint64_t w3 = 0, w0 = 0;
-    uint32_t piece2[4] = {0, 0, 0, 0}, piece1[4] = {0, 0, 0, 0};
-    uint64_t l1[4], h1[4], l2[4], h2[4], l3[4], h3[4];
+    uint64_t w4[4] = {0, 0, 0, 0}, w0[4] = {0, 0, 0, 0}, p3[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
+    uint64_t l1[4], h1[4], l2[4], h2[4], l3[4], h3[4], l4[4], h4[4];
     nm_quad_children<BIG>(ix, lo, hi, l1, h1);
     for (uint32_t b1 = 0; b1 < 4; b1++) {
         if (h1[b1] <= l1[b1]) continue;
@@ -795,56 +798,73 @@ NM_HD void nm_quad_build_one(const nm_view &ix, uint64_t Z, uint32_t m, uint64_t
             if (h2[b2] <= l2[b2]) continue;
             nm_quad_children<BIG>(ix, l2[b2], h2[b2], l3, h3);
             for (uint32_t b3 = 0; b3 < 4; b3++) {
-                if (h3[b3] - l3[b3] != 1) continue;        // Z b1 b2 b3 occurs exactly once
-                w3 |= 1ULL << (b1 | (b2 << 2) | (b3 << 4));
-                w0 |= 1ULL << ((3u - b3) | ((3u - b2) << 2) | ((3u - b1) << 4));
-                piece2[b1] |= 1u << (b2 | (b3 << 2));
-                piece1[b1] |= 1u << ((3u - b3) | ((3u - b2) << 2));
+                if (h3[b3] <= l3[b3]) continue;
+                nm_quad_children<BIG>(ix, l3[b3], h3[b3], l4, h4);
+                for (uint32_t b4 = 0; b4 < 4; b4++) {
+                    if (h4[b4] - l4[b4] != 1) continue;    // Z b1 b2 b3 b4 occurs exactly once
+                    const uint32_t c2 = 3u - b2, c3 = 3u - b3, c4 = 3u - b4;
+                    w4[b4] |= 1ULL << (b1 | (b2 << 2) | (b3 << 4));                  // i = 4 of Z:      r = b1 b2 b3 b4
+                    w0[3u - b1] |= 1ULL << (c4 | (c3 << 2) | (c2 << 4));             // i = 0 of rc(Z):  l = ~b4 ~b3 ~b2 ~b1
+                    p3[b1] |= 1ULL << (b2 | (b3 << 2) | (b4 << 4));                  // i = 3 of Z[1..m) b1: l0 = Z[0], r = b2 b3 b4
+                    p1[b1] |= 1ULL << (c4 | (c3 << 2) | (c2 << 4));                  // i = 1 of its rc:  l = ~b4 ~b3 ~b2, r0 = ~Z[0]
+                }
             }
         }
     }
     const uint64_t mask = (1ULL << m) - 1ULL;
     const uint64_t zlo = Z & mask, zhi = (Z >> m) & mask;
     const uint32_t first = (uint32_t)(zlo & 1ULL) | ((uint32_t)(zhi & 1ULL) << 1);          // Z[0]
-    quad[Z * 4 + 3] = w3;
-    quad[nm_slot_revcomp(Z, m) * 4 + 0] = w0;
+    const uint64_t rcz = nm_slot_revcomp(Z, m);
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        quad[Z * NM_QUAD_WORDS + 12 + j] = w4[j];
+        quad[rcz * NM_QUAD_WORDS + j] = w0[j];
+    }
     for (uint32_t b1 = 0; b1 < 4; b1++) {
         const uint64_t core = (zlo >> 1) | ((uint64_t)(b1 & 1u) << (m - 1)) |
                               (((zhi >> 1) | ((uint64_t)(b1 >> 1) << (m - 1))) << m);      // Z[1..m) b1
-        ((uint16_t *)(quad + core * 4 + 2))[first] = (uint16_t)piece2[b1];
-        ((uint16_t *)(quad + nm_slot_revcomp(core, m) * 4 + 1))[3u - first] = (uint16_t)piece1[b1];
+        quad[core * NM_QUAD_WORDS + 8 + first] = p3[b1];
+        quad[nm_slot_revcomp(core, m) * NM_QUAD_WORDS + 4 + (3u - first)] = p1[b1];
     }
 }
 
-// core slot of the four positions whose first window is `w`
+// core slot of the windows around the site whose first window starts `w`
 NM_HD uint64_t nm_quad_slot(const nm_window &w, uint32_t m) {
     const uint64_t mask = (1ULL << m) - 1ULL;
     return ((w.lo >> NM_QUAD_EXT) & mask) | (((w.hi >> NM_QUAD_EXT) & mask) << m);
 }
 
-// bit i of the result: the (m+3)-mer at position i of the four occurs exactly once
-NM_HD uint32_t nm_quad_bits(const nm_window &w, uint32_t m, const uint64_t e[4]) {
-    const uint32_t c0 = nm_window_code(w, 0), c1 = nm_window_code(w, 1), c2 = nm_window_code(w, 2);
-    const uint32_t r0 = nm_window_code(w, 3 + m), r1 = nm_window_code(w, 4 + m), r2 = nm_window_code(w, 5 + m);
-    const uint32_t i0 = c0 | (c1 << 2) | (c2 << 4);
-    const uint32_t i1 = c1 | (c2 << 2) | (r0 << 4);
-    const uint32_t i2 = r0 | (r1 << 2) | (c2 << 4);
-    const uint32_t i3 = r0 | (r1 << 2) | (r2 << 4);
-    return (uint32_t)((e[0] >> i0) & 1ULL) | ((uint32_t)((e[1] >> i1) & 1ULL) << 1) |
-           ((uint32_t)((e[2] >> i2) & 1ULL) << 2) | ((uint32_t)((e[3] >> i3) & 1ULL) << 3);
+// bit indexes of the four windows (i = 0, 1, 3, 4) of the site whose first window starts `w`
+NM_HD void nm_quad_index(const nm_window &w, uint32_t m, uint32_t b[4]) {
+    const uint32_t c0 = nm_window_code(w, 0), c1 = nm_window_code(w, 1), c2 = nm_window_code(w, 2), c3 = nm_window_code(w, 3);
+    const uint32_t r0 = nm_window_code(w, 4 + m), r1 = nm_window_code(w, 5 + m), r2 = nm_window_code(w, 6 + m), r3 = nm_window_code(w, 7 + m);
+    b[0] = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
+    b[1] = c1 | (c2 << 2) | (c3 << 4) | (r0 << 6);
+    b[2] = r0 | (r1 << 2) | (r2 << 4) | (c3 << 6);
+    b[3] = r0 | (r1 << 2) | (r2 << 4) | (r3 << 6);
 }
 
-// ---- sites: one quad entry settles 4 + d positions (nm_engine.hip: k_sites, k_resolve) -----------
-// A string that contains a string occurring once occurs once itself.  If the w-mer (w = m + 3) that starts at P + i
+// the word of window g (of the entry at `entry`) that holds bit index b
+NM_HD const uint64_t *nm_quad_word(const uint64_t *entry, uint32_t g, uint32_t b) { return entry + 4 * g + (b >> 6); }
+
+// bit i of the result (i = 0, 1, 3, 4): the (m+4)-mer that starts i bases into the site occurs exactly once;
+// e[g] = the word nm_quad_word(entry, g, b[g])
+NM_HD uint32_t nm_quad_bits(const uint32_t b[4], const uint64_t e[4]) {
+    return (uint32_t)((e[0] >> (b[0] & 63u)) & 1ULL) | ((uint32_t)((e[1] >> (b[1] & 63u)) & 1ULL) << 1) |
+           ((uint32_t)((e[2] >> (b[2] & 63u)) & 1ULL) << 3) | ((uint32_t)((e[3] >> (b[3] & 63u)) & 1ULL) << 4);
+}
+
+// ---- sites: one quad entry settles 5 + d positions (nm_engine.hip: k_sites, k_resolve) -----------
+// A string that contains a string occurring once occurs once itself.  If the w-mer (w = m + 4) that starts at P + i
 // occurs exactly once, then every position q with  q <= P + i  and  P + i + w <= q + kmin  has a kmin-mer that
 // contains it: its least unique length is <= kmin and its element is kmin (given kmin unambiguous bases).  With
 // d = kmin - w that is q in [P + i - d, P + i].  A SITE is the entry lookup at P = p0 + d for the GROUP of
-// G = d + 4 positions p0 .. p0 + d + 3: bit i of the entry (i = 0 .. 3) settles the positions t = q - p0 in
-// [i, i + d], so the four bits together cover the whole group and the table is read once per G positions instead
-// of once per 4.  What no bit settles (the window is repeated, or the bit's window holds an ambiguous base) is
-// left to k_resolve: repeat probes, then the seed table and the walk.  The reference asks the index about every
-// position on its own (newmap/search.py:383-548); results are identical.
-#define NM_SITE_MAX_D 60u           /* G <= 64: a group's settled bits fit one word */
+// G = d + 5 positions p0 .. p0 + d + 4: window i of the entry (i = 0, 1, 3, 4) settles the positions t = q - p0 in
+// [i, i + d], so for d >= 1 the four windows together cover the whole group (for d = 0 position 2 stays open) and the
+// table is read once per G positions.  What no window settles (it is repeated, or it holds an ambiguous base) is
+// left open: second table, repeat probes, then the seed table and the walk.  The reference asks the index about
+// every position on its own (newmap/search.py:383-548); results are identical.
+#define NM_SITE_MAX_D 59u           /* G <= 64: a group's settled bits fit one word */
 #define NM_SITE_MAX_KMIN 252u       /* the kmin bases of a block's last position lie inside the words the block stages */
 #define NM_SITE_LA_MAX 448u         /* kmax up to here: a block stages the lookahead of its own walks too (else they go to k_resolve) */
 // words a block of BP positions stages: its own, the lookahead of the validity test (kmin <= 252) and -- for
@@ -856,23 +876,23 @@ NM_HD bool nm_site_core_valid(const nm_window &w, uint32_t m) {
     return ((w.amb >> NM_QUAD_EXT) & ((1ULL << m) - 1ULL)) == 0;
 }
 
-// bit i: the (m+3)-mer at position i of the site occurs exactly once AND its window is free of ambiguity
-NM_HD uint32_t nm_site_bits(const nm_window &w, uint32_t m, const uint64_t e[4]) {
-    const uint32_t once = nm_quad_bits(w, m, e);
+// bit i (i = 0, 1, 3, 4): the (m+4)-mer i bases into the site occurs exactly once AND its window is free of ambiguity
+NM_HD uint32_t nm_site_bits(const nm_window &w, uint32_t m, const uint32_t b[4], const uint64_t e[4]) {
+    const uint32_t once = nm_quad_bits(b, e);
     const uint64_t wm = (1ULL << (m + NM_QUAD_EXT)) - 1ULL;
     uint32_t ok = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) ok |= (uint32_t)(((w.amb >> i) & wm) == 0) << i;
-    return once & ok;
+    for (uint32_t i = 0; i < 5; i++) ok |= (uint32_t)(((w.amb >> i) & wm) == 0) << i;
+    return once & ok & NM_QUAD_OFFSETS;
 }
 
-// bit t of the result: position t of the group (t = 0 .. d + 3) is settled by one of the site's bits
-NM_HD uint64_t nm_site_settled(uint32_t bits4, uint32_t d) {
+// bit t of the result: position t of the group (t = 0 .. d + 4) is settled by one of the site's windows
+NM_HD uint64_t nm_site_settled(uint32_t bits5, uint32_t d) {
     const uint64_t run = (1ULL << (d + 1)) - 1ULL;        // d <= NM_SITE_MAX_D
     uint64_t s = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++)
-        if ((bits4 >> i) & 1u) s |= run << i;
+    for (uint32_t i = 0; i < 5; i++)
+        if ((bits5 >> i) & 1u) s |= run << i;
     return s;
 }
 
@@ -907,19 +927,21 @@ NM_HD uint32_t nm_valid4(AmbWord amb_word, uint64_t q, uint32_t kmin, uint32_t &
     return valid;
 }
 
-// Second chance (k_resolve): the sites of a launch may read a table with SHORT cores -- large groups, few table lines,
-// but more windows that are repeated.  A position they leave open first asks the table with longer cores: the entry
-// at P = p holds the bits of the windows at p .. p + 3, and any of them that occurs once inside the position's kmin-mer
-// (i <= kmin - w2) settles it.  One line instead of the seed entry plus the rank lines of a walk.  `w` = the 64 bases
-// from p on.
+// Second chance: the sites of a launch may read a table with SHORT cores -- large groups, few table lines, but more
+// windows that are repeated.  A position they leave open first asks the table with longer cores: the entry at P = p
+// holds the windows at p + 0, 1, 3, 4, and any of them that occurs once inside the position's kmin-mer (i <= kmin - w2)
+// settles it.  One line instead of the seed entry plus the rank lines of a walk.  `w` = the 64 bases from p on.
 NM_HD bool nm_second_chance(const nm_view &ix, const nm_window &w, uint32_t kmin) {
     const uint32_t m = ix.quad2_m, len = m + NM_QUAD_EXT;
     if (!nm_site_core_valid(w, m)) return false;
-    const uint64_t *e = ix.quad2 + nm_quad_slot(w, m) * 4;
-    const uint64_t ee[4] = {e[0], e[1], e[2], e[3]};
+    const uint64_t *entry = ix.quad2 + nm_quad_slot(w, m) * NM_QUAD_WORDS;
+    uint32_t b[4];
+    nm_quad_index(w, m, b);
     const uint32_t reach = kmin - len;                     // windows p + i with i <= reach lie inside the kmin-mer
-    const uint32_t usable = reach >= 3 ? 0xFu : (1u << (reach + 1)) - 1u;
-    return (nm_site_bits(w, m, ee) & usable) != 0;
+    const uint32_t usable = reach >= 4 ? 0x1Fu : (1u << (reach + 1)) - 1u;
+    const uint64_t e[4] = {usable & 1u ? *nm_quad_word(entry, 0, b[0]) : 0ULL, usable & 2u ? *nm_quad_word(entry, 1, b[1]) : 0ULL,
+                           usable & 8u ? *nm_quad_word(entry, 2, b[2]) : 0ULL, usable & 16u ? *nm_quad_word(entry, 3, b[3]) : 0ULL};
+    return (nm_site_bits(w, m, b, e) & usable) != 0;
 }
 
 // Which strides get a repeat probe when the probes run AFTER the sites: a stretch that occurs twice over more than a

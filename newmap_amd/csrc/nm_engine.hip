@@ -250,9 +250,9 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique(nm_view ix, const nm_en
     nm_epilogue<STATS>(inb, amb0, err, p, t, status);
 }
 
-// ---- k_sites: one 128-byte table line serves a GROUP of 4 + d positions ---------------------------
-// (nm_core.h "sites".)  Range mode on both strands with m + 3 <= kmin <= NM_SITE_MAX_KMIN, and list mode whose
-// first length takes the place of kmin.  A block owns BP = 512 G consecutive positions (G = d + 4, d = kmin - m - 3
+// ---- k_sites: one 128-byte table line serves a GROUP of 5 + d positions ---------------------------
+// (nm_core.h "sites".)  Range mode on both strands with m + 4 <= kmin <= NM_SITE_MAX_KMIN, and list mode whose
+// first length takes the place of kmin.  A block owns BP = 512 G consecutive positions (G = d + 5, d = kmin - m - 4
 // capped at NM_SITE_MAX_D): every lane looks up the sites of two groups (both loads in flight before either is
 // used), ORs the positions its entries settle into a bitmap in LDS, and the block then writes the elements four
 // at a time in position order -- kmin where settled and the kmin bases are unambiguous, else 0 -- together with the
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NM_BLOCK) void k_min_unique(nm_view ix, const nm_en
 // encoded array for the kernels that may follow (repeat probes, k_resolve); there is no separate encode pass.
 #define NM_SITE_BLOCK 256
 #define NM_SITE_PER_LANE 2
-static inline uint32_t nm_site_block_positions(uint32_t d) { return NM_SITE_BLOCK * NM_SITE_PER_LANE * (d + 4); }
+static inline uint32_t nm_site_block_positions(uint32_t d) { return NM_SITE_BLOCK * NM_SITE_PER_LANE * (d + 5); }
 static inline size_t nm_site_lds_bytes(uint32_t d, uint32_t kmax) {
     const uint32_t bp = nm_site_block_positions(d);
     return (size_t)NM_SITE_STAGE_WORDS(bp, kmax) * sizeof(nm_enc_word) + (size_t)bp / 8 * 2;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
     extern __shared__ uint64_t s_mem[];
     __shared__ uint32_t s_open_total, s_qn;
     __shared__ uint32_t s_q[NM_SITE_CHANCE_MAX];
-    const uint32_t G = d + 4, m = ix.quad_m;
+    const uint32_t G = d + 5, m = ix.quad_m;
     const uint32_t BP = NM_SITE_BLOCK * NM_SITE_PER_LANE * G;          // a multiple of 512
     const uint32_t n_stage = NM_SITE_STAGE_WORDS(BP, kmax);
     nm_enc_word *s_enc = reinterpret_cast<nm_enc_word *>(s_mem);      // words w0 .. w0 + n_stage - 1 of the segment
@@ -332,7 +332,8 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
     };
     // ---- phase 1: the sites
     nm_window win[NM_SITE_PER_LANE];
-    uint64_t e[NM_SITE_PER_LANE][4];
+    uint64_t e[NM_SITE_PER_LANE][4];                                   // one word per window of the entry
+    uint32_t bidx[NM_SITE_PER_LANE][4];
     bool go[NM_SITE_PER_LANE];
     uint32_t n_entries = 0;
 #pragma unroll
@@ -340,17 +341,18 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         const uint32_t g = (uint32_t)s * NM_SITE_BLOCK + tid;          // group g: positions base + g G .. + G - 1, site at + d
         win[s] = lds_window(g * G + d);
         go[s] = base + (uint64_t)g * G < num_kmers && nm_site_core_valid(win[s], m) && !(ix.seed_policy & 0x200u);
+        nm_quad_index(win[s], m, bidx[s]);
         e[s][0] = e[s][1] = e[s][2] = e[s][3] = 0;
         if (go[s]) {
-            const ulonglong2 *ep = reinterpret_cast<const ulonglong2 *>(ix.quad + nm_quad_slot(win[s], m) * 4);
-            const ulonglong2 a = ep[0], b = ep[1];
-            e[s][0] = a.x; e[s][1] = a.y; e[s][2] = b.x; e[s][3] = b.y;
+            const uint64_t *entry = ix.quad + nm_quad_slot(win[s], m) * NM_QUAD_WORDS;     // one 128-byte line
+#pragma unroll
+            for (uint32_t g4 = 0; g4 < 4; g4++) e[s][g4] = *nm_quad_word(entry, g4, bidx[s][g4]);
             n_entries += 4;
         }
     }
 #pragma unroll
     for (int s = 0; s < NM_SITE_PER_LANE; s++) {
-        const uint64_t settled = go[s] ? nm_site_settled(nm_site_bits(win[s], m, e[s]), d) : 0ULL;
+        const uint64_t settled = go[s] ? nm_site_settled(nm_site_bits(win[s], m, bidx[s], e[s]), d) : 0ULL;
         if (settled) {
             const uint32_t o = ((uint32_t)s * NM_SITE_BLOCK + tid) * G;   // bit offset of the group in the block
             const uint32_t wi = o >> 5, sh = o & 31;
@@ -758,7 +760,7 @@ static double nm_now() { return std::chrono::duration<double>(std::chrono::stead
 #define NM_PHASE(t0, what) do { if (nm_verbose()) { fprintf(stderr, "[open] %s: %.3fs\n", what, nm_now() - (t0)); (t0) = nm_now(); } } while (0)
 
 // quad table for cores of m bases, from the seed table of that length (a level of the seed-table build):
-// 4^m entries x 32 bytes
+// 4^m entries x 128 bytes
 static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m, bool small = false) {
     if (!small) { ix->view.quad = nullptr; ix->view.quad_m = 0; }
     else ix->quad_small_m = 0;
@@ -766,15 +768,15 @@ static int nm_build_quad(nm_index *ix, const uint64_t *level_table, uint32_t m, 
     const uint64_t n_cores = 1ULL << (2 * m);
     double tq = nm_now();
     void **slot = small ? &ix->d_quad_small : &ix->d_quad;
-    if (hipMalloc(slot, n_cores * 32) != hipSuccess) {     // (someone else holds the memory: go on without the table)
+    if (hipMalloc(slot, n_cores * NM_QUAD_WORDS * 8) != hipSuccess) {     // (someone else holds the memory: go on without the table)
         (void)hipGetLastError();
         *slot = nullptr;
         if (nm_verbose()) fprintf(stderr, "[open] quad table of %llu GB does not fit: range mode runs on the seed table\n",
-                                  (unsigned long long)(n_cores * 32 >> 30));
+                                  (unsigned long long)(n_cores * NM_QUAD_WORDS * 8 >> 30));
         return NM_OK;
     }
     NM_PHASE(tq, "quad table hipMalloc");
-    ix->device_bytes += n_cores * 32;
+    ix->device_bytes += n_cores * NM_QUAD_WORDS * 8;
     nm_view v = ix->view;
     v.seed = level_table;
     v.seed_len = m;
@@ -821,14 +823,14 @@ static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table, uint32_
 }
 
 // core length of the quad table: as long as the seed, at most 60 % of the HBM still free once the seed table is
-// in place (4^m x 32 bytes: 137 GB for m = 16; the pair table is not built next to it)
+// in place (4^m x 128 bytes: 137 GB for m = 15)
 static uint32_t nm_auto_quad_len(const nm_index *ix, uint32_t s) {
     (void)ix;
     uint32_t m = s;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
     free_b -= free_b < (8ULL << (2 * s)) ? free_b : (8ULL << (2 * s));      // the seed table comes first
-    while (m >= 8 && (32ULL << (2 * m)) > free_b / 5 * 3) m--;
+    while (m >= 8 && (128ULL << (2 * m)) > free_b / 5 * 3) m--;
     return m >= 8 ? m : 0;
 }
 
@@ -1006,7 +1008,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     uint32_t s = seed_len_override == -1 ? h.seed_len
                : (seed_len_override < -1 ? nm_auto_seed_len(ix) : (uint32_t)seed_len_override);
     if (s > 16) s = 16;
-    // -3: automatic with small tables (seed <= 15, quad cores <= 14: 17 GB at most).  A one-shot run never earns
+    // -3: automatic with small tables (seed <= 15, quad cores <= 13 + a table with shorter cores: 20 GB at most).  A one-shot run never earns
     // back what the large tables cost to allocate: hipMalloc of more than ~40 GB waits 3 - 5 s for the driver to
     // clear the memory (measured), the large tables save ~1.5 ps per position.
     const bool small_tables = seed_len_override == -3;
@@ -1016,20 +1018,20 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     uint32_t quad_m = 0;
     if (seed_len_override < -1 && s >= 8) {
         quad_m = nm_auto_quad_len(ix, s);
-        if (small_tables && quad_m > 14) quad_m = 14;
+        if (small_tables && quad_m > 13) quad_m = 13;
         if (const char *q = getenv("NEWMAP_AMD_QUAD_M")) quad_m = (uint32_t)atoi(q);
         if (quad_m > s) quad_m = s;
         if (quad_m && quad_m < 8) quad_m = 8;              // the level-wise build starts at length 8
     }
     // a second quad table with SHORT cores (larger groups per table line, nm_core.h "sites"): windows of
     // ceil(log4(20 n)) bases -- about one in twenty repeated -- when that is shorter than the first table's and the
-    // table stays below 9 GB (cores <= 14); NEWMAP_AMD_QUAD_SMALL_M overrides (0 = none)
+    // table stays below 9 GB (cores <= 13); NEWMAP_AMD_QUAD_SMALL_M overrides (0 = none)
     uint32_t quad_small_m = 0;
     if (quad_m) {
         uint32_t w1 = 1;
         while (w1 < 32 && (double)(1ULL << (2 * w1)) < 20.0 * (double)h.n) w1++;
         quad_small_m = w1 > NM_QUAD_EXT + 8 ? w1 - NM_QUAD_EXT : 8;
-        if (quad_small_m > 14) quad_small_m = 14;
+        if (quad_small_m > 13) quad_small_m = 13;
         if (const char *q = getenv("NEWMAP_AMD_QUAD_SMALL_M")) quad_small_m = (uint32_t)atoi(q);
         if (quad_small_m && quad_small_m < 8) quad_small_m = 8;
         if (quad_small_m >= quad_m) quad_small_m = 0;
@@ -1132,7 +1134,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         ix->repeat_probes = value != 0;
         return NM_OK;
     }
-    if (option == NM_OPT_SITE_D) {         // measurement / tests: cap on d = kmin - window of the sites (a group = d + 4 positions)
+    if (option == NM_OPT_SITE_D) {         // measurement / tests: cap on d = kmin - window of the sites (a group = d + 5 positions)
         if (value < 0 || value > (int64_t)NM_SITE_MAX_D) { nm_set_error("site d cap must be 0..%u", NM_SITE_MAX_D); return NM_E_ARGUMENT; }
         ix->site_d_cap = (uint32_t)value;
         return NM_OK;
@@ -1248,17 +1250,18 @@ static bool nm_sites_apply(const nm_index *ix, const nm_view &view, uint32_t kmi
     return kmin >= view.quad_m + NM_QUAD_EXT || (ix->d_quad_small && ix->quad_small_m && kmin >= ix->quad_small_m + NM_QUAD_EXT);
 }
 
-// Expected table lines per position when the sites read the table with cores of m bases (windows of w = m + 3): one line
-// per group of G = kmin - w + 4 positions, plus what the positions cost that no window settles.  f = share of repeated
+// Expected table lines per position when the sites read the table with cores of m bases (windows of w = m + 4): one line
+// per group of G = kmin - w + 5 positions, plus what the positions cost that no window settles.  f = share of repeated
 // windows among the w-mers of a text of n symbols (uniform model); the first and last position of a group lie in one
 // window, the others in at least two.
 static double nm_site_cost(uint64_t n, uint32_t m, uint32_t kmin, uint32_t d_cap, double next_cost) {
     const uint32_t w = m + NM_QUAD_EXT;
     uint32_t d = kmin - w;
     if (d > d_cap) d = d_cap;
-    const double G = d + 4.0;
+    const double G = d + 5.0;
     const double f = 1.0 - exp(-(double)n / pow(4.0, (double)w));
-    const double open = d == 0 ? f : (2.0 * f + (G - 2.0) * f * f) / G;
+    // d = 0: positions 0, 1, 3, 4 of a group lie in one window each, position 2 in none
+    const double open = d == 0 ? (4.0 * f + 1.0) / 5.0 : (2.0 * f + (G - 2.0) * f * f) / G;
     return 1.0 / G + open * next_cost;
 }
 

@@ -126,7 +126,7 @@ class Index:
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LF_BLOCKS, int(bool(on))))
 
     def set_site_d(self, d_cap: int):
-        """measurement / tests: cap on d = kmin - (quad core length + 3); a site settles a group of d + 4 positions"""
+        """measurement / tests: cap on d = kmin - (quad core length + 4); a site settles a group of d + 5 positions"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SITE_D, int(d_cap)))
 
     def set_site_table(self, which: int):

@@ -108,7 +108,7 @@ class HostSim:
                                         words.ctypes.data, decided.ctypes.data)
         return words[:n_probes], decided[:num_kmers], int(steps)
 
-    def sites(self, seq: bytes, num_kmers, kmin, kmax, d_cap=60, probes=1, ks=None, dtype=np.uint8, chance_max=256, walk_max=64):
+    def sites(self, seq: bytes, num_kmers, kmin, kmax, d_cap=59, probes=1, ks=None, dtype=np.uint8, chance_max=256, walk_max=64):
         """k_sites -> gated repeat probes -> k_resolve, as the device runs them (needs check_quad() first: it builds the
         quad table).  ks: list mode (kmin / kmax are then its first / longest length).  Returns (elements, status,
         rc, need bitmap, counters) -- counters: table entries read, positions walked, probes run, probe-decided."""

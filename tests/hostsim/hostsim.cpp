@@ -108,38 +108,48 @@ uint64_t hs_check_lfb(hs_index *ix) {
 // every bit a group of four positions can read is compared with a direct count of its (m+3)-mer.
 // Returns the number of wrong bits (+ 2^32 per 16-bit piece no lane wrote).
 uint64_t hs_check_quad(hs_index *ix) {
-    const uint32_t m = ix->v.seed_len, w = m + 3;
+    const uint32_t m = ix->v.seed_len, w = m + NM_QUAD_EXT;
     if (!m || m > 8) return ~0ULL;
     const uint64_t cores = 1ULL << (2 * m);
-    ix->quad.assign(cores * 4, 0x5A5A5A5A5A5A5A5AULL);
-    std::vector<uint64_t> ref(cores * 4, 0x5A5A5A5A5A5A5A5AULL), other(cores * 4, 0xA5A5A5A5A5A5A5A5ULL);
+    ix->quad.assign(cores * NM_QUAD_WORDS, 0x5A5A5A5A5A5A5A5AULL);
+    std::vector<uint64_t> other(cores * NM_QUAD_WORDS, 0xA5A5A5A5A5A5A5A5ULL);
     for (uint64_t Z = 0; Z < cores; Z++) {
         if (ix->big) { nm_quad_build_one<true>(ix->v, Z, m, ix->quad.data()); nm_quad_build_one<true>(ix->v, Z, m, other.data()); }
         else { nm_quad_build_one<false>(ix->v, Z, m, ix->quad.data()); nm_quad_build_one<false>(ix->v, Z, m, other.data()); }
     }
     uint64_t bad = 0;
-    for (uint64_t i = 0; i < cores * 4; i++)                // a piece nobody wrote keeps its (different) fill pattern
-        for (int h = 0; h < 4; h++)
-            if (((ix->quad[i] >> (16 * h)) & 0xFFFF) != ((other[i] >> (16 * h)) & 0xFFFF)) bad += 1ULL << 32;
+    for (uint64_t i = 0; i < cores * NM_QUAD_WORDS; i++)    // a word nobody wrote keeps its (different) fill pattern
+        if (ix->quad[i] != other[i]) bad += 1ULL << 32;
     ix->v.quad = ix->quad.data();
     ix->v.quad_m = m;
-    // windows of m + 6 bases: L (3) . core (m) . R (3); position i of the group reads word i
-    const uint64_t n_win = 1ULL << (2 * (m + 6));
-    for (uint64_t x = 0; x < n_win; x++) {
+    // stretches of m + 8 bases: L (4) . core (m) . R (4); the windows 0, 1, 3, 4 bases in are read from one entry.
+    // All of them for short cores, a pseudo-random sample of 16 M otherwise.
+    const uint32_t span = m + 8;
+    const uint64_t n_all = 1ULL << (2 * span), n_win = n_all <= (1ULL << 26) ? n_all : (1ULL << 24);
+    uint64_t state = 0x9E3779B97F4A7C15ULL;
+    for (uint64_t k = 0; k < n_win; k++) {
+        uint64_t x = k;
+        if (n_win != n_all) { state = state * 6364136223846793005ULL + 1442695040888963407ULL; x = (state >> 11) & (n_all - 1); }
         nm_window win{0, 0, 0};
-        for (uint32_t j = 0; j < m + 6; j++) {
+        for (uint32_t j = 0; j < span; j++) {
             const uint32_t c = (uint32_t)(x >> (2 * j)) & 3u;
             win.lo |= (uint64_t)(c & 1u) << j;
             win.hi |= (uint64_t)(c >> 1) << j;
         }
-        const uint64_t slot = nm_quad_slot(win, m);
-        const uint32_t got = nm_quad_bits(win, m, ix->quad.data() + slot * 4);
-        for (uint32_t i = 0; i < 4; i++) {
+        const uint64_t *entry = ix->quad.data() + nm_quad_slot(win, m) * NM_QUAD_WORDS;
+        uint32_t b[4];
+        nm_quad_index(win, m, b);
+        const uint64_t e[4] = {*nm_quad_word(entry, 0, b[0]), *nm_quad_word(entry, 1, b[1]), *nm_quad_word(entry, 2, b[2]), *nm_quad_word(entry, 3, b[3])};
+        const uint32_t got = nm_quad_bits(b, e);
+        if (got & ~NM_QUAD_OFFSETS) bad++;
+        for (uint32_t i = 0; i < 5; i++) {
+            if (!((NM_QUAD_OFFSETS >> i) & 1u)) continue;
             nm_window wi{win.lo >> i, win.hi >> i, 0};
-            const uint64_t e = ix->big ? nm_seed_entry<true>(ix->v, nm_seed_slot(wi, w), w) : nm_seed_entry<false>(ix->v, nm_seed_slot(wi, w), w);
-            const uint32_t want = (e >> NM_SEED_LO_BITS) == 1 ? 1u : 0u;
+            const uint64_t se = ix->big ? nm_seed_entry<true>(ix->v, nm_seed_slot(wi, w), w) : nm_seed_entry<false>(ix->v, nm_seed_slot(wi, w), w);
+            const uint32_t want = (se >> NM_SEED_LO_BITS) == 1 ? 1u : 0u;
             if (((got >> i) & 1u) != want) bad++;
         }
+        if (nm_quad_once_first(ix->v, win, 1000) != ((got & 1u) != 0)) bad++;
     }
     return bad;
 }
@@ -153,7 +163,7 @@ int hs_build_quad2(hs_index *ix, uint32_t m2) {
         seed[slot] = ix->big ? nm_seed_entry<true>(v, slot, m2) : nm_seed_entry<false>(v, slot, m2);
     v.seed = seed.data();
     v.seed_len = m2;
-    ix->quad2.assign(cores * 4, 0);
+    ix->quad2.assign(cores * NM_QUAD_WORDS, 0);
     for (uint64_t Z = 0; Z < cores; Z++) {
         if (ix->big) nm_quad_build_one<true>(v, Z, m2, ix->quad2.data());
         else nm_quad_build_one<false>(v, Z, m2, ix->quad2.data());
@@ -298,7 +308,7 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
     };
     uint32_t d = kmin - (m + NM_QUAD_EXT);
     if (d > d_cap) d = d_cap;
-    const uint32_t G = d + 4, BLOCK = 256, PER_LANE = 2, BP = BLOCK * PER_LANE * G, n_stage = NM_SITE_STAGE_WORDS(BP, kmax);
+    const uint32_t G = d + 5, BLOCK = 256, PER_LANE = 2, BP = BLOCK * PER_LANE * G, n_stage = NM_SITE_STAGE_WORDS(BP, kmax);
     const uint64_t n_need = (num_kmers + 63) / 64;
     std::vector<uint64_t> need(n_need + 1, 0);
     bool any_open = false;                                  // work[NM_WORK_OPEN]
@@ -338,7 +348,11 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             const nm_window win = lds_window(g * G + d);
             if (!(base + (uint64_t)g * G < num_kmers && nm_site_core_valid(win, m))) continue;
             counters[0]++;
-            const uint64_t settled = nm_site_settled(nm_site_bits(win, m, v.quad + nm_quad_slot(win, m) * 4), d);
+            const uint64_t *entry = v.quad + nm_quad_slot(win, m) * NM_QUAD_WORDS;
+            uint32_t b[4];
+            nm_quad_index(win, m, b);
+            const uint64_t e[4] = {*nm_quad_word(entry, 0, b[0]), *nm_quad_word(entry, 1, b[1]), *nm_quad_word(entry, 2, b[2]), *nm_quad_word(entry, 3, b[3])};
+            const uint64_t settled = nm_site_settled(nm_site_bits(win, m, b, e), d);
             if (!settled) continue;
             const uint32_t o = g * G, wi = o >> 5, sh = o & 31;
             s_set[wi] |= (uint32_t)(settled << sh);

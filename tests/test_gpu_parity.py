@@ -363,7 +363,7 @@ def test_large_random_genome_properties(tmp_path, eng):
         assert (tot2 > 1).all()
     with eng.Index(idx, 0, "auto-small") as small:          # the one-shot CLI's tables: same kernels, 17 GB
         info = small.info()
-        assert info["seed_length"] == 15 and info["quad_core_length"] == 14 and info["device_bytes"] < 21e9
+        assert info["seed_length"] == 15 and info["quad_core_length"] == 13 and info["device_bytes"] < 21e9
         got, _ = small.min_unique_segment(rec[:20_000_199], 20_000_000, kmin, kmax)
         assert small.info()["last_range_kernel"] == 5 and np.array_equal(got, whole[:20_000_000])
     with eng.Index(idx, 0, 12) as ix12:                   # the reference's default seed length, simple kernel
@@ -425,7 +425,7 @@ def test_config3_full_size_properties(tmp_path, eng, monkeypatch):
     monkeypatch.setenv("NEWMAP_AMD_COARSE_MIN", "0")
     with eng.Index(idx, 0) as ix:
         info = ix.info()
-        assert info["bwt_length"] > 2 ** 32 and info["quad_core_length"] == 16
+        assert info["bwt_length"] > 2 ** 32 and info["quad_core_length"] == 15
         for kmin, kmax in ((24, 150), (20, 200)):
             whole, amb = ix.min_unique_segment(chr1[:100_000_000 + kmax - 1], 100_000_000, kmin, kmax)
             assert amb == 0 and ix.info()["last_range_kernel"] == 5
@@ -628,7 +628,7 @@ def test_both_range_kernels_agree(mixed_genome, eng):
     with eng.Index(g["idx"], 0) as ix:
         info = ix.info()
         assert 8 <= info["quad_small_core_length"] < info["quad_core_length"] <= info["seed_length"]
-        w = info["quad_small_core_length"] + 3                # the shortest window the sites can use
+        w = info["quad_small_core_length"] + 4                # the shortest window the sites can use
         for rec in (g["r1"], g["r2"]):
             for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (w + 1, 64), (60, 90), (61, 90), (62, 90),
                                (64, 64), (100, 300), (124, 200), (125, 200), (252, 255), (253, 255)):
@@ -645,7 +645,7 @@ def test_both_range_kernels_agree(mixed_genome, eng):
                         ix.set_kernel(kernel)
                         for probes in (True, False):
                             ix.set_repeat_probes(probes)
-                            for d_cap, table in (((60, 0), (0, 1), (2, 2), (60, 1), (60, 2)) if kernel == 5 and probes else ((60, 0),)):
+                            for d_cap, table in (((59, 0), (0, 1), (2, 2), (59, 1), (59, 2)) if kernel == 5 and probes else ((59, 0),)):
                                 ix.set_site_d(d_cap)
                                 ix.set_site_table(table)          # picked per launch / long cores / short cores + second chance
                                 c, amb_c = ix.min_unique_segment(rec, len(rec), kmin, kmax)
@@ -654,7 +654,7 @@ def test_both_range_kernels_agree(mixed_genome, eng):
                                 assert np.array_equal(a, c) and amb_c == amb_a, (kernel, big, probes, d_cap, table, kmin, kmax)
                                 if used == 5 and table == 2:
                                     assert ix.info()["last_site_core_length"] == info["quad_small_core_length"]
-                ix.set_site_d(60)
+                ix.set_site_d(59)
                 ix.set_site_table(0)
                 ix.set_force_big(False)
                 ix.set_kernel(0)

@@ -328,7 +328,7 @@ def test_quad_table_bits_equal_direct_counts(tmp_path, m, force_big):
     # repeat probes that consult the quad table first decide nothing the oracle contradicts
     oracle = rd.OracleIndex([bytes(r1), r2])
     rec = bytes(r1)
-    for kmin, kmax in ((m + 3, 40), (4, 12)):
+    for kmin, kmax in ((m + 4, 40), (4, 12)):
         want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True).astype(np.int64)
         words, decided, _ = sim.repeat_probes(rec, len(rec), kmin, kmax, 16)
         closed = decided != 0xFFFFFFFF
@@ -359,7 +359,7 @@ def test_sites_pipeline_equals_oracle(tmp_path, m, force_big):
     assert sim.check_quad() == 0                           # builds the quad table (cores of m bases)
     sim.enable_lfb(True)
     oracle = rd.OracleIndex([bytes(r1), r2])
-    w = m + 3
+    w = m + 4
     for rec in (bytes(r1), r2):
         n_amb = sum(ch not in b"ACGTacgt" for ch in rec)
         for kmin, kmax in ((w, 40), (w + 1, 40), (w + 3, 200), (20, 200), (24, 150), (61, 90), (62, 300), (64, 64), (70, 255), (130, 200), (252, 255)):
@@ -367,25 +367,25 @@ def test_sites_pipeline_equals_oracle(tmp_path, m, force_big):
             want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
             plain, _, code = sim.min_unique(rec, len(rec), kmin, kmax, True, dtype)
             assert code == 0 and np.array_equal(plain, want)
-            for d_cap in (0, 1, 5, 60):
+            for d_cap in (0, 1, 5, 59):
                 for probes in (0, 1, 2):
                     got, status, code, need, counters = sim.sites(rec, len(rec), kmin, kmax, d_cap, probes, dtype=dtype)
                     assert code == 0 and got.dtype == want.dtype
                     assert np.array_equal(got, want), (kmin, kmax, d_cap, probes, np.flatnonzero(got != want)[:10])
                     assert int(status[0]) == n_amb and int(status[7]) == len(rec) - n_amb
                     d = min(kmin - w, d_cap)
-                    assert int(counters[0]) <= -(-len(rec) // (d + 4))          # one entry per group of d + 4 positions
+                    assert int(counters[0]) <= -(-len(rec) // (d + 5))          # one entry per group of d + 5 positions
                     if probes == 0:
                         assert int(counters[2]) == 0 and int(counters[3]) == 0
             # a prefix that ends inside a block and inside a group; a num_kmers that leaves lookahead behind
             for cut in (1, 3, 517, len(rec) - kmin):
                 if cut <= 0 or cut > len(rec):
                     continue
-                got, _, code, _, _ = sim.sites(rec, cut, kmin, kmax, 60, 1, dtype=dtype)
+                got, _, code, _, _ = sim.sites(rec, cut, kmin, kmax, 59, 1, dtype=dtype)
                 assert code == 0 and np.array_equal(got, want[:cut]), (kmin, kmax, cut)
     # the probes really run on the tandem array and decide most of it; elsewhere (open bits sparse) none runs
     rec = bytes(r1)
-    got, _, _, need, counters = sim.sites(rec, len(rec), 20, 60, 60, 1)
+    got, _, _, need, counters = sim.sites(rec, len(rec), 20, 60, 59, 1)
     dense = np.array([bin(int(x)).count("1") >= 32 for x in need])
     assert dense[600 // 64 + 1:(1800 - 60) // 64 - 1].all() and int(counters[2]) <= 2 * int(dense.sum()) + 2
     assert int(counters[3]) > 600 and int(counters[1]) < len(rec) // 4
@@ -396,7 +396,7 @@ def test_sites_pipeline_equals_oracle(tmp_path, m, force_big):
         for kmin, kmax in ((w, 40), (w + 1, 40), (w + 2, 40), (w + 3, 200), (20, 200), (70, 255)):
             want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
             for probes, chance_max, walk_max in ((0, 256, 64), (1, 256, 64), (1, 1 << 20, 64), (1, 1 << 20, 1 << 20), (0, 0, 0)):
-                got, _, code, _, counters = sim.sites(rec, len(rec), kmin, kmax, 60, probes, chance_max=chance_max, walk_max=walk_max)
+                got, _, code, _, counters = sim.sites(rec, len(rec), kmin, kmax, 59, probes, chance_max=chance_max, walk_max=walk_max)
                 assert code == 0 and np.array_equal(got, want), (kmin, kmax, probes, chance_max, walk_max)
                 assert kmin >= w + 2 or int(counters[4]) == 0       # (the second table's window must fit the kmin-mer)
                 second += int(counters[4])
@@ -414,7 +414,7 @@ def test_sites_pipeline_equals_oracle(tmp_path, m, force_big):
             want, _ = rd.linear_search_segment(oracle, seg, ks, kmax, dtype, True)
             head = len(rec) - kmax + 1                      # the caller keeps the truncated k-mers at the end out
             for probes in (0, 1):
-                got, _, code, _, _ = sim.sites(rec, head, ks[0], kmax, 60, probes, ks=ks, dtype=dtype)
+                got, _, code, _, _ = sim.sites(rec, head, ks[0], kmax, 59, probes, ks=ks, dtype=dtype)
                 # (the lone R: list mode drops a position on any non-ACGT byte, the reference only on N -- DESIGN.md)
                 keep = np.ones(head, bool)
                 r_at = rec.find(b"R")

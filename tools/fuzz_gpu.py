@@ -75,9 +75,9 @@ def main():
                 plain.set_repeat_probes(False)
                 plain.set_list_via_range(False)
                 fast.set_force_big(bool(rng.random() < 0.5))
-                w = (fast.info()["quad_small_core_length"] or fast.info()["quad_core_length"]) + 3
+                w = (fast.info()["quad_small_core_length"] or fast.info()["quad_core_length"]) + 4
                 for _ in range(6):
-                    fast.set_site_d(int(rng.choice([60, 60, 60, 0, 1, 3, 17])))
+                    fast.set_site_d(int(rng.choice([59, 59, 59, 0, 1, 3, 17])))
                     fast.set_repeat_probes(bool(rng.random() < 0.8))
                     fast.set_site_table(int(rng.choice([0, 0, 1, 2])))
                     kmin = int(rng.choice([w, w + 1, 20, 24, 36, 60, 61, 62, 64, 100, 124, 125, 190, 252, 253, int(rng.integers(1, 200))]))

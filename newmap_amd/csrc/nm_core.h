@@ -391,7 +391,7 @@ NM_HD bool nm_quad_once_first(const nm_view &ix, const nm_window &w, uint32_t km
     const uint64_t mask = (1ULL << m) - 1ULL;
     const uint64_t slot = ((w.lo >> 4) & mask) | (((w.hi >> 4) & mask) << m);
     const uint32_t b0 = nm_window_code(w, 0) | (nm_window_code(w, 1) << 2) | (nm_window_code(w, 2) << 4) | (nm_window_code(w, 3) << 6);
-    return ((ix.quad[slot * 16 + (b0 >> 6)] >> (b0 & 63u)) & 1ULL) != 0;
+    return ((ix.quad[slot * 16 + 2 * (b0 >> 6)] >> (b0 & 63u)) & 1ULL) != 0;
 }
 
 // (settled <= stride and exact are returned separately: the coarse probes use strides that do not fit the word)
@@ -729,16 +729,21 @@ NM_HD uint64_t nm_seed_entry_from_parent(const nm_view &ix, uint64_t parent_entr
 // L.Y.R with the 4-i bases L before the core and the i bases R after it, 4^4 = 256 bits "L.Y.R occurs
 // exactly once (both strands)" per window.  An entry holds the windows i = 0, 1, 3, 4 (the sites do not
 // need i = 2, see below): 4 x 256 bits = one 128-byte line per core, nothing of the line is unused.
-// Words 4 g .. 4 g + 3 of an entry are window g = 0..3 (i = 0, 1, 3, 4); bit index b, word b >> 6, bit b & 63:
-//      i = 0:  l0 | l1<<2 | l2<<4 | l3<<6        i = 1:  l0 | l1<<2 | l2<<4 | r0<<6
-//      i = 3:  r0 | r1<<2 | r2<<4 | l0<<6        i = 4:  r0 | r1<<2 | r2<<4 | r3<<6     (bases in text order)
-// A lookup reads ONE word per window (which one: the flank base in the top two index bits).
+// Per window an 8-bit index b (bases in text order; the top two bits pick one of four 64-bit words):
+//      i = 0:  l0 | l1<<2 | l2<<4 | l3<<6        i = 1:  l0 | l1<<2 | r0<<4 | l2<<6
+//      i = 3:  r1 | r2<<2 | l0<<4 | r0<<6        i = 4:  r1 | r2<<2 | r3<<4 | r0<<6
+// The word selector of windows 0 and 1 is the SAME base (the one just before the core), that of windows 3 and 4 too
+// (the one just after it), and the words are laid out so that a lookup is TWO 16-byte loads from one line:
+//      word 2 a + 0 / + 1      = windows 0 / 1 with selector a (base before the core)
+//      word 8 + 2 c + 0 / + 1  = windows 3 / 4 with selector c (base after the core)
+// (four scattered 8-byte loads of one line cost four address translations: on the 137 GB table the sites ran at
+// half the line rate.)
 // The table is derived from the seed table of length m without atomics: the lane of m-mer Z walks the
 // (pruned) tree of its 256 four-base extensions; the leaves are the four words of window i = 4 of entry Z,
 // and -- the index holds both strands, so a string and its reverse complement have the same count -- of
-// window i = 0 of entry rc(Z).  The same leaves, read as Z[0] . (Z[1..m) b1) . b2 b3 b4, are word Z[0] of
-// window i = 3 of four entries and, mirrored, word 3 - Z[0] of window i = 1 of four more.  Every word of the
-// table is written exactly once.
+// window i = 0 of entry rc(Z).  The same leaves, read as Z[0] . (Z[1..m) b1) . b2 b3 b4, are a 16-bit piece of
+// every word of window i = 3 of four entries and, mirrored, of window i = 1 of four more.  Every 16-bit piece
+// of the table is written exactly once.
 #define NM_QUAD_EXT 4u
 #define NM_QUAD_WORDS 16u
 #define NM_QUAD_OFFSETS 0x1Bu       /* window offsets an entry holds: bits 0, 1, 3, 4 */
@@ -788,7 +793,8 @@ NM_HD void nm_quad_build_one(const nm_view &ix, uint64_t Z, uint32_t m, uint64_t
         lo = 0; hi = ix.n;
         for (uint32_t j = 0; j < m && lo < hi; j++) nm_lf_interval<BIG>(ix, 3u - nm_seed_slot_code(Z, m, j), lo, hi);
     }
-    uint64_t w4[4] = {0, 0, 0, 0}, w0[4] = {0, 0, 0, 0}, p3[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
+    uint64_t w4[4] = {0, 0, 0, 0}, w0[4] = {0, 0, 0, 0};
+    uint16_t p3[4][4] = {{0}}, p1[4][4] = {{0}};           // [b1][selector]: 16-bit pieces of windows 3 and 1
     uint64_t l1[4], h1[4], l2[4], h2[4], l3[4], h3[4], l4[4], h4[4];
     nm_quad_children<BIG>(ix, lo, hi, l1, h1);
     for (uint32_t b1 = 0; b1 < 4; b1++) {
@@ -803,10 +809,10 @@ NM_HD void nm_quad_build_one(const nm_view &ix, uint64_t Z, uint32_t m, uint64_t
                 for (uint32_t b4 = 0; b4 < 4; b4++) {
                     if (h4[b4] - l4[b4] != 1) continue;    // Z b1 b2 b3 b4 occurs exactly once
                     const uint32_t c2 = 3u - b2, c3 = 3u - b3, c4 = 3u - b4;
-                    w4[b4] |= 1ULL << (b1 | (b2 << 2) | (b3 << 4));                  // i = 4 of Z:      r = b1 b2 b3 b4
-                    w0[3u - b1] |= 1ULL << (c4 | (c3 << 2) | (c2 << 4));             // i = 0 of rc(Z):  l = ~b4 ~b3 ~b2 ~b1
-                    p3[b1] |= 1ULL << (b2 | (b3 << 2) | (b4 << 4));                  // i = 3 of Z[1..m) b1: l0 = Z[0], r = b2 b3 b4
-                    p1[b1] |= 1ULL << (c4 | (c3 << 2) | (c2 << 4));                  // i = 1 of its rc:  l = ~b4 ~b3 ~b2, r0 = ~Z[0]
+                    w4[b1] |= 1ULL << (b2 | (b3 << 2) | (b4 << 4));                  // i = 4 of Z: r = b1 b2 b3 b4, selector r0 = b1
+                    w0[3u - b1] |= 1ULL << (c4 | (c3 << 2) | (c2 << 4));             // i = 0 of rc(Z): l = ~b4 ~b3 ~b2 ~b1, selector l3
+                    p3[b1][b2] |= (uint16_t)(1u << (b3 | (b4 << 2)));                // i = 3 of Z[1..m) b1: l0 = Z[0], r = b2 b3 b4, selector r0 = b2
+                    p1[b1][c2] |= (uint16_t)(1u << (c4 | (c3 << 2)));                // i = 1 of its rc: l = ~b4 ~b3 ~b2, r0 = ~Z[0], selector l2 = ~b2
                 }
             }
         }
@@ -817,14 +823,18 @@ NM_HD void nm_quad_build_one(const nm_view &ix, uint64_t Z, uint32_t m, uint64_t
     const uint64_t rcz = nm_slot_revcomp(Z, m);
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
-        quad[Z * NM_QUAD_WORDS + 12 + j] = w4[j];
-        quad[rcz * NM_QUAD_WORDS + j] = w0[j];
+        quad[Z * NM_QUAD_WORDS + 8 + 2 * j + 1] = w4[j];                                    // window 4, selector j
+        quad[rcz * NM_QUAD_WORDS + 2 * j] = w0[j];                                          // window 0, selector j
     }
     for (uint32_t b1 = 0; b1 < 4; b1++) {
         const uint64_t core = (zlo >> 1) | ((uint64_t)(b1 & 1u) << (m - 1)) |
                               (((zhi >> 1) | ((uint64_t)(b1 >> 1) << (m - 1))) << m);      // Z[1..m) b1
-        quad[core * NM_QUAD_WORDS + 8 + first] = p3[b1];
-        quad[nm_slot_revcomp(core, m) * NM_QUAD_WORDS + 4 + (3u - first)] = p1[b1];
+        const uint64_t rcc = nm_slot_revcomp(core, m);
+#pragma unroll
+        for (uint32_t sel = 0; sel < 4; sel++) {
+            ((uint16_t *)(quad + core * NM_QUAD_WORDS + 8 + 2 * sel))[first] = p3[b1][sel];       // window 3: piece l0 = Z[0]
+            ((uint16_t *)(quad + rcc * NM_QUAD_WORDS + 2 * sel + 1))[3u - first] = p1[b1][sel];   // window 1: piece r0 = ~Z[0]
+        }
     }
 }
 
@@ -839,16 +849,17 @@ NM_HD void nm_quad_index(const nm_window &w, uint32_t m, uint32_t b[4]) {
     const uint32_t c0 = nm_window_code(w, 0), c1 = nm_window_code(w, 1), c2 = nm_window_code(w, 2), c3 = nm_window_code(w, 3);
     const uint32_t r0 = nm_window_code(w, 4 + m), r1 = nm_window_code(w, 5 + m), r2 = nm_window_code(w, 6 + m), r3 = nm_window_code(w, 7 + m);
     b[0] = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
-    b[1] = c1 | (c2 << 2) | (c3 << 4) | (r0 << 6);
-    b[2] = r0 | (r1 << 2) | (r2 << 4) | (c3 << 6);
-    b[3] = r0 | (r1 << 2) | (r2 << 4) | (r3 << 6);
+    b[1] = c1 | (c2 << 2) | (r0 << 4) | (c3 << 6);
+    b[2] = r1 | (r2 << 2) | (c3 << 4) | (r0 << 6);
+    b[3] = r1 | (r2 << 2) | (r3 << 4) | (r0 << 6);
 }
 
-// the word of window g (of the entry at `entry`) that holds bit index b
-NM_HD const uint64_t *nm_quad_word(const uint64_t *entry, uint32_t g, uint32_t b) { return entry + 4 * g + (b >> 6); }
+// the two 16-byte halves of a lookup: windows 0, 1 (selector b[0] >> 6 == b[1] >> 6) and windows 3, 4
+NM_HD const uint64_t *nm_quad_pair01(const uint64_t *entry, const uint32_t b[4]) { return entry + 2 * (b[0] >> 6); }
+NM_HD const uint64_t *nm_quad_pair34(const uint64_t *entry, const uint32_t b[4]) { return entry + 8 + 2 * (b[2] >> 6); }
 
 // bit i of the result (i = 0, 1, 3, 4): the (m+4)-mer that starts i bases into the site occurs exactly once;
-// e[g] = the word nm_quad_word(entry, g, b[g])
+// e[0], e[1] = the pair at nm_quad_pair01, e[2], e[3] = the pair at nm_quad_pair34
 NM_HD uint32_t nm_quad_bits(const uint32_t b[4], const uint64_t e[4]) {
     return (uint32_t)((e[0] >> (b[0] & 63u)) & 1ULL) | ((uint32_t)((e[1] >> (b[1] & 63u)) & 1ULL) << 1) |
            ((uint32_t)((e[2] >> (b[2] & 63u)) & 1ULL) << 3) | ((uint32_t)((e[3] >> (b[3] & 63u)) & 1ULL) << 4);
@@ -939,8 +950,8 @@ NM_HD bool nm_second_chance(const nm_view &ix, const nm_window &w, uint32_t kmin
     nm_quad_index(w, m, b);
     const uint32_t reach = kmin - len;                     // windows p + i with i <= reach lie inside the kmin-mer
     const uint32_t usable = reach >= 4 ? 0x1Fu : (1u << (reach + 1)) - 1u;
-    const uint64_t e[4] = {usable & 1u ? *nm_quad_word(entry, 0, b[0]) : 0ULL, usable & 2u ? *nm_quad_word(entry, 1, b[1]) : 0ULL,
-                           usable & 8u ? *nm_quad_word(entry, 2, b[2]) : 0ULL, usable & 16u ? *nm_quad_word(entry, 3, b[3]) : 0ULL};
+    const uint64_t *p01 = nm_quad_pair01(entry, b), *p34 = nm_quad_pair34(entry, b);
+    const uint64_t e[4] = {p01[0], p01[1], usable & 0x18u ? p34[0] : 0ULL, usable & 0x18u ? p34[1] : 0ULL};
     return (nm_site_bits(w, m, b, e) & usable) != 0;
 }
 

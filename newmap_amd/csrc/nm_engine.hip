@@ -344,9 +344,10 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         nm_quad_index(win[s], m, bidx[s]);
         e[s][0] = e[s][1] = e[s][2] = e[s][3] = 0;
         if (go[s]) {
-            const uint64_t *entry = ix.quad + nm_quad_slot(win[s], m) * NM_QUAD_WORDS;     // one 128-byte line
-#pragma unroll
-            for (uint32_t g4 = 0; g4 < 4; g4++) e[s][g4] = *nm_quad_word(entry, g4, bidx[s][g4]);
+            const uint64_t *entry = ix.quad + nm_quad_slot(win[s], m) * NM_QUAD_WORDS;     // one 128-byte line, two 16-byte loads
+            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(nm_quad_pair01(entry, bidx[s]));
+            const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(nm_quad_pair34(entry, bidx[s]));
+            e[s][0] = a.x; e[s][1] = a.y; e[s][2] = c.x; e[s][3] = c.y;
             n_entries += 4;
         }
     }

@@ -118,8 +118,9 @@ uint64_t hs_check_quad(hs_index *ix) {
         else { nm_quad_build_one<false>(ix->v, Z, m, ix->quad.data()); nm_quad_build_one<false>(ix->v, Z, m, other.data()); }
     }
     uint64_t bad = 0;
-    for (uint64_t i = 0; i < cores * NM_QUAD_WORDS; i++)    // a word nobody wrote keeps its (different) fill pattern
-        if (ix->quad[i] != other[i]) bad += 1ULL << 32;
+    for (uint64_t i = 0; i < cores * NM_QUAD_WORDS; i++)    // a 16-bit piece nobody wrote keeps its (different) fill pattern
+        for (int h = 0; h < 4; h++)
+            if (((ix->quad[i] >> (16 * h)) & 0xFFFF) != ((other[i] >> (16 * h)) & 0xFFFF)) bad += 1ULL << 32;
     ix->v.quad = ix->quad.data();
     ix->v.quad_m = m;
     // stretches of m + 8 bases: L (4) . core (m) . R (4); the windows 0, 1, 3, 4 bases in are read from one entry.
@@ -139,7 +140,8 @@ uint64_t hs_check_quad(hs_index *ix) {
         const uint64_t *entry = ix->quad.data() + nm_quad_slot(win, m) * NM_QUAD_WORDS;
         uint32_t b[4];
         nm_quad_index(win, m, b);
-        const uint64_t e[4] = {*nm_quad_word(entry, 0, b[0]), *nm_quad_word(entry, 1, b[1]), *nm_quad_word(entry, 2, b[2]), *nm_quad_word(entry, 3, b[3])};
+        const uint64_t *p01 = nm_quad_pair01(entry, b), *p34 = nm_quad_pair34(entry, b);
+        const uint64_t e[4] = {p01[0], p01[1], p34[0], p34[1]};
         const uint32_t got = nm_quad_bits(b, e);
         if (got & ~NM_QUAD_OFFSETS) bad++;
         for (uint32_t i = 0; i < 5; i++) {
@@ -351,7 +353,8 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             const uint64_t *entry = v.quad + nm_quad_slot(win, m) * NM_QUAD_WORDS;
             uint32_t b[4];
             nm_quad_index(win, m, b);
-            const uint64_t e[4] = {*nm_quad_word(entry, 0, b[0]), *nm_quad_word(entry, 1, b[1]), *nm_quad_word(entry, 2, b[2]), *nm_quad_word(entry, 3, b[3])};
+            const uint64_t *p01 = nm_quad_pair01(entry, b), *p34 = nm_quad_pair34(entry, b);
+            const uint64_t e[4] = {p01[0], p01[1], p34[0], p34[1]};
             const uint64_t settled = nm_site_settled(nm_site_bits(win, m, b, e), d);
             if (!settled) continue;
             const uint32_t o = g * G, wi = o >> 5, sh = o & 31;

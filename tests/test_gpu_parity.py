@@ -450,6 +450,18 @@ def test_config3_full_size_properties(tmp_path, eng, monkeypatch):
                 got, _ = ix.min_unique_segment(sub, 20_000_000, kmin, kmax)
                 assert np.array_equal(got, plain), (kmin, table)
             ix.set_site_table(0)
+        # BASELINE configs[3]'s mode (fixed-k list mode, k = 36 and k = 100; the GRCh38 file itself is on no box) at this
+        # size: the sites route == the list kernel, and a list of several lengths too
+        sub = chr1[40_000_000:50_000_000]
+        for ks in ([36], [100], [24, 36, 50, 100]):
+            ix.set_list_via_range(True)
+            a, _ = ix.fixed_k_segment(sub, len(sub), ks)
+            assert ix.info()["last_range_kernel"] == 5
+            ix.set_list_via_range(False)
+            b, _ = ix.fixed_k_segment(sub, len(sub), ks)
+            ix.set_list_via_range(True)
+            assert np.array_equal(a, b), ks
+            assert (a[:-max(ks)] >= min(ks)).all()
     monkeypatch.setenv("NEWMAP_AMD_COARSE", "2")            # coarse probes forced (they find nothing to settle here)
     with eng.Index(idx, 0, "auto-small") as ix:             # the one-shot CLI's tables on the same index
         got, _ = ix.min_unique_segment(chr1[:30_000_000 + 199], 30_000_000, 20, 200)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--k", type=int, nargs="+", default=[36, 100])
     ap.add_argument("--lists", nargs="*", default=["24,36,50,100"], help="comma-separated length lists timed as well")
     ap.add_argument("--passes", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=100_000_000, help="positions per launch")
     a = ap.parse_args()
     import torch
     from newmap_amd import parallel, synth
@@ -42,12 +43,12 @@ def main():
     d_out = torch.zeros(n, dtype=torch.uint8, device=dev)
     d_st = torch.zeros(8, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    res = {"config": a.config, "positions": n}
+    res = {"config": a.config, "positions": n, "batch": a.batch}
     with Index(wd / "genome.awfmi", 0) as ix:
         for spec in [[k] for k in a.k] + [[int(x) for x in l.split(",")] for l in a.lists]:
             k = max(spec)
             tag = "k" + "_".join(str(x) for x in spec)
-            units = parallel.units_for_slice(lengths, 0, n, 10_000_000, k)
+            units = parallel.units_for_slice(lengths, 0, n, a.batch, k)
             segs = [(int(off[u.record]) + u.start, u.seg_len, u.count) for u in units]
             outs = {}
             for name, via in (("range_kernels", True), ("list_kernel", False)):

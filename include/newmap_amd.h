@@ -64,10 +64,10 @@ int nm_index_build_device(const char *fasta_path, const char *index_path, uint8_
 
 /* Read an index file and upload it to HBM of `device` (>= 0).  seed_len_override: -1 keeps the
  * length recorded in the file (the reference's --seed-length, default 12), -2 = automatic
- * (ceil(log4 n) + 2 bases, at most 16 and at most a quarter of the free HBM: with 288 GB the table
- * can be long enough that most positions resolve in ONE lookup; automatic mode also builds the LF
- * blocks and the quad table that the sites read), -3 = automatic with small tables (seed <= 15, quad cores <= 14, 17 GB at most: what a
- * one-shot run wants, the large ones cost 3 - 5 s of allocation), 0 disables the seed table, 1..16
+ * (ceil(log4 n) + 2 bases, at most 16 and at most a quarter of the free HBM; automatic mode also
+ * builds the LF blocks and the two quad tables that the sites read), -3 = automatic
+ * with small tables (seed <= 15, quad cores <= 13, 20 GB at most: what a one-shot run wants, the large
+ * ones can cost seconds of allocation), 0 disables the seed table, 1..16
  * forces a length.  Searches whose shortest length is below the table's get a second small
  * table of that length on first use.  Replaces createIndex()
  * (src/newmap-count.c:9-17) -- but returns an error instead of continuing with a bad handle. */

@@ -39,20 +39,10 @@ struct nm_rank_block {             /* 32 bytes, 64 BWT positions */
     uint64_t lo, hi;
 };
 
-/* Two-step rank block, built on the device when the index is opened (not stored in the file):
- * one 128-byte line per 64 BWT positions that answers BOTH "prepend x" and "prepend x, then y".
- * c1 = BWT[i] (the base in front of suffix i), c2 = BWT[LF(i)] (the base in front of that). */
-struct nm_rank2_block {
-    uint32_t cnt2[16];             /* rows before the block with (c1, c2) = (t >> 2, t & 3), superblock-relative */
-    uint32_t cnt1[4];              /* rows before the block with c1 = c, superblock-relative */
-    uint64_t c1lo, c1hi, c2lo, c2hi;
-    uint64_t valid1, valid2;       /* c1 is a base; c1 and c2 are both bases */
-};
-
 /* LF block, built on the device when the index is opened: per 64 BWT rows and per base c one
  * 16-byte entry {C[c] + occurrences of c before the block, indicator bits of c}.  LF_c(i) is then ONE
  * 16-byte load, one popcount and one add -- half the load instructions of the packed rank block
- * (walks with wide intervals are bound by the L1's divergent-address rate, DESIGN.md 7.3), no
+ * (walks with wide intervals are bound by the L1's divergent-address rate), no
  * superblock table, and separators need no exception path (their rows match no base).
  * Layout: entry (64-row block b, base c) at index b * 4 + c. */
 struct nm_lf_entry {
@@ -88,7 +78,6 @@ struct nm_file_header {            /* 1024 bytes */
 #ifdef __cplusplus
 static_assert(sizeof(nm_rank_block) == 32, "rank block must be 32 bytes");
 static_assert(sizeof(nm_strand_block) == 16, "strand block must be 16 bytes");
-static_assert(sizeof(nm_rank2_block) == 128, "two-step rank block must be one 128-byte line");
 static_assert(sizeof(nm_lf_entry) == 16, "LF entry must be 16 bytes");
 static_assert(sizeof(nm_file_header) == 1024, "header must be 1024 bytes");
 #endif

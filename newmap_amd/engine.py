@@ -41,8 +41,8 @@ class Index:
 
     def __init__(self, index_path, device: int | None = None, seed_length: int | str | None = None):
         """seed_length: None / "auto" = tables sized for throughput (seed ceil(log4 n)+2 <= 16 bases, quad table of
-        the same core length: up to 172 GB, 3 - 5 s to allocate), "auto-small" = the same kernels on tables of at
-        most 17 GB (what the one-shot CLI uses), "file" = the --seed-length recorded by `newmap index`,
+        cores as long as the free HBM allows: up to 180 GB), "auto-small" = the same kernels on tables of at
+        most 20 GB (what the one-shot CLI uses), "file" = the --seed-length recorded by `newmap index`,
         0 = no seed table, 1..16 = that length."""
         self._L = _lib.lib()
         self.path = Path(index_path)

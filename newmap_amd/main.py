@@ -96,8 +96,8 @@ def parse_subcommands(argv=None):
         parser.print_help()
         return
     args = parser.parse_args(argv)
-    # a command-line run opens the index once and searches once: small device tables (17 GB, 0.3 s to set up)
-    # instead of the throughput-sized ones of a resident handle (172 GB, 3 - 5 s to allocate).  Override with
+    # a command-line run opens the index once and searches once: small device tables (<= 20 GB, 0.3 - 0.6 s to set up)
+    # instead of the throughput-sized ones of a resident handle (up to 180 GB, seconds to allocate).  Override with
     # NEWMAP_AMD_SEED_LENGTH=auto.
     import os
     os.environ.setdefault("NEWMAP_AMD_SEED_LENGTH", "auto-small")

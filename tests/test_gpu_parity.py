@@ -361,7 +361,7 @@ def test_large_random_genome_properties(tmp_path, eng):
         tot2 = ix.count_from_sequence(rec, pos[longer], k[longer] - 1) + \
             ix.count_from_sequence(rcrec, len(rec) - pos[longer] - (k[longer] - 1), k[longer] - 1)
         assert (tot2 > 1).all()
-    with eng.Index(idx, 0, "auto-small") as small:          # the one-shot CLI's tables: same kernels, 17 GB
+    with eng.Index(idx, 0, "auto-small") as small:          # the one-shot CLI's tables: same kernels, <= 20 GB
         info = small.info()
         assert info["seed_length"] == 15 and info["quad_core_length"] == 13 and info["device_bytes"] < 21e9
         got, _ = small.min_unique_segment(rec[:20_000_199], 20_000_000, kmin, kmax)

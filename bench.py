@@ -69,7 +69,7 @@ def parse():
                     help="skip the extra passes at the reference's 10 M batch (profiling runs: one launch size per kernel)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 3 Gbp / 20:200 block (profiling runs)")
     ap.add_argument("--north-star-mbp", type=float, default=None, help="shrink the north-star genome (rehearsals)")
-    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the baseline sample (30 s: the whole 100 Mbp on the 128 threads of the GPU box)")
     ap.add_argument("--workdir", default=os.environ.get("NEWMAP_AMD_BENCH_DIR", "/tmp/newmap_amd_bench"))
     return ap.parse_args()
 

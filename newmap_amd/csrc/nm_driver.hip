@@ -378,6 +378,8 @@ struct FastFile {
     uint64_t n_elems = 0;
     nm_search_summary sum;
     std::atomic<long> outstanding{0};
+    std::atomic<bool> submitted_all{false};                // every unit of the file has been handed to the device
+    int last_record = -1;                                  // the last record that writes into it
     bool reported = false;
 };
 
@@ -645,6 +647,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
             for (size_t b = a + 1; b < d.files.size(); b++)
                 if (d.files[b].id == d.files[a].id) { d.files[a].n_elems = 0; break; }     // superseded by a later run
         for (FastRecord &rec : d.recs) if (rec.file >= 0 && d.files[rec.file].n_elems == 0) rec.file = -1;
+        for (size_t r = 0; r < d.recs.size(); r++) if (d.recs[r].file >= 0) d.files[d.recs[r].file].last_record = (int)r;
     }
     uint64_t total_positions = 0;
     for (FastRecord &rec : d.recs) if (rec.file >= 0) { rec.global = total_positions; total_positions += rec.n_bases; }
@@ -715,6 +718,19 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
 
     // ---- the units of my ranges, record by record
     std::vector<long> file_units(d.files.size(), 0);
+    size_t next_report = 0;
+    auto report_ready = [&]() {                                 // per-file summaries, in file order, as soon as a file has drained
+        while (next_report < d.files.size()) {
+            FastFile &f = d.files[next_report];
+            if (f.n_elems) {
+                if (!f.submitted_all.load() || f.outstanding.load() != 0) break;
+                f.sum.records = 1;
+                if (cb && d.error.load() == NM_OK && (world <= 1 || file_units[next_report])) cb(f.id.c_str(), &f.sum, user);
+                f.reported = true;
+            }
+            next_report++;
+        }
+    };
     for (size_t ri = 0; ri < d.recs.size() && rc == NM_OK && d.error.load() == NM_OK; ri++) {
         FastRecord &rec = d.recs[ri];
         if (rec.file < 0) continue;
@@ -785,9 +801,12 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
                     d.jobs.push_back(si);
                 }
                 d.cv_job.notify_one();
+                report_ready();
             }
         }
+        if (d.files[rec.file].last_record == (int)ri) d.files[rec.file].submitted_all = true;
     }
+    for (FastFile &f : d.files) f.submitted_all = true;         // (records this rank has no share of, early exits)
     // ---- drain
     {
         std::unique_lock<std::mutex> lk(d.mu);
@@ -810,6 +829,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
     if (d.stream) (void)hipStreamDestroy(d.stream);
     unmap();
     if (rc != NM_OK) return rc;
+    report_ready();
     // ---- summaries in file order (this rank's share when world > 1), then the totals
     nm_search_summary tot;
     memset(&tot, 0, sizeof tot);
@@ -829,7 +849,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
             if (rs.max_len > tot.max_len) tot.max_len = rs.max_len;
             if (rs.min_len < tot.min_len) tot.min_len = rs.min_len;
         }
-        if (cb && (world <= 1 || file_units[fi])) cb(f.id.c_str(), &rs, user);
+        if (cb && !f.reported && (world <= 1 || file_units[fi])) cb(f.id.c_str(), &rs, user);
     }
     if (total) *total = tot;
     return NM_OK;

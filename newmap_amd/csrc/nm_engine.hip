@@ -1032,7 +1032,10 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         uint32_t w1 = 1;
         while (w1 < 32 && (double)(1ULL << (2 * w1)) < 20.0 * (double)h.n) w1++;
         quad_small_m = w1 > NM_QUAD_EXT + 8 ? w1 - NM_QUAD_EXT : 8;
-        if (quad_small_m > 13) quad_small_m = 13;
+        if (quad_small_m > 13) {                             // capped: worth its memory only while most of its windows still occur once
+            quad_small_m = 13;
+            if (1.0 - exp(-(double)h.n / pow(4.0, (double)(quad_small_m + NM_QUAD_EXT))) > 0.15) quad_small_m = 0;
+        }
         if (const char *q = getenv("NEWMAP_AMD_QUAD_SMALL_M")) quad_small_m = (uint32_t)atoi(q);
         if (quad_small_m && quad_small_m < 8) quad_small_m = 8;
         if (quad_small_m >= quad_m) quad_small_m = 0;

@@ -124,9 +124,9 @@ uint64_t hs_check_quad(hs_index *ix) {
     ix->v.quad = ix->quad.data();
     ix->v.quad_m = m;
     // stretches of m + 8 bases: L (4) . core (m) . R (4); the windows 0, 1, 3, 4 bases in are read from one entry.
-    // All of them for short cores, a pseudo-random sample of 16 M otherwise.
+    // A pseudo-random sample of 4 M of them (all, if there are fewer).
     const uint32_t span = m + 8;
-    const uint64_t n_all = 1ULL << (2 * span), n_win = n_all <= (1ULL << 26) ? n_all : (1ULL << 24);
+    const uint64_t n_all = 1ULL << (2 * span), n_win = n_all <= (1ULL << 22) ? n_all : (1ULL << 22);
     uint64_t state = 0x9E3779B97F4A7C15ULL;
     for (uint64_t k = 0; k < n_win; k++) {
         uint64_t x = k;

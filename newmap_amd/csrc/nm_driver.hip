@@ -39,6 +39,7 @@
 #include <zlib.h>
 
 #include "../../include/newmap_amd.h"
+#include "nm_fasta_scan.hpp"
 #include "nm_internal.h"
 
 #define HIP_TRY(expr)                                                                         \
@@ -53,9 +54,7 @@
 
 namespace {
 
-inline bool is_space(unsigned char c) {      // what bytes.rstrip() removes (newmap/fasta.py:47)
-    return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f';
-}
+using nm_fasta::is_space;
 
 struct Slot {                                 // one segment in flight
     uint8_t *h_in = nullptr;                  // pinned
@@ -342,35 +341,9 @@ int run(Driver &d, const char *fasta_path) {
 
 // ------------------------------------------------------------------------------ parallel front-end
 
-// run fn(i) for i in [0, n) on up to `threads` threads (dynamic distribution)
-void parallel_for(size_t n, unsigned threads, const std::function<void(size_t)> &fn) {
-    if (n == 0) return;
-    if (threads <= 1 || n == 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
-    std::atomic<size_t> next{0};
-    auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); };
-    std::vector<std::thread> pool;
-    const unsigned t = threads < n ? threads : (unsigned)n;
-    for (unsigned k = 1; k < t; k++) pool.emplace_back(work);
-    work();
-    for (auto &th : pool) th.join();
-}
-
-unsigned host_threads() {
-    if (const char *e = getenv("NEWMAP_AMD_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)v; }
-    const unsigned hw = std::thread::hardware_concurrency();
-    return hw == 0 ? 4 : (hw > 32 ? 32 : hw);
-}
-
-struct FastRecord {
-    std::string id;
-    const unsigned char *data = nullptr, *end = nullptr;   // its data lines in the mapped file
-    std::vector<const unsigned char *> chunk;             // line starts that cut the data into pieces of ~FAST_CHUNK bytes
-    std::vector<uint64_t> before;                          // bases (stripped bytes) in front of each piece; back() = all of them
-    uint64_t n_bases = 0;
-    int file = -1;                                         // output file (run of adjacent records with one id), -1 = none
-    uint64_t file_offset = 0;                              // first element of this record inside that file
-    uint64_t global = 0;                                   // first position of this record in the position space of the job
-};
+using nm_fasta::parallel_for;
+using nm_fasta::host_threads;
+typedef nm_fasta::Record FastRecord;
 
 struct FastFile {
     std::string id, path;
@@ -382,25 +355,6 @@ struct FastFile {
     int last_record = -1;                                  // the last record that writes into it
     bool reported = false;
 };
-
-const size_t FAST_CHUNK = 4u << 20;
-
-// bases of the lines in [p, e): every line without its trailing whitespace (bytes.rstrip(), newmap/fasta.py:47);
-// dst != nullptr: copy them there.  p is a line start.
-uint64_t strip_lines(const unsigned char *p, const unsigned char *e, uint8_t *dst) {
-    uint64_t n = 0;
-    while (p < e) {
-        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(e - p));
-        const unsigned char *le = nl ? nl : e;
-        const unsigned char *q = le;
-        while (q > p && is_space(q[-1])) q--;
-        const size_t len = (size_t)(q - p);
-        if (dst && len) memcpy(dst + n, p, len);
-        n += len;
-        p = nl ? nl + 1 : e;
-    }
-    return n;
-}
 
 struct FastSlot {
     uint8_t *h_in = nullptr, *h_out = nullptr;
@@ -547,75 +501,8 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
     d.lookahead = d.kmax - 1;                                            // newmap/search.py:229
     auto unmap = [&]() { if (base) munmap((void *)base, size); };
 
-    // ---- header lines: '>' or ';' at a line start (newmap/fasta.py:59), found by a threaded scan
-    std::vector<size_t> heads;
-    {
-        const size_t slab = 32u << 20;
-        const size_t n_slabs = (size + slab - 1) / slab;
-        std::vector<std::vector<size_t>> found(n_slabs);
-        parallel_for(n_slabs, threads, [&](size_t k) {
-            const size_t lo = k * slab, hi = lo + slab < size ? lo + slab : size;
-            for (const char c : {'>', ';'}) {
-                const unsigned char *p = base + lo;
-                while (p < base + hi) {
-                    p = (const unsigned char *)memchr(p, c, (size_t)(base + hi - p));
-                    if (!p) break;
-                    const size_t i = (size_t)(p - base);
-                    if (i == 0 || base[i - 1] == '\n') found[k].push_back(i);
-                    p++;
-                }
-            }
-        });
-        for (auto &v : found) heads.insert(heads.end(), v.begin(), v.end());
-        std::sort(heads.begin(), heads.end());
-    }
-    // ---- records (ids: first whitespace-delimited token minus its first byte, newmap/fasta.py:75; data in front of any
-    // header has the id "")
-    auto add_record = [&](const std::string &id, size_t lo, size_t hi) {
-        FastRecord r;
-        r.id = id;
-        r.data = base + lo;
-        r.end = base + hi;
-        d.recs.push_back(std::move(r));
-    };
-    if (heads.empty() || heads[0] > 0) add_record("", 0, heads.empty() ? size : heads[0]);
-    for (size_t h = 0; h < heads.size(); h++) {
-        const unsigned char *p = base + heads[h];
-        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', size - heads[h]);
-        size_t len = nl ? (size_t)(nl - p) : size - heads[h];
-        while (len && is_space(p[len - 1])) len--;
-        size_t e = 0;
-        while (e < len && !is_space(p[e])) e++;
-        const size_t data_lo = nl ? (size_t)(nl - base) + 1 : size;
-        add_record(std::string((const char *)p + 1, e ? e - 1 : 0), data_lo, h + 1 < heads.size() ? heads[h + 1] : size);
-    }
-    // ---- pass 1: pieces of every record and the bases in front of each (threaded count)
-    struct Piece { size_t rec, idx; };
-    std::vector<Piece> pieces;
-    for (size_t r = 0; r < d.recs.size(); r++) {
-        FastRecord &rec = d.recs[r];
-        const unsigned char *p = rec.data;
-        while (p < rec.end) {
-            rec.chunk.push_back(p);
-            const unsigned char *q = p + FAST_CHUNK < rec.end ? p + FAST_CHUNK : rec.end;
-            if (q < rec.end) {                                  // cut at the next line start
-                const unsigned char *nl = (const unsigned char *)memchr(q, '\n', (size_t)(rec.end - q));
-                q = nl ? nl + 1 : rec.end;
-            }
-            p = q;
-        }
-        rec.chunk.push_back(rec.end);
-        rec.before.assign(rec.chunk.size(), 0);
-        for (size_t i = 0; i + 1 < rec.chunk.size(); i++) pieces.push_back({r, i});
-    }
-    parallel_for(pieces.size(), threads, [&](size_t k) {
-        FastRecord &rec = d.recs[pieces[k].rec];
-        rec.before[pieces[k].idx + 1] = strip_lines(rec.chunk[pieces[k].idx], rec.chunk[pieces[k].idx + 1], nullptr);
-    });
-    for (FastRecord &rec : d.recs) {
-        for (size_t i = 1; i < rec.before.size(); i++) rec.before[i] += rec.before[i - 1];
-        rec.n_bases = rec.before.empty() ? 0 : rec.before.back();
-    }
+    // ---- records, their pieces, the bases in front of each piece (nm_fasta_scan.hpp; threaded)
+    d.recs = nm_fasta::scan(base, size, threads);
     // ---- output files: one per run of adjacent records (that hold data and are wanted) with one id; an id that
     // comes back later truncates the file again (newmap/search.py:268-305), so only its LAST run is searched
     auto wanted = [&](const std::string &id) {
@@ -744,15 +631,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         for (auto &part : mine) {
             // strip the pieces that hold [part.first, part.second + lookahead) into rec_buf
             const uint64_t need_hi = part.second + d.lookahead < rec.n_bases ? part.second + d.lookahead : rec.n_bases;
-            size_t c_lo = (size_t)(std::upper_bound(rec.before.begin(), rec.before.end(), part.first) - rec.before.begin()) - 1;
-            size_t c_hi = (size_t)(std::lower_bound(rec.before.begin(), rec.before.end(), need_hi) - rec.before.begin());
-            if (c_hi > rec.chunk.size() - 1) c_hi = rec.chunk.size() - 1;
-            const uint64_t buf_base = rec.before[c_lo];
-            rec_buf.resize((size_t)(rec.before[c_hi] - buf_base));
-            parallel_for(c_hi - c_lo, threads, [&](size_t k) {
-                const size_t c = c_lo + k;
-                strip_lines(rec.chunk[c], rec.chunk[c + 1], rec_buf.data() + (rec.before[c] - buf_base));
-            });
+            const uint64_t buf_base = nm_fasta::materialize(rec, part.first, need_hi, threads, rec_buf);
             for (uint64_t p = part.first; p < part.second && rc == NM_OK && d.error.load() == NM_OK; p += d.batch) {
                 const uint64_t count = part.second - p < d.batch ? part.second - p : d.batch;
                 const uint64_t seg_len = (p + count + d.lookahead < rec.n_bases ? p + count + d.lookahead : rec.n_bases) - p;

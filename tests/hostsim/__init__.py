@@ -16,10 +16,11 @@ def lib():
         return _lib
     src = _HERE / "hostsim.cpp"
     core = _HERE.parent.parent / "newmap_amd" / "csrc" / "nm_core.h"
-    stale = (not _SO.exists() or _SO.stat().st_mtime < max(src.stat().st_mtime, core.stat().st_mtime))
+    scan = core.parent / "nm_fasta_scan.hpp"
+    stale = (not _SO.exists() or _SO.stat().st_mtime < max(src.stat().st_mtime, core.stat().st_mtime, scan.stat().st_mtime))
     if stale:
         _SO.parent.mkdir(exist_ok=True)
-        subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-o", str(_SO), str(src)],
+        subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unknown-pragmas", "-o", str(_SO), str(src)],
                        check=True)
     L = ctypes.CDLL(str(_SO))
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
@@ -41,6 +42,14 @@ def lib():
     L.hs_min_unique.argtypes = [vp, vp, u64, u64, u32, u32, i32, i32, vp, vp]
     L.hs_repeat_probes.restype = u64
     L.hs_repeat_probes.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, vp, vp]
+    L.hs_fasta_open.restype = vp
+    L.hs_fasta_open.argtypes = [ctypes.c_char_p, u32, u64]
+    L.hs_fasta_close.argtypes = [vp]
+    L.hs_fasta_count.restype = u64
+    L.hs_fasta_count.argtypes = [vp]
+    L.hs_fasta_record.restype = u64
+    L.hs_fasta_record.argtypes = [vp, u64, ctypes.c_char_p, u64, vp]
+    L.hs_fasta_read.argtypes = [vp, u64, u64, u64, vp]
     L.hs_build_quad2.restype = i32
     L.hs_build_quad2.argtypes = [vp, u32]
     L.hs_valid_bits.argtypes = [vp, u64, u32, vp]
@@ -146,6 +155,37 @@ class HostSim:
         out = np.zeros(max(num_kmers, 1), dtype=np.uint32)
         lib().hs_upper(buf.ctypes.data, buf.size, num_kmers, kmax, out.ctypes.data)
         return out[:num_kmers]
+
+
+def fasta_scan(path, threads=4, chunk_bytes=4 << 20, ranges=()):
+    """newmap_amd/csrc/nm_fasta_scan.hpp (the FASTA scan of the native driver's parallel front-end) on a file:
+    [(id bytes, data bytes)] of every record that holds data, as newmap_amd.fasta.fasta_records yields them; `ranges`
+    = (record index among ALL scanned records, lo, hi) triples read back separately -> list of bytes."""
+    L = lib()
+    h = L.hs_fasta_open(str(path).encode(), threads, chunk_bytes)
+    if not h:
+        raise OSError(f"cannot scan {path}")
+    try:
+        out, pieces = [], []
+        n = int(L.hs_fasta_count(h))
+        lens = []
+        for i in range(n):
+            idbuf = ctypes.create_string_buffer(4096)
+            nb = ctypes.c_uint64(0)
+            idlen = int(L.hs_fasta_record(h, i, idbuf, 4096, ctypes.byref(nb)))
+            lens.append(int(nb.value))
+            if nb.value == 0:
+                continue
+            data = np.zeros(nb.value, dtype=np.uint8)
+            L.hs_fasta_read(h, i, 0, nb.value, data.ctypes.data)
+            out.append((idbuf.raw[:idlen], data.tobytes()))
+        for i, lo, hi in ranges:
+            piece = np.zeros(hi - lo, dtype=np.uint8)
+            L.hs_fasta_read(h, i, lo, hi, piece.ctypes.data)
+            pieces.append(piece.tobytes())
+        return (out, lens, pieces) if ranges else out
+    finally:
+        L.hs_fasta_close(h)
 
 
 def valid_bits(seq: bytes, kmin: int) -> np.ndarray:

@@ -11,6 +11,11 @@
 
 #define NM_HD static inline
 #include "../../newmap_amd/csrc/nm_core.h"
+#include "../../newmap_amd/csrc/nm_fasta_scan.hpp"
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 struct hs_index {
     nm_file_header h;
@@ -553,6 +558,53 @@ int hs_multi(hs_index **ixs, uint32_t n_idx, const uint8_t **seqs, uint32_t n_se
         if (err) { status[1] = 1; if (p < status[2]) status[2] = p; }
     }
     return status[1] ? 8 : 0;
+}
+
+// ---- the FASTA scan of the native driver's parallel front-end (newmap_amd/csrc/nm_fasta_scan.hpp) ----
+struct hs_fasta {
+    const unsigned char *base = nullptr;
+    size_t size = 0;
+    std::vector<nm_fasta::Record> recs;
+    unsigned threads = 1;
+};
+
+hs_fasta *hs_fasta_open(const char *path, unsigned threads, uint64_t chunk_bytes) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return nullptr; }
+    hs_fasta *h = new hs_fasta();
+    h->size = (size_t)st.st_size;
+    h->threads = threads;
+    if (h->size) {
+        void *m = mmap(nullptr, h->size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); delete h; return nullptr; }
+        h->base = (const unsigned char *)m;
+    }
+    close(fd);
+    h->recs = nm_fasta::scan(h->base, h->size, threads, (size_t)chunk_bytes);
+    return h;
+}
+void hs_fasta_close(hs_fasta *h) {
+    if (!h) return;
+    if (h->base) munmap((void *)h->base, h->size);
+    delete h;
+}
+uint64_t hs_fasta_count(hs_fasta *h) { return h->recs.size(); }
+// id (copied, NUL-terminated, at most cap - 1 bytes) and number of bases of record i; returns the id's length
+uint64_t hs_fasta_record(hs_fasta *h, uint64_t i, char *id_out, uint64_t cap, uint64_t *n_bases) {
+    const nm_fasta::Record &r = h->recs[i];
+    const size_t n = r.id.size() < cap - 1 ? r.id.size() : (size_t)cap - 1;
+    memcpy(id_out, r.id.data(), n);
+    id_out[n] = 0;
+    *n_bases = r.n_bases;
+    return r.id.size();
+}
+// bases [lo, hi) of record i -> out (hi - lo bytes)
+void hs_fasta_read(hs_fasta *h, uint64_t i, uint64_t lo, uint64_t hi, uint8_t *out) {
+    std::vector<uint8_t> buf;
+    const uint64_t b0 = nm_fasta::materialize(h->recs[i], lo, hi, h->threads, buf);
+    memcpy(out, buf.data() + (lo - b0), (size_t)(hi - lo));
 }
 
 void hs_upper(const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmax, uint32_t *out) {

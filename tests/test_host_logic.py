@@ -48,8 +48,8 @@ def test_product_never_imports_the_oracle():
     for p in (ROOT / "newmap_amd").rglob("*"):
         if p.suffix in (".py", ".h", ".hpp", ".cpp", ".hip"):
             hits = [m.group(0) for m in bad.finditer(p.read_text())]
-            # nm_core.h names the host simulator in a comment only
-            hits = [h for h in hits if not (p.name == "nm_core.h" and h == "hostsim")]
+            # nm_core.h and nm_fasta_scan.hpp name the host simulator in a comment only
+            hits = [h for h in hits if not (p.name in ("nm_core.h", "nm_fasta_scan.hpp") and h == "hostsim")]
             assert not hits, (p, hits)
 
 
@@ -134,3 +134,46 @@ def test_synthetic_generators_are_seeded():
     assert t.size == 200_000
     recs = synth.config_genome("c3", 1.0)
     assert len(recs) == 24 and recs[0][0] == "chr1" and recs[-1][0] == "chrY"
+
+
+def test_native_fasta_scan_equals_python_reader(tmp_path, golden_host):
+    """csrc/nm_fasta_scan.hpp -- the threaded FASTA scan of the native driver's parallel front-end -- yields the records
+    of newmap_amd.fasta.fasta_records (itself pinned by the reference-generated segment fixtures): ids, data with every
+    line stripped of trailing whitespace, ';' headers, data in front of any header, records without data, CR LF, a
+    last line without newline; for pieces of a few bytes and of megabytes, 1 and 5 threads; and arbitrary ranges of a
+    record read back on their own (what a rank of a sharded job does)."""
+    import io
+    import numpy as np
+    from newmap_amd.fasta import fasta_records
+    from tests import hostsim
+    rng = np.random.default_rng(3)
+    body = bytes(np.frombuffer(b"ACGTNacgtn", np.uint8)[rng.integers(0, 10, 40_000)])
+    texts = [
+        b"", b"\n\n", b">only header\n", b"ACGT", b"ACGT\n", b">a\nAC GT \t\n>b\n\n>c desc here\nAAA\r\nCC\r\n",
+        b"ACGTACGTTTGACCA" + body[:200] + b"\n>r1 first\n" + body[200:1500] + b"\n" + body[1500:1700] + b"  \n"
+        b">r1 again\n" + body[1700:2500] + b"\n;r2\r\n" + body[2500:3300] + b"\r\n>empty\n>r3\n" + body[3300:6000] +
+        b"\n>r1\n" + body[6000:6100] + b"\n\n>r4 x\n" + b"\n".join(body[6100 + i:6100 + i + 61] for i in range(0, 2900, 61)) + b"\nNNNN",
+        b">big one\n" + b"\n".join(body[i:i + 70] for i in range(0, len(body), 70)) + b"\n>x>y;z\n" + body[:999] + b" \n \n" + body[999:1500],
+        b";c\n>\nAC\n> spaced id\nGG\n>\tt\nTT\n",
+    ]
+    for c in golden_host.get("segments", [])[:20]:
+        if "fasta" in c:
+            texts.append(c["fasta"].encode("latin-1"))
+    for k, text in enumerate(texts):
+        fa = tmp_path / f"f{k}.fa"
+        fa.write_bytes(text)
+        want = list(fasta_records(io.BytesIO(text)))
+        for threads, chunk in ((1, 4 << 20), (5, 7), (3, 64), (4, 1000)):
+            got = hostsim.fasta_scan(fa, threads, chunk)
+            assert got == want, (k, threads, chunk)
+    # ranges of a record, read back alone
+    fa = tmp_path / "f7.fa"
+    want = list(fasta_records(io.BytesIO(texts[7])))
+    data = want[0][1]
+    ranges = [(0, 0, 1), (0, 5, 5000), (0, len(data) - 1, len(data)), (0, 12345, 12346), (0, 0, len(data))] + \
+             [(0, int(a), int(a) + int(b)) for a, b in zip(rng.integers(0, len(data) - 3000, 20), rng.integers(1, 3000, 20))]
+    for threads, chunk in ((1, 50), (4, 333), (2, 1 << 20)):
+        _, lens, pieces = hostsim.fasta_scan(fa, threads, chunk, ranges)
+        assert lens[0] == len(data)
+        for (i, lo, hi), piece in zip(ranges, pieces):
+            assert piece == data[lo:hi], (threads, chunk, lo, hi)

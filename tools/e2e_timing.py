@@ -65,8 +65,8 @@ def main():
         import ctypes
         from newmap_amd import _lib
         L = _lib.lib()
-        seg_in = np.zeros(10_000_000 + kmax - 1, dtype=np.uint8)
         seg_out = np.zeros(10_000_000, dtype=np.uint8)
+        seq_c = np.ascontiguousarray(seq)
         amb, bad = ctypes.c_uint64(0), ctypes.c_uint64(0)
         with Index(idx, 0) as ix:
             same = True
@@ -74,14 +74,13 @@ def main():
                 t0 = time.time()
                 for p in range(0, n - n % 10_000_000, 10_000_000):
                     m = min(10_000_000 + kmax - 1, n - p)
-                    seg_in[:m] = seq[p:p + m]
-                    rc = L.nm_min_unique_segment(ix.handle, seg_in.ctypes.data, m, 10_000_000, kmin, kmax, 0, 1, 1,
+                    rc = L.nm_min_unique_segment(ix.handle, seq_c.ctypes.data + p, m, 10_000_000, kmin, kmax, 0, 1, 1,
                                                  seg_out.ctypes.data, ctypes.byref(amb), ctypes.byref(bad))
                     assert rc == 0
                     if rep == 2:
                         same = same and bool(np.array_equal(seg_out, got[p:p + 10_000_000]))
                 dt2 = time.time() - t0
-            res["host_api_reused_buffers_positions_per_s"] = (n - n % 10_000_000) / dt2     # (includes the copy into seg_in)
+            res["host_api_reused_buffers_positions_per_s"] = (n - n % 10_000_000) / dt2     # (third pass: every page touched before)
             res["host_api_reused_buffers_equal_cli_files"] = same
     print(json.dumps(res))
     if args.out:

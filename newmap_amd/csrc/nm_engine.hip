@@ -674,8 +674,6 @@ struct nm_index {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;           // repeat probes of repeat-rich input run here, beside k_sites (launch_sites)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t copy = nullptr;           // D2H copies of the host-buffer calls, beside the kernels of the next chunk
-    std::vector<hipEvent_t> chunk_ev;     // one per chunk of a host-buffer call (grown on demand)
     // scratch owned by the handle (grown on demand)
     nm_buffer enc, seq, out, status, ks, starts, lens, work, settled, coarse, need;
     uint64_t coarse_min = 32ull << 20;    // launches of at least this many positions also run the coarse probes (NEWMAP_AMD_COARSE_MIN) ...
@@ -943,7 +941,6 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         (void)hipGetLastError();                               // (without them the probes simply follow k_sites on one stream)
         ix->side = nullptr;
     }
-    if (hipStreamCreateWithFlags(&ix->copy, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ix->copy = nullptr; }
 
     const uint64_t rank_bytes = h.n_rank_blocks * sizeof(nm_rank_block);
     const uint64_t strand_bytes = h.n_strand_blocks * sizeof(nm_strand_block);
@@ -1080,8 +1077,6 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (ix->d_seen_latch) (void)hipFree(ix->d_seen_latch);
     for (auto &pool : ix->ev_pool) for (hipEvent_t e : pool) (void)hipEventDestroy(e);
     if (ix->side) { (void)hipStreamSynchronize(ix->side); (void)hipStreamDestroy(ix->side); }
-    if (ix->copy) { (void)hipStreamSynchronize(ix->copy); (void)hipStreamDestroy(ix->copy); }
-    for (hipEvent_t e : ix->chunk_ev) (void)hipEventDestroy(e);
     if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
     if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -1501,73 +1496,6 @@ static int nm_stage_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, 
     return NM_OK;
 }
 
-// A host-buffer segment in CHUNKS of positions, so that the three legs of the call overlap: while the kernels of chunk c
-// run, the bytes of chunk c + 1 arrive (same stream, behind them) and the elements of chunk c - 1 leave (copy stream,
-// other DMA engine).  A position's element does not depend on how a segment is cut (Appendix A.2: a chunk brings its own
-// `lookahead` bytes), the ambiguous counts add up, the first absent k-mer is the one of the first chunk that has one.
-// launch(d_seq, seg_len, count, d_out, d_status): the device-resident call for one chunk.
-template <class Launch>
-static int nm_run_chunked(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint64_t lookahead, int elem_bytes,
-                          void *out, uint64_t *n_ambiguous, uint64_t *bad_pos, Launch launch) {
-    int rc;
-    HIP_TRY(hipSetDevice(ix->device));
-    const uint64_t target = 2500000;
-    uint64_t n_chunks = ix->copy && num_kmers >= 2 * target ? (num_kmers + target - 1) / target : 1;
-    if (n_chunks > 16) n_chunks = 16;
-    uint64_t per = (num_kmers + n_chunks - 1) / n_chunks;
-    per = (per + 4095) / 4096 * 4096;                              // (chunks start on aligned elements and encoded words)
-    n_chunks = per ? (num_kmers + per - 1) / per : 1;
-    if (n_chunks == 0) n_chunks = 1;
-    const uint64_t out_bytes = num_kmers * (uint64_t)elem_bytes;
-    if ((rc = nm_grow(ix->seq, seq_len + 64)) != NM_OK) return rc;
-    if ((rc = nm_grow(ix->out, out_bytes + 64)) != NM_OK) return rc;
-    if ((rc = nm_grow(ix->status, n_chunks * NM_STATUS_WORDS * sizeof(uint64_t))) != NM_OK) return rc;
-    while (ix->chunk_ev.size() < n_chunks) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ix->chunk_ev.push_back(e);
-    }
-    std::vector<uint64_t> status(n_chunks * NM_STATUS_WORDS, 0);
-    hipStream_t st = ix->stream, cp = n_chunks > 1 ? ix->copy : ix->stream;
-    uint64_t copied = 0;                                          // bytes of seq on the device so far
-    for (uint64_t c = 0; c < n_chunks; c++) {
-        const uint64_t a = c * per, cnt = num_kmers - a < per ? num_kmers - a : per;
-        const uint64_t end = c + 1 == n_chunks ? seq_len : (a + cnt + lookahead < seq_len ? a + cnt + lookahead : seq_len);
-        if (end > copied) {
-            HIP_TRY(hipMemcpyAsync((uint8_t *)ix->seq.p + copied, seq + copied, end - copied, hipMemcpyHostToDevice, st));
-            copied = end;
-        }
-        uint64_t *d_status = (uint64_t *)ix->status.p + c * NM_STATUS_WORDS;
-        if ((rc = launch((const uint8_t *)ix->seq.p + a, end - a, cnt, (uint8_t *)ix->out.p + a * (uint64_t)elem_bytes, d_status)) != NM_OK) {
-            (void)hipStreamSynchronize(st);
-            if (cp != st) (void)hipStreamSynchronize(cp);
-            return rc;
-        }
-        if (cp != st) {
-            HIP_TRY(hipEventRecord(ix->chunk_ev[c], st));
-            HIP_TRY(hipStreamWaitEvent(cp, ix->chunk_ev[c], 0));
-        }
-        if (cnt) HIP_TRY(hipMemcpyAsync((uint8_t *)out + a * (uint64_t)elem_bytes, (const uint8_t *)ix->out.p + a * (uint64_t)elem_bytes,
-                                        cnt * (uint64_t)elem_bytes, hipMemcpyDeviceToHost, cp));
-        HIP_TRY(hipMemcpyAsync(status.data() + c * NM_STATUS_WORDS, d_status, NM_STATUS_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, cp));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (cp != st) HIP_TRY(hipStreamSynchronize(cp));
-    uint64_t amb = 0;
-    for (uint64_t c = 0; c < n_chunks; c++) amb += status[c * NM_STATUS_WORDS];
-    if (n_ambiguous) *n_ambiguous = amb;
-    if (bad_pos) *bad_pos = ~0ULL;
-    for (uint64_t c = 0; c < n_chunks; c++)
-        if (status[c * NM_STATUS_WORDS + 1]) {
-            const uint64_t at = c * per + status[c * NM_STATUS_WORDS + 2];
-            if (bad_pos) *bad_pos = at;
-            nm_set_error("a generated k-mer was not found in the index (first at segment position %llu); "
-                         "possibly a mismatch between the sequence and the index", (unsigned long long)at);
-            return NM_E_KMER_NOT_FOUND;
-        }
-    return NM_OK;
-}
-
 extern "C" int nm_min_unique_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
                                      uint32_t kmin, uint32_t kmax, uint32_t initial_len, int use_revcomp,
                                      int elem_bytes, void *out, uint64_t *n_ambiguous, uint64_t *bad_pos) {
@@ -1575,11 +1503,12 @@ extern "C" int nm_min_unique_segment(nm_index *ix, const uint8_t *seq, uint64_t 
     int rc = nm_check_segment_args(ix, seq_len, num_kmers, elem_bytes);
     if (rc != NM_OK) return rc;
     if ((!seq && seq_len) || (!out && num_kmers)) { nm_set_error("null buffer"); return NM_E_ARGUMENT; }
-    if (kmin < 1 || kmin > kmax) { nm_set_error("need 1 <= kmin <= kmax (got %u, %u)", kmin, kmax); return NM_E_ARGUMENT; }
-    return nm_run_chunked(ix, seq, seq_len, num_kmers, (uint64_t)kmax - 1, elem_bytes, out, n_ambiguous, bad_pos,
-                          [&](const uint8_t *d_seq, uint64_t seg_len, uint64_t cnt, void *d_out, uint64_t *d_status) {
-                              return nm_min_unique_segment_dev(ix, d_seq, seg_len, cnt, kmin, kmax, use_revcomp, elem_bytes, d_out, d_status, ix->stream);
-                          });
+    const uint64_t out_bytes = num_kmers * (uint64_t)elem_bytes;
+    if ((rc = nm_stage_segment(ix, seq, seq_len, out_bytes)) != NM_OK) return rc;
+    rc = nm_min_unique_segment_dev(ix, ix->seq.p, seq_len, num_kmers, kmin, kmax, use_revcomp, elem_bytes, ix->out.p,
+                                   (uint64_t *)ix->status.p, ix->stream);
+    if (rc != NM_OK) return rc;
+    return nm_finish_segment(ix, out, out_bytes, n_ambiguous, bad_pos);
 }
 
 extern "C" int nm_fixed_k_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
@@ -1588,13 +1517,12 @@ extern "C" int nm_fixed_k_segment(nm_index *ix, const uint8_t *seq, uint64_t seq
     int rc = nm_check_segment_args(ix, seq_len, num_kmers, elem_bytes);
     if (rc != NM_OK) return rc;
     if ((!seq && seq_len) || (!out && num_kmers)) { nm_set_error("null buffer"); return NM_E_ARGUMENT; }
-    if (!ks || nk == 0) { nm_set_error("empty k list"); return NM_E_ARGUMENT; }
-    uint32_t kmax = 0;
-    for (uint32_t i = 0; i < nk; i++) if (ks[i] > kmax) kmax = ks[i];
-    return nm_run_chunked(ix, seq, seq_len, num_kmers, kmax ? (uint64_t)kmax - 1 : 0, elem_bytes, out, n_ambiguous, bad_pos,
-                          [&](const uint8_t *d_seq, uint64_t seg_len, uint64_t cnt, void *d_out, uint64_t *d_status) {
-                              return nm_fixed_k_segment_dev(ix, d_seq, seg_len, cnt, ks, nk, use_revcomp, elem_bytes, d_out, d_status, ix->stream);
-                          });
+    const uint64_t out_bytes = num_kmers * (uint64_t)elem_bytes;
+    if ((rc = nm_stage_segment(ix, seq, seq_len, out_bytes)) != NM_OK) return rc;
+    rc = nm_fixed_k_segment_dev(ix, ix->seq.p, seq_len, num_kmers, ks, nk, use_revcomp, elem_bytes, ix->out.p,
+                                (uint64_t *)ix->status.p, ix->stream);
+    if (rc != NM_OK) return rc;
+    return nm_finish_segment(ix, out, out_bytes, n_ambiguous, bad_pos);
 }
 
 extern "C" int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,

@@ -50,7 +50,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -62,6 +62,9 @@ def parse():
                     help="device tables: auto (default: sized for throughput), auto-small (<= 20 GB, what the one-shot CLI uses), "
                          "file (the index's seed length, 12), or a seed length 0..16")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3, 4, 5],
+                    help="the segments of a pass are launched round-robin on this many HIP streams (the handle keeps one set of launch "
+                         "scratch per stream, so neighbouring segments overlap); passes of one segment use one stream")
     ap.add_argument("--index-builder", choices=["host", "device"], default="device",
                     help="suffix sort on the GPU (default) or on the host cores (same index file; not timed in `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -71,7 +74,7 @@ def parse():
     ap.add_argument("--north-star-mbp", type=float, default=None, help="shrink the north-star genome (rehearsals)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the baseline sample (30 s: the whole 100 Mbp on the 128 threads of the GPU box)")
     ap.add_argument("--workdir", default=os.environ.get("NEWMAP_AMD_BENCH_DIR", "/tmp/newmap_amd_bench"))
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------ workloads
@@ -226,12 +229,20 @@ class Run:
         torch.cuda.synchronize()
         self.t_upload = time.time() - t0
         self.stream = torch.cuda.current_stream().cuda_stream
+        self._extra_streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1) - 1)]
+        self.streams = [self.stream] + [s_.cuda_stream for s_ in self._extra_streams]
         self.segs = [(int(so), u.seg_len, u.count, int(oo), i) for i, (u, so, oo) in enumerate(zip(units, seg_off[:-1], out_off[:-1]))]
 
-    def step(self, segs=None):
+    def step(self, segs=None, streams=None):
+        """one pass: every segment once.  Segments are independent (own input, output and status row); with several
+        streams they are dealt round-robin, a stream keeps the order of its own segments"""
         sp, op, st = self.d_seq.data_ptr(), self.d_out.data_ptr(), self.d_status.data_ptr()
-        for (so, seg_len, cnt, oo, i) in (self.segs if segs is None else segs):
-            self.ix.min_unique_segment_dev(sp + so, seg_len, cnt, self.KMIN, self.KMAX, True, 1, op + oo, st + 64 * i, self.stream)
+        segs = self.segs if segs is None else segs
+        streams = self.streams if streams is None else streams
+        if len(segs) < 2:
+            streams = streams[:1]
+        for j, (so, seg_len, cnt, oo, i) in enumerate(segs):
+            self.ix.min_unique_segment_dev(sp + so, seg_len, cnt, self.KMIN, self.KMAX, True, 1, op + oo, st + 64 * i, streams[j % len(streams)])
 
     def max_over_ranks(self, x: float) -> float:
         if self.world == 1:
@@ -247,30 +258,49 @@ class Run:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
-    def timed(self, steps, warmup, segs=None):
+    def timed(self, steps, warmup, segs=None, kernel_events=True):
+        """`steps` passes between barrier + synchronize on both sides.  Kernel times (HIP events on the launch stream,
+        read_timing kinds 0 and 1) are taken in the timed passes themselves when a pass runs on ONE stream (the headline:
+        one launch per pass); passes whose segments overlap on several streams get one extra pass on one stream for
+        them afterwards (outside `elapsed`), since events around overlapping kernels time each other's work."""
         torch = self.torch
+        n_segs = len(self.segs if segs is None else segs)
+        overlapped = len(self.streams) > 1 and n_segs > 1
         for _ in range(warmup):
             self.step(segs)
         torch.cuda.synchronize()
         self.barrier()
-        self.ix.set_timing(True)
+        if kernel_events and not overlapped:
+            self.ix.set_timing(True)
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step(segs)
         torch.cuda.synchronize()
         self.barrier()
         elapsed = time.perf_counter() - t0
-        k0 = self.ix.read_timing(0)
-        k1 = self.ix.read_timing(1)
-        self.ix.set_timing(False)
+        k0 = k1 = (0, 0.0, 0.0)
+        if kernel_events:
+            if overlapped:
+                self.ix.set_timing(True)
+                self.step(segs, self.streams[:1])
+                torch.cuda.synchronize()
+            k0 = self.ix.read_timing(0)
+            k1 = self.ix.read_timing(1)
+            self.ix.set_timing(False)
         return self.max_over_ranks(elapsed), k0, k1
 
     def check_status(self):
         st = self.d_status.cpu().numpy()
-        bad = np.flatnonzero(st[:len(self.units), 1])
+        bad = np.flatnonzero(st[:, 1])
         if bad.size:
-            u = self.units[int(bad[0])]
-            raise SystemExit(f"k-mer not found in the index: record {self.wl.records[u.record][0]}, position {u.start + int(st[bad[0], 2])}")
+            where = f"record {self.wl.records[self.units[int(bad[0])].record][0]}" if int(bad[0]) < len(self.units) else f"status row {int(bad[0])}"
+            raise SystemExit(f"k-mer not found in the index: {where}, segment position {int(st[bad[0], 2])}")
+
+    def more_status_rows(self, n):
+        """`n` further status rows (segments cut differently from the resident units get their own); returns the first"""
+        first = self.d_status.shape[0]
+        self.d_status = self.torch.cat([self.d_status, self.torch.zeros((n, 8), dtype=self.torch.int64, device=self.dev)])
+        return first
 
     def counters(self):
         """counter build of the kernels, one pass: [3] LF steps, [4] rank blocks, [5] table words read by k_sites,
@@ -509,14 +539,21 @@ def main():
         for i, u in enumerate(units):
             by_unit[(u.record, u.start)] = i
         ref_segs = []
+        row0 = run.more_status_rows(len(ref_units))
         for ru in ref_units:                        # a reference-sized unit lies inside one of the resident units
             j = max(i for (r, s), i in by_unit.items() if r == ru.record and s <= ru.start)
             u = units[j]
             d = ru.start - u.start
-            ref_segs.append((int(run.seg_off[j]) + d, ru.seg_len, ru.count, int(run.out_off[j]) + d, j))
-        ref_elapsed, _, _ = run.timed(args.steps, 1, ref_segs)
+            ref_segs.append((int(run.seg_off[j]) + d, ru.seg_len, ru.count, int(run.out_off[j]) + d, row0 + len(ref_segs)))
+        ref_elapsed, _, _ = run.timed(args.steps, 1, ref_segs, kernel_events=False)
         ref_batch = {"batch": REFERENCE_BATCH, "value": total_positions * args.steps / ref_elapsed, "unit": "positions/s",
-                     "ms_per_step": ref_elapsed / args.steps * 1e3, "launches_per_step": len(ref_segs)}
+                     "ms_per_step": ref_elapsed / args.steps * 1e3, "launches_per_step": len(ref_segs), "streams": len(run.streams)}
+        if len(run.streams) > 1:                    # the same on one stream
+            saved, run.streams = run.streams, run.streams[:1]
+            one_elapsed, _, _ = run.timed(args.steps, 1, ref_segs, kernel_events=False)
+            run.streams = saved
+            ref_batch["value_one_stream"] = total_positions * args.steps / one_elapsed
+        run.check_status()
     gather = run.final_gather()
     tallies, probe = run.counters()
     result = None
@@ -532,6 +569,7 @@ def main():
             "config": {"workload": wl.desc + f", search-range {KMIN}:{KMAX}, both strands",
                        "records": len(wl.records), "positions": int(total_positions), "positions_per_gpu": run.my_positions,
                        "batch": args.batch, "segments_per_rank": len(run.segs),
+                       "streams": len(run.streams) if len(run.segs) > 1 else 1,
                        "seed_length": run.info["seed_length"], "quad_core_length": run.info.get("quad_core_length", 0),
                        "quad_small_core_length": run.info.get("quad_small_core_length", 0),
                        "index_bytes_hbm": run.info["device_bytes"],

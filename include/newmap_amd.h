@@ -131,7 +131,11 @@ int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, u
  * [4] distinct rank structures those steps read (lo and hi in one block count once),
  * [5] 8-byte table words read by the dominant kernel (k_sites: 4 per quad entry; k_min_unique / k_fixed_k: seed entries),
  * [6] strand-block reads (--norc, compat counts) or, after k_sites, the table words k_resolve read (4 per second-chance
- * entry, 1 per seed entry), [7] positions searched. */
+ * entry, 1 per seed entry), [7] positions searched.
+ * Streams: a call is ordered on the stream it is given and nowhere else.  The handle keeps its launch scratch once per
+ * caller stream (up to 5; further streams take over the least recently used set behind an event), so calls given
+ * different streams -- independent segments with their own d_out / d_status -- may overlap on the device.  Host-side the
+ * calls on one handle are still made one at a time (nm_set_option / info likewise). */
 #define NM_STATUS_WORDS 8
 int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
                               uint32_t kmin, uint32_t kmax, int use_revcomp, int elem_bytes,

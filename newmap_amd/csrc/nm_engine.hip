@@ -658,6 +658,18 @@ struct nm_buffer {
     uint64_t bytes = 0;
 };
 
+#define NM_LANES 6
+struct nm_lane {
+    hipStream_t owner = nullptr;          // the stream whose launches use this scratch
+    bool ready = false;                   // side stream and events exist
+    uint64_t tick = 0;                    // last use (LRU)
+    hipStream_t side = nullptr;           // repeat probes of repeat-rich input run here, beside k_sites (launch_sites)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_last = nullptr;         // end of the lane's last call on its owner's stream
+    nm_buffer enc, ks, work, settled, coarse, need;      // grown on demand
+    uint64_t enc_words = 0;               // words written by the last nm_encode
+};
+
 struct nm_index {
     int device = 0;
     nm_file_header h;
@@ -672,10 +684,16 @@ struct nm_index {
     void *d_lfb = nullptr;                // LF blocks
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;           // repeat probes of repeat-rich input run here, beside k_sites (launch_sites)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // scratch owned by the handle (grown on demand)
-    nm_buffer enc, seq, out, status, ks, starts, lens, work, settled, coarse, need;
+    // Launch scratch comes in LANES, one per stream the caller launches on: segments given on different streams have
+    // their own encoded words, bitmaps and counters and may overlap on the GPU (a 10 M-position launch leaves most of
+    // the chip idle while its last blocks drain and its three small kernels run).  Lane 0 belongs to the handle's own
+    // stream (host-buffer entry points); a caller stream keeps its lane until more than NM_LANES - 1 streams are in use,
+    // then the least recently used lane changes hands behind its `ev_last` (nm_lane_for).
+    nm_lane lanes[NM_LANES];
+    nm_lane *cur = &lanes[0];             // lane of the call in progress / of the last call (nm_index_info 14..17)
+    uint64_t lane_tick = 0;
+    // scratch of the host-buffer entry points (they run on `stream`, one call at a time)
+    nm_buffer seq, out, status, starts, lens;
     uint64_t coarse_min = 32ull << 20;    // launches of at least this many positions also run the coarse probes (NEWMAP_AMD_COARSE_MIN) ...
     uint32_t coarse_stride = NM_COARSE_STRIDE;   // positions per coarse probe (NEWMAP_AMD_COARSE_STRIDE: 128, 256, 512)
     int coarse_mode = 1;                  // ... 1: once an earlier launch has met long repeats, 2: always, 0: never (NEWMAP_AMD_COARSE)
@@ -684,7 +702,6 @@ struct nm_index {
     uint32_t *d_seen_latch = nullptr;     // device-side copy of the flag
     bool list_via_range = true;           // list mode with one length runs on the range kernels (NM_OPT_LIST_VIA_RANGE, A/B)
     bool repeat_probes = true;            // k_repeat_probe before the both-strand range kernels (NM_OPT_REPEAT_PROBES)
-    uint64_t enc_words = 0;               // words written by the last nm_encode
     int kernel_version = 0;               // 0 = automatic (sites when the quad table applies, else 1); 1 / 5 force a kernel
     uint32_t last_site_m = 0;             // core length of the table the sites of the last launch read (nm_index_info 20)
     bool probes_beside = true;            // NEWMAP_AMD_PROBES_BESIDE=0: the probes always follow k_sites on its stream (A/B)
@@ -724,6 +741,51 @@ static int nm_grow(nm_buffer &b, uint64_t bytes) {
     uint64_t want = bytes + bytes / 8 + 4096;
     HIP_TRY(hipMalloc(&b.p, want));
     b.bytes = want;
+    return NM_OK;
+}
+
+// side stream, events and counters of a lane (once)
+static int nm_lane_ready(nm_lane &L) {
+    if (L.ready) return NM_OK;
+    if (hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();                               // (without them the probes simply follow k_sites on one stream)
+        L.side = nullptr;
+    }
+    HIP_TRY(hipEventCreateWithFlags(&L.ev_last, hipEventDisableTiming));
+    int rc = nm_grow(L.work, NM_WORK_WORDS * sizeof(unsigned long long));
+    if (rc != NM_OK) return rc;
+    L.ready = true;
+    return NM_OK;
+}
+
+// the lane of a launch on stream `st` becomes ix->cur.  A stream keeps its lane; a new stream takes a free lane, or the
+// least recently used one of lanes 1.. after waiting (on the device) for that lane's last call.
+static int nm_lane_for(nm_index *ix, hipStream_t st) {
+    nm_lane *pick = nullptr;
+    for (nm_lane &L : ix->lanes)
+        if (L.owner == st && (L.ready || &L == &ix->lanes[0])) { pick = &L; break; }
+    if (!pick) {
+        for (int i = 1; i < NM_LANES && !pick; i++)
+            if (!ix->lanes[i].owner) pick = &ix->lanes[i];
+        if (!pick) {
+            pick = &ix->lanes[1];
+            for (int i = 2; i < NM_LANES; i++)
+                if (ix->lanes[i].tick < pick->tick) pick = &ix->lanes[i];
+            HIP_TRY(hipStreamWaitEvent(st, pick->ev_last, 0));
+        }
+        pick->owner = st;
+    }
+    int rc = nm_lane_ready(*pick);
+    if (rc != NM_OK) return rc;
+    pick->tick = ++ix->lane_tick;
+    ix->cur = pick;
+    return NM_OK;
+}
+
+// end of a call: whoever takes the lane over later waits for this point of the owner's stream
+static int nm_lane_done(nm_index *ix, hipStream_t st) {
+    if (ix->cur != &ix->lanes[0]) HIP_TRY(hipEventRecord(ix->cur->ev_last, st));
     return NM_OK;
 }
 
@@ -936,11 +998,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     auto fail = [&](int code) { fclose(fp); nm_index_close(ix); return code; };
     if (hipSetDevice(device) != hipSuccess) { nm_set_error("hipSetDevice(%d) failed", device); return fail(NM_E_DEVICE); }
     if (hipStreamCreate(&ix->stream) != hipSuccess) { nm_set_error("hipStreamCreate failed"); return fail(NM_E_DEVICE); }
-    if (hipStreamCreateWithFlags(&ix->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();                               // (without them the probes simply follow k_sites on one stream)
-        ix->side = nullptr;
-    }
+    ix->lanes[0].owner = ix->stream;
 
     const uint64_t rank_bytes = h.n_rank_blocks * sizeof(nm_rank_block);
     const uint64_t strand_bytes = h.n_strand_blocks * sizeof(nm_strand_block);
@@ -1059,7 +1117,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         ix->h_repeats_seen = nullptr;
     }
     rc = nm_grow(ix->status, NM_STATUS_WORDS * sizeof(uint64_t));
-    if (rc == NM_OK) rc = nm_grow(ix->work, NM_WORK_WORDS * sizeof(unsigned long long));
+    if (rc == NM_OK) rc = nm_lane_ready(ix->lanes[0]);
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     *out = ix;
     return NM_OK;
@@ -1069,16 +1127,21 @@ extern "C" void nm_index_close(nm_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->enc.p, ix->seq.p,
-                    ix->out.p, ix->status.p, ix->ks.p, ix->starts.p, ix->lens.p, ix->work.p, ix->settled.p, ix->coarse.p, ix->need.p};
+    (void)hipDeviceSynchronize();                              // launches on caller streams and side streams included
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->seq.p,
+                    ix->out.p, ix->status.p, ix->starts.p, ix->lens.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (nm_lane &L : ix->lanes) {
+        for (void *p : {L.enc.p, L.ks.p, L.work.p, L.settled.p, L.coarse.p, L.need.p})
+            if (p) (void)hipFree(p);
+        if (L.side) (void)hipStreamDestroy(L.side);
+        for (hipEvent_t e : {L.ev_fork, L.ev_join, L.ev_last})
+            if (e) (void)hipEventDestroy(e);
+    }
     if (ix->h_repeats_seen) (void)hipHostFree(ix->h_repeats_seen);
     if (ix->d_seen_latch) (void)hipFree(ix->d_seen_latch);
     for (auto &pool : ix->ev_pool) for (hipEvent_t e : pool) (void)hipEventDestroy(e);
-    if (ix->side) { (void)hipStreamSynchronize(ix->side); (void)hipStreamDestroy(ix->side); }
-    if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
-    if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -1106,7 +1169,7 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 14: case 15: case 16: case 17: {              // probe tally of the last range-mode launch
             unsigned long long v = 0;
             if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
-            if (hipMemcpy(&v, (const unsigned long long *)ix->work.p + 1 + (what - 14), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+            if (hipMemcpy(&v, (const unsigned long long *)ix->cur->work.p + 1 + (what - 14), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
             return v;
         }
         default: return 0;
@@ -1187,29 +1250,29 @@ extern "C" int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_
 // room for the encoded words of a segment (filled by the encode pass or by k_sites)
 static int nm_prepare_enc(nm_index *ix, uint64_t seq_len) {
     const uint64_t n_words = seq_len / 64 + 3;
-    int rc = nm_grow(ix->enc, n_words * sizeof(nm_enc_word));
+    int rc = nm_grow(ix->cur->enc, n_words * sizeof(nm_enc_word));
     if (rc != NM_OK) return rc;
-    ix->enc_words = n_words;
+    ix->cur->enc_words = n_words;
     return NM_OK;
 }
 
 static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStream_t st, uint64_t *d_status = nullptr) {
-    unsigned long long *work = d_status ? (unsigned long long *)ix->work.p : nullptr;
+    unsigned long long *work = d_status ? (unsigned long long *)ix->cur->work.p : nullptr;
     int rc = nm_prepare_enc(ix, seq_len);
     if (rc != NM_OK) return rc;
-    const uint64_t n_words = ix->enc_words;
+    const uint64_t n_words = ix->cur->enc_words;
     if (((uintptr_t)d_seq & 15) == 0)
         hipLaunchKernelGGL(k_encode16, dim3(nm_grid(n_words * 4)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
-                           (nm_enc_word *)ix->enc.p, n_words, d_status, work);
+                           (nm_enc_word *)ix->cur->enc.p, n_words, d_status, work);
     else
         hipLaunchKernelGGL(k_encode, dim3(nm_grid(n_words * 64)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
-                           (nm_enc_word *)ix->enc.p, n_words, d_status, work);
+                           (nm_enc_word *)ix->cur->enc.p, n_words, d_status, work);
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }
 
 static int nm_reset_status(nm_index *ix, uint64_t *d_status, hipStream_t st) {
-    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(NM_WAVE), 0, st, d_status, (unsigned long long *)ix->work.p);
+    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(NM_WAVE), 0, st, d_status, (unsigned long long *)ix->cur->work.p);
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }
@@ -1227,24 +1290,24 @@ template <bool BIG>
 static int nm_launch_probes(nm_index *ix, const nm_view &view, uint64_t n, uint32_t kmax, hipStream_t st, const uint32_t **words,
                             const uint64_t *need = nullptr) {
     const dim3 block(NM_BLOCK);
-    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    const nm_enc_word *enc = (const nm_enc_word *)ix->cur->enc.p;
     const uint64_t n_probes = (n + NM_PROBE_STRIDE - 1) / NM_PROBE_STRIDE;
-    int rc = nm_grow(ix->settled, (n_probes + 1) * sizeof(uint32_t));
+    int rc = nm_grow(ix->cur->settled, (n_probes + 1) * sizeof(uint32_t));
     if (rc != NM_OK) return rc;
-    unsigned long long *tally = (unsigned long long *)ix->work.p + 1;
+    unsigned long long *tally = (unsigned long long *)ix->cur->work.p + 1;
     const uint32_t *coarse = nullptr;
     const bool repeats_met = ix->h_repeats_seen && *(volatile uint32_t *)ix->h_repeats_seen != 0;
     if (n >= ix->coarse_min && (ix->coarse_mode == 2 || (ix->coarse_mode == 1 && repeats_met))) {
         const uint32_t cstride = ix->coarse_stride;
         const uint64_t n_coarse = (n + cstride - 1) / cstride;
-        if ((rc = nm_grow(ix->coarse, n_coarse * sizeof(uint32_t))) != NM_OK) return rc;
-        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally, need, n_probes, cstride);
-        else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->coarse.p, tally, need, n_probes, cstride);
-        coarse = (const uint32_t *)ix->coarse.p;
+        if ((rc = nm_grow(ix->cur->coarse, n_coarse * sizeof(uint32_t))) != NM_OK) return rc;
+        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->cur->coarse.p, tally, need, n_probes, cstride);
+        else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->cur->coarse.p, tally, need, n_probes, cstride);
+        coarse = (const uint32_t *)ix->cur->coarse.p;
     }
-    if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
-    else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
-    *words = (const uint32_t *)ix->settled.p;
+    if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->cur->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
+    else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->cur->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
+    *words = (const uint32_t *)ix->cur->settled.p;
     return NM_OK;
 }
 
@@ -1299,11 +1362,11 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
                         const uint32_t *d_list = nullptr, uint32_t n_list = 0) {
     int rc = nm_prepare_enc(ix, seq_len);
     if (rc != NM_OK) return rc;
-    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    const nm_enc_word *enc = (const nm_enc_word *)ix->cur->enc.p;
     const uint64_t n_need = (n + 63) / 64;
-    if ((rc = nm_grow(ix->need, (n_need + 1) * sizeof(uint64_t))) != NM_OK) return rc;
-    uint64_t *need = (uint64_t *)ix->need.p;
-    unsigned long long *work = (unsigned long long *)ix->work.p;
+    if ((rc = nm_grow(ix->cur->need, (n_need + 1) * sizeof(uint64_t))) != NM_OK) return rc;
+    uint64_t *need = (uint64_t *)ix->cur->need.p;
+    unsigned long long *work = (unsigned long long *)ix->cur->work.p;
     nm_view view = view_in;
     nm_pick_site_tables(ix, view, kmin);
     ix->last_site_m = view.quad_m;
@@ -1319,26 +1382,26 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
     // and look only at the strides it left mostly open -- on input without long repeats that is none at all.
     const uint32_t *probe = nullptr;
     const bool repeats_met = ix->h_repeats_seen && *(volatile uint32_t *)ix->h_repeats_seen != 0;
-    const bool beside = ix->repeat_probes && repeats_met && ix->side && ix->probes_beside && n >= (1u << 16);
-    nm_enc_word *enc_out = (nm_enc_word *)ix->enc.p;      // k_sites leaves the encoded words for the probes and k_resolve
+    const bool beside = ix->repeat_probes && repeats_met && ix->cur->side && ix->probes_beside && n >= (1u << 16);
+    nm_enc_word *enc_out = (nm_enc_word *)ix->cur->enc.p;      // k_sites leaves the encoded words for the probes and k_resolve
     if (beside) {
         // (the probes start before k_sites has encoded anything: this launch takes the separate encode pass)
         if ((rc = nm_encode(ix, d_seq, seq_len, st, status_ready ? nullptr : d_status)) != NM_OK) return rc;
         enc_out = nullptr;
-        HIP_TRY(hipEventRecord(ix->ev_fork, st));
-        HIP_TRY(hipStreamWaitEvent(ix->side, ix->ev_fork, 0));
-        if ((rc = nm_launch_probes<BIG>(ix, view, n, kmax, ix->side, &probe, nullptr)) != NM_OK) return rc;
-        HIP_TRY(hipEventRecord(ix->ev_join, ix->side));
+        HIP_TRY(hipEventRecord(ix->cur->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(ix->cur->side, ix->cur->ev_fork, 0));
+        if ((rc = nm_launch_probes<BIG>(ix, view, n, kmax, ix->cur->side, &probe, nullptr)) != NM_OK) return rc;
+        HIP_TRY(hipEventRecord(ix->cur->ev_join, ix->cur->side));
     } else if (!status_ready && (rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
     {
         nm_timed timed(ix, st);
 #define NM_LAUNCH_SITES(STATS_, LIST_) hipLaunchKernelGGL((k_sites<BIG, STATS_, LIST_>), sgrid, sblock, lds, st, view, (const uint8_t *)d_seq, seq_len, \
-                                                          enc_out, ix->enc_words, n, kmin, kmax, d, d_out, elem_bytes, d_status, need, work, d_list, n_list)
+                                                          enc_out, ix->cur->enc_words, n, kmin, kmax, d, d_out, elem_bytes, d_status, need, work, d_list, n_list)
         if (d_list) { if (ix->count_steps) NM_LAUNCH_SITES(true, true); else NM_LAUNCH_SITES(false, true); }
         else        { if (ix->count_steps) NM_LAUNCH_SITES(true, false); else NM_LAUNCH_SITES(false, false); }
 #undef NM_LAUNCH_SITES
     }
-    if (beside) HIP_TRY(hipStreamWaitEvent(st, ix->ev_join, 0));
+    if (beside) HIP_TRY(hipStreamWaitEvent(st, ix->cur->ev_join, 0));
     else if (ix->repeat_probes && (rc = nm_launch_probes<BIG>(ix, view, n, kmax, st, &probe, need)) != NM_OK) return rc;
     const dim3 rgrid((unsigned)((n_need + NM_RES_WORDS - 1) / NM_RES_WORDS)), rblock(NM_RES_BLOCK);
 #define NM_LAUNCH_RES(STATS_, LIST_) hipLaunchKernelGGL((k_resolve<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, \
@@ -1359,7 +1422,7 @@ static int launch_min_unique(nm_index *ix, const nm_view &view, const void *d_se
     int rc = nm_encode(ix, d_seq, seq_len, st, status_ready ? nullptr : d_status);
     if (rc != NM_OK) return rc;
     const dim3 block(NM_BLOCK);
-    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    const nm_enc_word *enc = (const nm_enc_word *)ix->cur->enc.p;
     // one lane per position; on both strands the repeat probes run first (every stride: there is no bitmap to gate them)
     const uint32_t *settled = nullptr;
     if (RC && ix->repeat_probes) {
@@ -1384,6 +1447,7 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
     if (!d_status) { nm_set_error("d_status is required"); return NM_E_ARGUMENT; }
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    if ((rc = nm_lane_for(ix, st)) != NM_OK) return rc;
     if (num_kmers == 0) return nm_reset_status(ix, d_status, st);
     nm_view view;
     if ((rc = nm_view_for(ix, kmin, &view)) != NM_OK) return rc;
@@ -1394,14 +1458,14 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
                                   : launch_min_unique<false, false>(ix, view, d_seq, seq_len, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st, false);
     if (rc != NM_OK) return rc;
     HIP_TRY(hipGetLastError());
-    return NM_OK;
+    return nm_lane_done(ix, st);
 }
 
 template <bool BIG, bool RC>
 static void launch_fixed_k(nm_index *ix, const nm_view &view, uint64_t seq_len, uint64_t first, uint64_t num_kmers, const uint32_t *d_ks, uint32_t nk,
                            void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st) {
     const dim3 grid(nm_grid(num_kmers - first)), block(NM_BLOCK);      // positions [first, num_kmers)
-    const nm_enc_word *enc = (const nm_enc_word *)ix->enc.p;
+    const nm_enc_word *enc = (const nm_enc_word *)ix->cur->enc.p;
     nm_timed timed(ix, st);
     if (ix->count_steps) hipLaunchKernelGGL((k_fixed_k<BIG, RC, true>), grid, block, 0, st, view, enc, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
     else                 hipLaunchKernelGGL((k_fixed_k<BIG, RC, false>), grid, block, 0, st, view, enc, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status);
@@ -1422,13 +1486,14 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     if (!d_status) { nm_set_error("d_status is required"); return NM_E_ARGUMENT; }
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    if ((rc = nm_lane_for(ix, st)) != NM_OK) return rc;
     if ((rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
     if (num_kmers == 0) return NM_OK;
     nm_timed whole(ix, st, 1);
-    if ((rc = nm_grow(ix->ks, (uint64_t)nk * sizeof(uint32_t))) != NM_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(ix->ks.p, ks, (uint64_t)nk * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if ((rc = nm_grow(ix->cur->ks, (uint64_t)nk * sizeof(uint32_t))) != NM_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->cur->ks.p, ks, (uint64_t)nk * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     bool encoded = false;                                   // the range / sites launches below leave the segment's encoded words behind
-    const uint32_t *d_ks = (const uint32_t *)ix->ks.p;
+    const uint32_t *d_ks = (const uint32_t *)ix->cur->ks.p;
     uint32_t kshort = ks[0];
     for (uint32_t i = 1; i < nk; i++) if (ks[i] < kshort) kshort = ks[i];
     nm_view view;
@@ -1467,7 +1532,7 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
         else         { if (use_revcomp) launch_fixed_k<false, true>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<false, false>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
     }
     HIP_TRY(hipGetLastError());
-    return NM_OK;
+    return nm_lane_done(ix, st);
 }
 
 // host-buffer wrappers ---------------------------------------------------------------------
@@ -1537,8 +1602,9 @@ extern "C" int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t
     const uint64_t out_bytes = num_kmers * 4;
     if ((rc = nm_stage_segment(ix, seq, seq_len, out_bytes)) != NM_OK) return rc;
     if (num_kmers == 0) return NM_OK;
+    if ((rc = nm_lane_for(ix, ix->stream)) != NM_OK) return rc;
     if ((rc = nm_encode(ix, ix->seq.p, seq_len, ix->stream)) != NM_OK) return rc;
-    hipLaunchKernelGGL(k_upper, dim3(nm_grid(num_kmers)), dim3(NM_BLOCK), 0, ix->stream, (const nm_enc_word *)ix->enc.p,
+    hipLaunchKernelGGL(k_upper, dim3(nm_grid(num_kmers)), dim3(NM_BLOCK), 0, ix->stream, (const nm_enc_word *)ix->cur->enc.p,
                        num_kmers, kmax, (uint32_t *)ix->out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, ix->out.p, out_bytes, hipMemcpyDeviceToHost, ix->stream));
@@ -1634,13 +1700,13 @@ extern "C" int nm_search_segment_multi(nm_index *const *indexes, uint32_t n_inde
         hipLaunchKernelGGL(k_encode16, dim3(nm_grid(n_words * 4)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len, (nm_enc_word *)d_enc, n_words, (uint64_t *)nullptr, (unsigned long long *)nullptr);
     }
     const uint64_t out_bytes = num_kmers * (uint64_t)elem_bytes;
-    if ((rc = nm_grow(ix0->out, out_bytes + 64)) != NM_OK || (rc = nm_grow(ix0->ks, (uint64_t)nk * 4)) != NM_OK) { cleanup(); return rc; }
+    if ((rc = nm_grow(ix0->out, out_bytes + 64)) != NM_OK || (rc = nm_grow(ix0->lanes[0].ks, (uint64_t)nk * 4)) != NM_OK) { cleanup(); return rc; }
     if ((rc = nm_reset_status(ix0, (uint64_t *)ix0->status.p, st)) != NM_OK) { cleanup(); return rc; }
-    if (hipMemcpyAsync(ix0->ks.p, ks, (uint64_t)nk * 4, hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); nm_set_error("copy to device failed"); return NM_E_DEVICE; }
+    if (hipMemcpyAsync(ix0->lanes[0].ks.p, ks, (uint64_t)nk * 4, hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); nm_set_error("copy to device failed"); return NM_E_DEVICE; }
     if (num_kmers) {
         const uint32_t list_n = range_mode ? 0u : nk;
-        if (use_revcomp) hipLaunchKernelGGL(k_multi<true>, dim3(nm_grid(num_kmers)), dim3(NM_BLOCK), 0, st, a, seq_len, num_kmers, kmin, kmax, (const uint32_t *)ix0->ks.p, list_n, ix0->out.p, elem_bytes, (uint64_t *)ix0->status.p);
-        else             hipLaunchKernelGGL(k_multi<false>, dim3(nm_grid(num_kmers)), dim3(NM_BLOCK), 0, st, a, seq_len, num_kmers, kmin, kmax, (const uint32_t *)ix0->ks.p, list_n, ix0->out.p, elem_bytes, (uint64_t *)ix0->status.p);
+        if (use_revcomp) hipLaunchKernelGGL(k_multi<true>, dim3(nm_grid(num_kmers)), dim3(NM_BLOCK), 0, st, a, seq_len, num_kmers, kmin, kmax, (const uint32_t *)ix0->lanes[0].ks.p, list_n, ix0->out.p, elem_bytes, (uint64_t *)ix0->status.p);
+        else             hipLaunchKernelGGL(k_multi<false>, dim3(nm_grid(num_kmers)), dim3(NM_BLOCK), 0, st, a, seq_len, num_kmers, kmin, kmax, (const uint32_t *)ix0->lanes[0].ks.p, list_n, ix0->out.p, elem_bytes, (uint64_t *)ix0->status.p);
         if (hipGetLastError() != hipSuccess) { cleanup(); nm_set_error("kernel launch failed"); return NM_E_DEVICE; }
     }
     rc = nm_finish_segment(ix0, out, out_bytes, n_ambiguous, bad_pos);

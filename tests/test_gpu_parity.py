@@ -327,6 +327,71 @@ def test_torch_tensors_share_the_runtime(mixed_genome):
         assert np.array_equal(out.cpu().numpy(), want)
 
 
+def test_segments_on_several_streams_overlap_safely(tmp_path):
+    """The handle keeps one set of launch scratch (encoded words, need bitmap, probe results, counters, side stream) per
+    caller stream -- a LANE (nm_engine.hip nm_lane_for) -- so segments launched on different streams may overlap.
+    A tandem-rich genome (side-stream probes, resolve walks) and a uniform one, cut into segments of uneven sizes and
+    dealt over 1, 2, 3 and 6 streams (6 > lanes: the least recently used lane changes hands): every position equals the
+    one-stream result, which equals the oracle; list mode likewise; per-segment status rows keep their own counts."""
+    import torch
+    from newmap_amd import engine, synth
+    tandem = synth.tandem_dna(1_500_000, 77).tobytes()
+    uniform = synth.uniform_dna(700_000, 78).tobytes()
+    text = b">t\n" + tandem + b"\n>u\n" + uniform + b"\n"
+    fa, idx = _build_index(tmp_path, text, "lanes")
+    oracle = rd.OracleIndex([tandem, uniform])
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    for rec, (kmin, kmax) in ((tandem, (20, 255)), (uniform, (20, 200)), (tandem, (24, 60))):
+        want = rd.closed_form_min_unique(rec, oracle, kmin, kmax)
+        n = len(rec)
+        cuts = np.concatenate(([0], np.sort(rng.choice(np.arange(1, n), 22, replace=False)), [n]))
+        cuts[1:6] = cuts[0] + np.arange(1, 6) * 70_001 if n > 500_000 else cuts[1:6]        # a few launches big enough for the side-stream probes
+        cuts = np.unique(cuts)
+        seq = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
+        with engine.Index(idx, 0) as ix:
+            results = []
+            for n_streams in (1, 2, 3, 6):
+                streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+                out = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
+                st = torch.zeros((len(cuts) - 1, 8), dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()
+                for rounds in range(2):                                   # second round: every lane is reused while warm
+                    for j, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                        a, b = int(a), int(b)
+                        seg_len = min(n, b + kmax - 1) - a
+                        cnt = b - a if b < n else seg_len
+                        ix.min_unique_segment_dev(seq.data_ptr() + a, seg_len, cnt, kmin, kmax, True, 1, out.data_ptr() + a,
+                                                  st.data_ptr() + 64 * j, streams[(j + rounds) % n_streams].cuda_stream)
+                torch.cuda.synchronize()
+                results.append((out.cpu().numpy(), st.cpu().numpy()))
+            assert np.array_equal(results[0][0], want), (kmin, kmax)
+            for got, status in results[1:]:
+                assert np.array_equal(got, want), (kmin, kmax)
+                assert np.array_equal(status[:, [0, 1, 7]], results[0][1][:, [0, 1, 7]])      # ambiguous, errors, positions searched
+            # list mode over the lanes
+            ks = [kmin + 4]
+            want_l = None
+            for n_streams in (1, 3):
+                streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+                out = torch.zeros(n, dtype=torch.uint8, device=dev)
+                st = torch.zeros((len(cuts) - 1, 8), dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()
+                for j, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                    a, b = int(a), int(b)
+                    seg_len = min(n, b + ks[0] - 1) - a
+                    cnt = b - a if b < n else seg_len
+                    ix.fixed_k_segment_dev(seq.data_ptr() + a, seg_len, cnt, ks, True, 1, out.data_ptr() + a, st.data_ptr() + 64 * j,
+                                           streams[j % n_streams].cuda_stream)
+                torch.cuda.synchronize()
+                if want_l is None:
+                    want_l = out.cpu().numpy()
+                    ref, _ = ix.fixed_k_segment(rec, n, ks)
+                    assert np.array_equal(want_l, ref)
+                else:
+                    assert np.array_equal(out.cpu().numpy(), want_l)
+
+
 # ------------------------------------------------------------------ larger sizes: properties
 def test_large_random_genome_properties(tmp_path, eng):
     """BASELINE configs[1] at FULL size (100 Mbp uniform genome, the bench workload): table

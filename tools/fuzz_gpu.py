@@ -1,6 +1,7 @@
 """Randomised A/B soak on the GPU: the default range path (sites on the quad table + gated repeat probes + resolve,
 list modes routed through it; random cap of the group size; the > 2^31-row instantiations on every other index)
-against the plain one-lane-per-position kernels without probes, on genomes with tandem arrays, dispersed and
+against the plain one-lane-per-position kernels without probes (and, half of the time, the same segments again through the
+device-pointer entry dealt over 2..7 streams = the handle's lanes, incl. lanes changing hands), on genomes with tandem arrays, dispersed and
 reverse-complement copies, N runs and soft-masked stretches, cut into segments at random batch sizes.
 
     python tools/fuzz_gpu.py [--rounds 40] [--seed 1]
@@ -58,6 +59,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
+    import torch
     from newmap_amd._c_newmap_generate_index import generate_fm_index
     from newmap_amd.engine import Index
     rng = np.random.default_rng(a.seed)
@@ -87,16 +89,38 @@ def main():
                     ks = lists[int(rng.integers(0, len(lists)))]
                     for rid, data in recs:
                         n = len(data)
+                        whole = []
                         for p in range(0, n, batch):
                             cnt = min(batch, n - p)
                             seg = data[p:min(p + cnt + kmax - 1, n)]
                             x, ax = fast.min_unique_segment(seg, cnt, kmin, kmax)
                             y, ay = plain.min_unique_segment(seg, cnt, kmin, kmax)
                             assert ax == ay and np.array_equal(x, y), ("range", rnd, rid, kmin, kmax, batch, p, mode)
+                            whole.append(x)
                             x, ax = fast.fixed_k_segment(seg, cnt, ks)
                             y, ay = plain.fixed_k_segment(seg, cnt, ks)
                             assert ax == ay and np.array_equal(x, y), ("list", rnd, rid, ks, batch, p, mode)
                             checks += 2
+                        if rng.random() < 0.5:
+                            # the same segments through the device-pointer entry, dealt over several streams (lanes of the handle)
+                            whole = np.concatenate(whole)
+                            eb = whole.dtype.itemsize
+                            streams = [torch.cuda.Stream() for _ in range(int(rng.integers(2, 8)))]
+                            seq_t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+                            out_t = torch.full((n * eb,), 0xEE, dtype=torch.uint8, device="cuda")
+                            starts = list(range(0, n, batch))
+                            st_t = torch.zeros((len(starts), 8), dtype=torch.int64, device="cuda")
+                            torch.cuda.synchronize()
+                            for j, p in enumerate(starts):
+                                cnt = min(batch, n - p)
+                                seg_len = min(p + cnt + kmax - 1, n) - p
+                                fast.min_unique_segment_dev(seq_t.data_ptr() + p, seg_len, cnt, kmin, kmax, True, eb, out_t.data_ptr() + p * eb,
+                                                            st_t.data_ptr() + 64 * j, streams[int(rng.integers(0, len(streams)))].cuda_stream)
+                            torch.cuda.synchronize()
+                            got = out_t.cpu().numpy().view(whole.dtype)
+                            assert np.array_equal(got, whole), ("lanes", rnd, rid, kmin, kmax, batch, len(streams), mode)
+                            assert not st_t[:, 1].any().item()
+                            checks += len(starts)
             if rnd % 5 == 4:
                 print(f"[fuzz] round {rnd + 1}/{a.rounds}: {checks} segment comparisons identical, {time.time() - t0:.0f}s", flush=True)
     print(f"fuzz ok: {checks} segment comparisons identical in {time.time() - t0:.0f}s")

@@ -53,8 +53,8 @@ def log(*a):
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)        # 100 passes of ~0.4 ms: a timed region of ~40 ms
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2",
                     help="headline workload: c2 = BASELINE configs[1] (default); c3 / c5 = configs[2] / configs[4] at --mbp (capability runs)")
     ap.add_argument("--mbp", type=float, default=None, help="genome size in Mbp of a c3 / c5 capability run")

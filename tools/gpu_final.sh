@@ -5,7 +5,7 @@ O=gpurun_out/${1:-final}
 mkdir -p $O
 bash tools/profile_c2.sh $O/prof_c2 > $O/prof_c2.txt 2>&1
 mkdir -p profiles/round2 && cp $O/prof_c2/pmc_sites_kernel_summary.csv profiles/round2/   # bench.py below reads it
-python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 python bench.py --config c3 --steps 5 --warmup 2 > $O/bench_c3.json 2> $O/bench_c3.err; echo "c3 rc=$?"
 python bench.py --config c5 --steps 5 --warmup 2 > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?"
 python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/gputest.log

@@ -261,6 +261,8 @@ class Index:
     # device-resident variants (bench, multi-GPU driver) ---------------------------------------
     def min_unique_segment_dev(self, d_seq: int, seq_len: int, num_kmers: int, kmin: int, kmax: int,
                                use_revcomp: bool, elem_bytes: int, d_out: int, d_status: int, stream: int = 0):
+        """asynchronous on `stream` (0 = the handle's own).  Independent segments given on different streams overlap
+        on the device: the handle keeps its launch scratch per stream (include/newmap_amd.h, "Streams")"""
         rc = self._L.nm_min_unique_segment_dev(self.handle, d_seq, seq_len, num_kmers, kmin, kmax,
                                                int(bool(use_revcomp)), elem_bytes, d_out, d_status, stream or None)
         _lib.raise_for(rc)

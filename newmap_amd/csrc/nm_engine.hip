@@ -1084,15 +1084,25 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     }
     // a second quad table with SHORT cores (larger groups per table line, nm_core.h "sites"): windows of
     // ceil(log4(20 n)) bases -- about one in twenty repeated -- when that is shorter than the first table's and the
-    // table stays below 9 GB (cores <= 13); NEWMAP_AMD_QUAD_SMALL_M overrides (0 = none)
+    // table stays below 9 GB (cores <= 13; 14 on large genomes, see below); NEWMAP_AMD_QUAD_SMALL_M overrides (0 = none)
     uint32_t quad_small_m = 0;
     if (quad_m) {
         uint32_t w1 = 1;
         while (w1 < 32 && (double)(1ULL << (2 * w1)) < 20.0 * (double)h.n) w1++;
         quad_small_m = w1 > NM_QUAD_EXT + 8 ? w1 - NM_QUAD_EXT : 8;
         if (quad_small_m > 13) {                             // capped: worth its memory only while most of its windows still occur once
+            auto repeated = [&](uint32_t m) { return 1.0 - exp(-(double)h.n / pow(4.0, (double)(m + NM_QUAD_EXT))); };
             quad_small_m = 13;
-            if (1.0 - exp(-(double)h.n / pow(4.0, (double)(quad_small_m + NM_QUAD_EXT))) > 0.15) quad_small_m = 0;
+            if (repeated(13) > 0.15) {
+                // genomes of several Gbp: cores of 14 (34 GB) for a resident handle, when the memory left after the seed
+                // table and the first quad table holds that twice (3.09 Gbp, 20:200: 7 positions per line instead of 6)
+                quad_small_m = 0;
+                size_t free_b = 0, total_b = 0;
+                const uint64_t first = (8ULL << (2 * s)) + (128ULL << (2 * quad_m)), want = 128ULL << 28;
+                if (!small_tables && quad_m > 14 && repeated(14) <= 0.15 && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                    free_b > first && want <= (free_b - first) / 2)
+                    quad_small_m = 14;
+            }
         }
         if (const char *q = getenv("NEWMAP_AMD_QUAD_SMALL_M")) quad_small_m = (uint32_t)atoi(q);
         if (quad_small_m && quad_small_m < 8) quad_small_m = 8;

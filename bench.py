@@ -232,6 +232,7 @@ class Run:
         self._extra_streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1) - 1)]
         self.streams = [self.stream] + [s_.cuda_stream for s_ in self._extra_streams]
         self.segs = [(int(so), u.seg_len, u.count, int(oo), i) for i, (u, so, oo) in enumerate(zip(units, seg_off[:-1], out_off[:-1]))]
+        self.overlap_identical = None          # set by timed(): output of the overlapped passes == output of a one-stream pass
 
     def step(self, segs=None, streams=None):
         """one pass: every segment once.  Segments are independent (own input, output and status row); with several
@@ -281,9 +282,15 @@ class Run:
         k0 = k1 = (0, 0.0, 0.0)
         if kernel_events:
             if overlapped:
+                snap = self.d_out.clone()                         # what the overlapped passes left
+                self.d_out.zero_()
                 self.ix.set_timing(True)
                 self.step(segs, self.streams[:1])
                 torch.cuda.synchronize()
+                self.overlap_identical = bool(torch.equal(snap, self.d_out))
+                del snap
+                if not self.overlap_identical:
+                    raise SystemExit("segments overlapped on several streams gave a different output than on one stream")
             k0 = self.ix.read_timing(0)
             k1 = self.ix.read_timing(1)
             self.ix.set_timing(False)
@@ -570,6 +577,7 @@ def main():
                        "records": len(wl.records), "positions": int(total_positions), "positions_per_gpu": run.my_positions,
                        "batch": args.batch, "segments_per_rank": len(run.segs),
                        "streams": len(run.streams) if len(run.segs) > 1 else 1,
+                       "streams_output_identical_to_one_stream": run.overlap_identical,
                        "seed_length": run.info["seed_length"], "quad_core_length": run.info.get("quad_core_length", 0),
                        "quad_small_core_length": run.info.get("quad_small_core_length", 0),
                        "index_bytes_hbm": run.info["device_bytes"],
@@ -616,6 +624,7 @@ def main():
             block = {"workload": ns.desc, "positions": int(n_total), "n_gpus": world, "scaling": "strong (fixed genome, units dealt to the ranks in interleaved chunks)",
                      "steps": n_steps, "warmup": n_warm, "ms_per_step": n_elapsed / n_steps * 1e3, "value": n_total * n_steps / n_elapsed,
                      "unit": "positions/s", "launches_per_step_per_rank": len(nrun.segs),
+                     "streams": len(nrun.streams) if len(nrun.segs) > 1 else 1, "streams_output_identical_to_one_stream": nrun.overlap_identical,
                      "index_bytes_hbm": nrun.info["device_bytes"], "bwt_rows": nrun.info["bwt_length"],
                      "roofline": roofline_block(nrun, nk0, n_tallies, ns.key), "pipeline": pipeline_block(nrun, nk1, n_tallies, n_probe),
                      "verify": n_verify,

@@ -71,6 +71,7 @@ def parse(argv=None):
     ap.add_argument("--no-reference-batch", action="store_true",
                     help="skip the extra passes at the reference's 10 M batch (profiling runs: one launch size per kernel)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 3 Gbp / 20:200 block (profiling runs)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTA-in -> files-out leg of the north-star block (kernel traces)")
     ap.add_argument("--north-star-mbp", type=float, default=None, help="shrink the north-star genome (rehearsals)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the baseline sample (30 s: the whole 100 Mbp on the 128 threads of the GPU box)")
     ap.add_argument("--workdir", default=os.environ.get("NEWMAP_AMD_BENCH_DIR", "/tmp/newmap_amd_bench"))
@@ -641,7 +642,7 @@ def main():
                             "rate on these host cores is lower) -- SURVEY.md section 8(d) sanctions the prefix / extrapolation",
                     "gpu_over_cpu": block["value"] / cb["value"]}
             result["north_star"] = block
-        if world == 1:
+        if world == 1 and not args.no_end_to_end:
             e2e = end_to_end(args, ns, nfa, nidx, dev_index, nrun)
             result["end_to_end"] = e2e
         nrun.close()

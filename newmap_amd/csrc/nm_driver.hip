@@ -20,6 +20,7 @@
 
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -390,6 +391,7 @@ struct FastDriver {
     nm_index *ix = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // odd slots run here: copies and kernels of neighbouring segments overlap (lanes of the handle)
     std::vector<uint32_t> ks;
     bool range_mode = true, use_rc = true;
     uint32_t kmin = 0, kmax = 0;
@@ -574,7 +576,10 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         }
     }
     // ---- device side
-    const int n_slots = 4, n_writers = 4;
+    // slots in flight = writer threads: a writer spends ~4 ms in pwrite per 10 MB segment, the GPU ~1 ms on it
+    int n_slots = d.batch <= (32u << 20) ? 8 : 4;
+    if (const char *e = getenv("NEWMAP_AMD_DRIVER_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= 32) n_slots = v; }
+    const int n_writers = n_slots;
     int n_ready = 0;                                          // slots that were fully allocated
     const uint64_t in_bytes = d.batch + d.lookahead + 64, out_bytes = d.batch * (uint64_t)d.elem_bytes + 64;
     std::vector<std::thread> writers;
@@ -585,7 +590,14 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         rc = NM_E_DEVICE;
         return false;
     };
-    if (rc == NM_OK && hip_ok(hipSetDevice(d.device), "hipSetDevice") && hip_ok(hipStreamCreate(&d.stream), "hipStreamCreate")) {
+    const char *one_stream = getenv("NEWMAP_AMD_DRIVER_STREAMS");
+    const bool two_streams = !(one_stream && one_stream[0] == '1');
+    const bool phase_times = getenv("NEWMAP_AMD_DRIVER_TIMING") != nullptr;
+    double t_strip = 0, t_copy = 0, t_slot = 0, t_submit = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    if (rc == NM_OK && hip_ok(hipSetDevice(d.device), "hipSetDevice") && hip_ok(hipStreamCreate(&d.stream), "hipStreamCreate") &&
+        (!two_streams || hip_ok(hipStreamCreate(&d.stream2), "hipStreamCreate"))) {
         d.slots.resize(n_slots);
         for (int i = 0; i < n_slots && rc == NM_OK; i++) {
             FastSlot &s = d.slots[i];
@@ -631,43 +643,52 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         for (auto &part : mine) {
             // strip the pieces that hold [part.first, part.second + lookahead) into rec_buf
             const uint64_t need_hi = part.second + d.lookahead < rec.n_bases ? part.second + d.lookahead : rec.n_bases;
+            double t0 = now();
             const uint64_t buf_base = nm_fasta::materialize(rec, part.first, need_hi, threads, rec_buf);
+            t_strip += now() - t0;
             for (uint64_t p = part.first; p < part.second && rc == NM_OK && d.error.load() == NM_OK; p += d.batch) {
                 const uint64_t count = part.second - p < d.batch ? part.second - p : d.batch;
                 const uint64_t seg_len = (p + count + d.lookahead < rec.n_bases ? p + count + d.lookahead : rec.n_bases) - p;
                 int si;
+                t0 = now();
                 {
                     std::unique_lock<std::mutex> lk(d.mu);
                     d.cv_free.wait(lk, [&] { return !d.free_slots.empty(); });
                     si = d.free_slots.front();
                     d.free_slots.pop_front();
                 }
+                t_slot += now() - t0;
                 FastSlot &s = d.slots[si];
                 s.rec = (int)ri; s.rec_start = p; s.count = count; s.seg_len = seg_len;
                 const uint8_t *src = rec_buf.data() + (p - buf_base);
-                const size_t cp = 8u << 20;
-                parallel_for((seg_len + cp - 1) / cp, seg_len > (32u << 20) ? 8 : 1, [&](size_t k) {
+                const size_t cp = 2u << 20;
+                t0 = now();
+                parallel_for((seg_len + cp - 1) / cp, seg_len > (4u << 20) ? 8 : 1, [&](size_t k) {
                     const size_t o = k * cp, m = seg_len - o < cp ? seg_len - o : cp;
                     memcpy(s.h_in + o, src + o, m);
                 });
-                bool ok = hip_ok(hipMemcpyAsync(s.d_in, s.h_in, seg_len, hipMemcpyHostToDevice, d.stream), "copy to device");
+                t_copy += now() - t0;
+                t0 = now();
+                hipStream_t st = (si & 1) && d.stream2 ? d.stream2 : d.stream;
+                bool ok = hip_ok(hipMemcpyAsync(s.d_in, s.h_in, seg_len, hipMemcpyHostToDevice, st), "copy to device");
                 if (ok) {
                     const int e = d.range_mode
-                        ? nm_min_unique_segment_dev(d.ix, s.d_in, seg_len, count, d.kmin, d.kmax, d.use_rc, d.elem_bytes, s.d_out, s.d_status, d.stream)
-                        : nm_fixed_k_segment_dev(d.ix, s.d_in, seg_len, count, d.ks.data(), (uint32_t)d.ks.size(), d.use_rc, d.elem_bytes, s.d_out, s.d_status, d.stream);
+                        ? nm_min_unique_segment_dev(d.ix, s.d_in, seg_len, count, d.kmin, d.kmax, d.use_rc, d.elem_bytes, s.d_out, s.d_status, st)
+                        : nm_fixed_k_segment_dev(d.ix, s.d_in, seg_len, count, d.ks.data(), (uint32_t)d.ks.size(), d.use_rc, d.elem_bytes, s.d_out, s.d_status, st);
                     if (e != NM_OK) { rc = e; ok = false; }
                 }
                 if (ok) {
-                    ok = hip_ok(hipMemsetAsync(s.d_sum, 0, 16, d.stream), "summary reset") &&             // count, largest
-                         hip_ok(hipMemsetAsync(s.d_sum + 2, 0xFF, 8, d.stream), "summary reset");        // smallest non-zero
+                    ok = hip_ok(hipMemsetAsync(s.d_sum, 0, 16, st), "summary reset") &&             // count, largest
+                         hip_ok(hipMemsetAsync(s.d_sum + 2, 0xFF, 8, st), "summary reset");        // smallest non-zero
                     const unsigned grid = (unsigned)((count + 256 * 16 - 1) / (256 * 16) < 2048 ? (count + 256 * 16 - 1) / (256 * 16) : 2048);
-                    if (d.elem_bytes == 1) hipLaunchKernelGGL(k_out_summary<uint8_t>, dim3(grid ? grid : 1), dim3(256), 0, d.stream, (const uint8_t *)s.d_out, count, (unsigned long long *)s.d_sum);
-                    else if (d.elem_bytes == 2) hipLaunchKernelGGL(k_out_summary<uint16_t>, dim3(grid ? grid : 1), dim3(256), 0, d.stream, (const uint16_t *)s.d_out, count, (unsigned long long *)s.d_sum);
-                    else hipLaunchKernelGGL(k_out_summary<uint32_t>, dim3(grid ? grid : 1), dim3(256), 0, d.stream, (const uint32_t *)s.d_out, count, (unsigned long long *)s.d_sum);
-                    ok = ok && hip_ok(hipMemcpyAsync(s.h_out, s.d_out, count * (uint64_t)d.elem_bytes, hipMemcpyDeviceToHost, d.stream), "copy from device") &&
-                         hip_ok(hipMemcpyAsync(s.h_status, s.d_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t), hipMemcpyDeviceToHost, d.stream), "status copy") &&
-                         hip_ok(hipEventRecord(s.done, d.stream), "event record");
+                    if (d.elem_bytes == 1) hipLaunchKernelGGL(k_out_summary<uint8_t>, dim3(grid ? grid : 1), dim3(256), 0, st, (const uint8_t *)s.d_out, count, (unsigned long long *)s.d_sum);
+                    else if (d.elem_bytes == 2) hipLaunchKernelGGL(k_out_summary<uint16_t>, dim3(grid ? grid : 1), dim3(256), 0, st, (const uint16_t *)s.d_out, count, (unsigned long long *)s.d_sum);
+                    else hipLaunchKernelGGL(k_out_summary<uint32_t>, dim3(grid ? grid : 1), dim3(256), 0, st, (const uint32_t *)s.d_out, count, (unsigned long long *)s.d_sum);
+                    ok = ok && hip_ok(hipMemcpyAsync(s.h_out, s.d_out, count * (uint64_t)d.elem_bytes, hipMemcpyDeviceToHost, st), "copy from device") &&
+                         hip_ok(hipMemcpyAsync(s.h_status, s.d_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t), hipMemcpyDeviceToHost, st), "status copy") &&
+                         hip_ok(hipEventRecord(s.done, st), "event record");
                 }
+                t_submit += now() - t0;
                 if (!ok) {                                         // give the slot back, stop
                     std::lock_guard<std::mutex> g(d.mu);
                     d.free_slots.push_back(si);
@@ -706,7 +727,11 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (d.stream) (void)hipStreamDestroy(d.stream);
+    if (d.stream2) (void)hipStreamDestroy(d.stream2);
     unmap();
+    if (phase_times)
+        fprintf(stderr, "[driver] total %.3fs: strip %.3f, copy to pinned %.3f, wait for a slot %.3f, submit %.3f (main thread)\n",
+                now() - t_begin, t_strip, t_copy, t_slot, t_submit);
     if (rc != NM_OK) return rc;
     report_ready();
     // ---- summaries in file order (this rank's share when world > 1), then the totals

@@ -5,7 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Two workloads per run, both with the sequence bytes resident in HBM before the timed region and one STEP = one pass of
-the hot path (encode pass, k_sites, repeat probes, k_resolve) over every position of the rank's work units:
+the hot path (k_sites with its encode stage, repeat probes, k_resolve) over every position of the rank's work units.  A
+pass of several segments (north star, `reference_batch`, --config c3 / c5) deals them round-robin over --streams HIP
+streams (default 2): the handle keeps its launch scratch per stream, neighbouring segments overlap; the headline is ONE
+launch per pass on one stream, and its kernel is timed with HIP events on that stream in the timed passes themselves:
 
   * headline (`value`): BASELINE.json configs[1] -- synthetic 100 Mbp single-record FASTA, uniform ACGT
     (numpy default_rng(20260515)), search range 20:200.  At N > 1 the path shards by independent units with no

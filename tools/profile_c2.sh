@@ -16,4 +16,3 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d $
 timeout -k 10 300 rocprofv3 --pmc TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS --output-format csv -d $O/pmc4 -o p -- $B > $O/pmc4.json 2> $O/pmc4.log || echo "pmc4 failed"
 timeout -k 10 300 rocprofv3 --pmc GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_LFIFO_FULL_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d $O/pmc5 -o p -- $B > $O/pmc5.json 2> $O/pmc5.log || echo "pmc5 failed"
 python3 tools/pmc_summary.py k_sites $O/pmc_sites_kernel_summary.csv $O/trace.json $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 $O/pmc5
-python3 tools/pmc_summary.py k_encode16 $O/pmc_encode_kernel_summary.csv $O/trace.json $O/pmc1 $O/pmc3

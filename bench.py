@@ -46,6 +46,7 @@ BATCH = 100_000_000            # positions per launch.  The reference's --kmer-b
 REFERENCE_BATCH = 10_000_000
 C2_SEED, C2_BASES = 20260515, 100_000_000
 PMC_SUMMARY = ROOT / "profiles" / "round2" / "pmc_sites_kernel_summary.csv"
+PMC_SUMMARY_NS = ROOT / "profiles" / "round2" / "pmc_ns_sites_kernel_summary.csv"     # the north-star block (tools/profile_ns.sh)
 KERNEL_SOURCES = [ROOT / "newmap_amd" / "csrc" / "nm_engine.hip", ROOT / "newmap_amd" / "csrc" / "nm_core.h"]
 
 
@@ -173,13 +174,14 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel: str, quad_m: int, positions_per_launch: float):
+def measured_traffic(kernel: str, quad_m: int, positions_per_launch: float, summary: Path = None):
     """HBM-side read + write bytes per launch of the dominant kernel from the PMC pass committed under profiles/
     (rocprofv3 --pmc cannot run inside this process).  The summary names the kernel sources it was measured on
     (sha256 of nm_engine.hip + nm_core.h), the core length of the table the sites read and the launch size; a summary
     of OTHER sources, another table or another launch size reports null with the reason.  Reads: TCC_EA0_RDREQ x 128 B
     (on gfx950 every read request of this gather is a 128-byte one, TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ -- the guide's
     "FETCH_SIZE reports half" correction stated exactly); writes: TCC_EA0_WRREQ x 64 B."""
+    PMC_SUMMARY = summary or globals()["PMC_SUMMARY"]
     if not PMC_SUMMARY.exists():
         return None, f"{PMC_SUMMARY.relative_to(ROOT)} not collected yet"
     meta, vals = {}, {}
@@ -192,7 +194,7 @@ def measured_traffic(kernel: str, quad_m: int, positions_per_launch: float):
         elif "," in line and not line.startswith("counter"):
             k, v = line.rsplit(",", 1)
             vals[k] = float(v)
-    if meta.get("kernel") != kernel:
+    if not meta.get("kernel", "").startswith(kernel):          # "k_sites" / "k_sites<true" (the > 2^31-row instantiation)
         return None, f"summary is for {meta.get('kernel')}, the run's dominant kernel is {kernel}"
     if meta.get("source_sha256") != source_hash():
         return None, f"summary was measured on other kernel sources ({meta.get('source_sha256')} != {source_hash()}): re-run tools/profile_c2.sh"
@@ -395,8 +397,12 @@ def roofline_block(run: Run, k0, tallies, config_key):
     per_launch = alg / n_seg
     avg_ms = kern_ms / max(n_launch, 1)
     achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, src = (None, "not the configs[1] headline") if config_key != "c2_100mbp" else \
-        measured_traffic(kernel_name, site_m, run.my_positions / n_seg)
+    if config_key == "c2_100mbp":
+        traffic, src = measured_traffic(kernel_name, site_m, run.my_positions / n_seg)
+    elif config_key.startswith("ns_") and run.world == 1:
+        traffic, src = measured_traffic(kernel_name, site_m, run.my_positions / n_seg, PMC_SUMMARY_NS)   # mean over the launches of a pass
+    else:
+        traffic, src = None, "no PMC pass for this workload"
     searched = max(int(tallies[7]), 1)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": kernel_name, "scope": "the dominant kernel alone (HIP events around it); "

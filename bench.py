@@ -2,26 +2,27 @@
 """bench.py -- genome positions/sec of the min-unique-k search (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Two workloads per run, both with the sequence bytes resident in HBM before the timed region and one STEP = one pass of
-the hot path (k_sites with its encode stage, repeat probes, k_resolve) over every position of the rank's work units.  A
-pass of several segments (north star, `reference_batch`, --config c3 / c5) deals them round-robin over --streams HIP
-streams (default 2): the handle keeps its launch scratch per stream, neighbouring segments overlap; the headline is ONE
-launch per pass on one stream, and its kernel is timed with HIP events on that stream in the timed passes themselves:
+With N > 1 and no launcher environment (WORLD_SIZE unset) the script starts its own N ranks -- a CHILD
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...`, before anything here imports torch or
+touches HIP -- and exits with the child's code; launched by torch.distributed.run directly it is one rank per GPU.
 
-  * headline (`value`): BASELINE.json configs[1] -- synthetic 100 Mbp single-record FASTA, uniform ACGT
-    (numpy default_rng(20260515)), search range 20:200.  At N > 1 the path shards by independent units with no
-    data-path collective, so the job grows with N ("scaling": "weak"): N records of 100 Mbp (seeds 20260515 + i) in ONE
-    index, replicated in every GPU's HBM; rank r searches record r.  `value` = positions all ranks searched / the
-    slowest rank's time.
-  * `north_star`: the configuration BASELINE.json's north_star states its target on -- the ~3 Gbp genome of
-    configs[2] (24 human-shaped records, 3.09 Gbp) searched at 20:200 on a device-built index, its work units dealt to
-    the ranks in interleaved chunks (fixed genome: strong scaling), plus, at N = 1, the same genome through the native
-    driver FASTA in -> files out (`end_to_end`).
+The headline (`value`) is the configuration BASELINE.json's metric and north_star are quoted on, at EVERY N: the
+synthetic ~3 Gbp genome (24 human-shaped records, 3.09 Gbp, uniform ACGT, seeds 20260516+i) searched at 20:200 on
+a device-built both-strand index, the genome fixed as N grows ("scaling": "strong"): its positions are cut into
+interleaved ~64 M chunks, chunk c owned by rank c mod N, no data-path collective, the index replicated in every GPU's
+HBM.  One STEP = one pass of the hot path (k_sites with its encode stage, repeat probes, k_resolve) over every position
+of the rank's work units, sequence bytes resident in HBM before the timed region; the segments of a pass are dealt
+round-robin over --streams HIP streams (default 2).  After the timed region ONE RCCL gather (N > 1) collects the
+per-rank uint8 results on rank 0 (`final_gather_ms`, outside `value`).
 
-After the timed region ONE RCCL gather (N > 1) collects the per-rank uint8 results on rank 0 (`final_gather_ms`,
-outside `value`).  Rank 0 prints ONE JSON line (README / DESIGN.md "Measurement").
+At N = 1 the same run also reports: `roofline` for the kernel with the largest total time (HIP events on the launch
+stream; PMC traffic from the committed pass under profiles/), `cpu_baseline` (the oracle's C/OpenMP port of the
+reference schedule on an FM-index of THIS genome, timed on a bounded sample and compared bit for bit with the GPU
+output), `end_to_end` (the same genome through the native driver, FASTA in -> files out) and the nested block
+`configs1` (BASELINE configs[1]: 100 Mbp single record, one launch per pass -- round 2's headline).
+
+Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
 """
 from __future__ import annotations
 
@@ -30,6 +31,7 @@ import hashlib
 import json
 import os
 import shutil
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -40,13 +42,14 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-BATCH = 100_000_000            # positions per launch.  The reference's --kmer-batch-size default (10 M) exists "to control
-#                                memory usage" on the host; with 288 GB of HBM a launch takes a whole 100 Mbp record.  The
-#                                throughput at the reference's 10 M is measured in the same run (`reference_batch`).
+BATCH = 1 << 28                # positions per launch: one launch per record (the largest has 249 M) or per 64 M chunk.  The
+#                                reference's --kmer-batch-size default (10 M) exists "to control memory usage" on the host; the
+#                                throughput at the reference's 10 M is measured in the `configs1` block (`reference_batch`).
 REFERENCE_BATCH = 10_000_000
+CHUNK = 64 << 20               # interleaved chunk of the multi-GPU split (newmap_amd/parallel.py)
 C2_SEED, C2_BASES = 20260515, 100_000_000
-PMC_SUMMARY = ROOT / "profiles" / "round2" / "pmc_sites_kernel_summary.csv"
-PMC_SUMMARY_NS = ROOT / "profiles" / "round2" / "pmc_ns_sites_kernel_summary.csv"     # the north-star block (tools/profile_ns.sh)
+PROFILES = ROOT / "profiles" / "round3"
+PMC_SUMMARIES = {"ns": PROFILES / "pmc_ns_sites_kernel_summary.csv", "c2": PROFILES / "pmc_sites_kernel_summary.csv"}
 KERNEL_SOURCES = [ROOT / "newmap_amd" / "csrc" / "nm_engine.hip", ROOT / "newmap_amd" / "csrc" / "nm_core.h"]
 
 
@@ -57,11 +60,12 @@ def log(*a):
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)        # 100 passes of ~0.4 ms: a timed region of ~40 ms
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2",
-                    help="headline workload: c2 = BASELINE configs[1] (default); c3 / c5 = configs[2] / configs[4] at --mbp (capability runs)")
-    ap.add_argument("--mbp", type=float, default=None, help="genome size in Mbp of a c3 / c5 capability run")
+    ap.add_argument("--steps", type=int, default=20)         # 20 passes of ~17 ms over 3.09 Gbp: a timed region of ~0.35 s
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=["ns", "c2", "c3", "c5"], default="ns",
+                    help="headline workload: ns = the metric's own configuration (default: ~3 Gbp genome, 20:200); c2 / c3 / c5 = "
+                         "BASELINE configs[1] / [2] / [4] as capability runs")
+    ap.add_argument("--mbp", type=float, default=None, help="shrink the headline genome to this many Mbp (rehearsals, tests)")
     ap.add_argument("--seed-length", default="auto",
                     help="device tables: auto (default: sized for throughput), auto-small (<= 20 GB, what the one-shot CLI uses), "
                          "file (the index's seed length, 12), or a seed length 0..16")
@@ -72,14 +76,28 @@ def parse(argv=None):
     ap.add_argument("--index-builder", choices=["host", "device"], default="device",
                     help="suffix sort on the GPU (default) or on the host cores (same index file; not timed in `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-reference-batch", action="store_true",
-                    help="skip the extra passes at the reference's 10 M batch (profiling runs: one launch size per kernel)")
-    ap.add_argument("--no-north-star", action="store_true", help="skip the 3 Gbp / 20:200 block (profiling runs)")
-    ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTA-in -> files-out leg of the north-star block (kernel traces)")
-    ap.add_argument("--north-star-mbp", type=float, default=None, help="shrink the north-star genome (rehearsals)")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the baseline sample (30 s: the whole 100 Mbp on the 128 threads of the GPU box)")
+    ap.add_argument("--no-configs1", action="store_true", help="skip the nested configs[1] block (profiling runs)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTA-in -> files-out leg (kernel traces)")
+    ap.add_argument("--no-spread", action="store_true", help="skip the separately synchronised passes behind `pass_ms` (kernel traces)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     ap.add_argument("--workdir", default=os.environ.get("NEWMAP_AMD_BENCH_DIR", "/tmp/newmap_amd_bench"))
     return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 from a bare shell: N child ranks under torch.distributed.run.  Nothing in THIS process has imported
+    torch or touched HIP (a process that has initialised the GPU must not exec or be replaced); it only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    log(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
 
 
 # ------------------------------------------------------------------------------------------ workloads
@@ -99,43 +117,45 @@ class Workload:
             self._cache[i] = synth.uniform_dna(n, seed) if kind == "uniform" else synth.tandem_dna(n, seed)
         return self._cache[i]
 
-    def drop(self, i):
-        self._cache.pop(i, None)
+    def drop(self, i=None):
+        if i is None:
+            self._cache.clear()
+        else:
+            self._cache.pop(i, None)
 
 
-def headline_workload(args, world) -> Workload:
+def human_shaped(mbp, first_seed):
     from newmap_amd import synth
+    total = sum(synth.HUMAN_SHAPED)
+    f = 1.0 if mbp is None else mbp * 1e6 / total
+    names = [f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY"]
+    return [(nm, first_seed + i, max(1000, int(L * f)), "uniform") for i, (nm, L) in enumerate(zip(names, synth.HUMAN_SHAPED))]
+
+
+def headline_workload(args) -> Workload:
+    if args.config == "ns":
+        recs = human_shaped(args.mbp, 20260516)
+        w = Workload("ns", "", (20, 200), recs)
+        w.key = f"ns_{w.total / 1e6:g}mbp"
+        w.desc = (f"the metric's configuration: synthetic ~3 Gbp genome ({w.total / 1e6:g} Mbp, 24 human-shaped records, uniform ACGT, "
+                  "seeds 20260516+i -- the genome of BASELINE configs[2])")
+        return w
     if args.config == "c2":
-        if world == 1:
-            return Workload("c2_100mbp", "configs[1]: synthetic 100 Mbp single-record FASTA (uniform ACGT, seed 20260515)",
-                            (20, 200), [("chr1", C2_SEED, C2_BASES, "uniform")])
-        recs = [(f"chr{i + 1}", C2_SEED + i, C2_BASES, "uniform") for i in range(world)]
-        return Workload(f"c2_weak_{world}x100mbp",
-                        f"configs[1] per GPU: {world} records of 100 Mbp (uniform ACGT, seeds 20260515+i) in one replicated index, rank r searches record r",
-                        (20, 200), recs)
+        return configs1_workload(int((args.mbp or 100) * 1e6))
     if args.config == "c3":
-        total = sum(synth.HUMAN_SHAPED)
-        f = 1.0 if args.mbp is None else args.mbp * 1e6 / total
-        names = [f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY"]
-        recs = [(nm, 20260516 + i, max(1000, int(L * f)), "uniform") for i, (nm, L) in enumerate(zip(names, synth.HUMAN_SHAPED))]
-        w = Workload(f"c3_{sum(r[2] for r in recs) / 1e6:g}mbp", "configs[2]: synthetic {mbp:g} Mbp FASTA as 24 human-shaped records (uniform ACGT, seeds 20260516+i)", (24, 150), recs)
-        w.desc = w.desc.format(mbp=w.total / 1e6)
+        recs = human_shaped(args.mbp, 20260516)
+        w = Workload("c3", "", (24, 150), recs)
+        w.key = f"c3_{w.total / 1e6:g}mbp"
+        w.desc = f"configs[2]: synthetic {w.total / 1e6:g} Mbp FASTA as 24 human-shaped records (uniform ACGT, seeds 20260516+i)"
         return w
     n = int((args.mbp or 1000) * 1e6)
     return Workload(f"c5_{n / 1e6:g}mbp", f"configs[4]: synthetic {n / 1e6:g} Mbp, 50 % tandem repeats (seed 20260517)", (20, 255),
                     [("rep1", 20260517, n, "tandem")])
 
 
-def north_star_workload(args) -> Workload:
-    from newmap_amd import synth
-    total = sum(synth.HUMAN_SHAPED)
-    f = 1.0 if args.north_star_mbp is None else args.north_star_mbp * 1e6 / total
-    names = [f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY"]
-    recs = [(nm, 20260516 + i, max(1000, int(L * f)), "uniform") for i, (nm, L) in enumerate(zip(names, synth.HUMAN_SHAPED))]
-    w = Workload(f"ns_{sum(r[2] for r in recs) / 1e6:g}mbp", "", (20, 200), recs)
-    w.desc = (f"north_star: the synthetic ~3 Gbp genome of configs[2] ({w.total / 1e6:g} Mbp, 24 human-shaped records, uniform ACGT, "
-              "seeds 20260516+i) searched at the north-star range 20:200")
-    return w
+def configs1_workload(n=C2_BASES) -> Workload:
+    return Workload(f"c2_{n / 1e6:g}mbp", f"configs[1]: synthetic {n / 1e6:g} Mbp single-record FASTA (uniform ACGT, seed 20260515)",
+                    (20, 200), [("chr1", C2_SEED, n, "uniform")])
 
 
 def prepare_index(args, wl: Workload, rank, barrier):
@@ -174,18 +194,17 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel: str, quad_m: int, positions_per_launch: float, summary: Path = None):
+def measured_traffic(kernel: str, quad_m: int, positions_per_launch: float, summary: Path):
     """HBM-side read + write bytes per launch of the dominant kernel from the PMC pass committed under profiles/
     (rocprofv3 --pmc cannot run inside this process).  The summary names the kernel sources it was measured on
     (sha256 of nm_engine.hip + nm_core.h), the core length of the table the sites read and the launch size; a summary
     of OTHER sources, another table or another launch size reports null with the reason.  Reads: TCC_EA0_RDREQ x 128 B
     (on gfx950 every read request of this gather is a 128-byte one, TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ -- the guide's
     "FETCH_SIZE reports half" correction stated exactly); writes: TCC_EA0_WRREQ x 64 B."""
-    PMC_SUMMARY = summary or globals()["PMC_SUMMARY"]
-    if not PMC_SUMMARY.exists():
-        return None, f"{PMC_SUMMARY.relative_to(ROOT)} not collected yet"
+    if summary is None or not summary.exists():
+        return None, f"{summary.relative_to(ROOT) if summary else 'PMC summary'} not collected for this workload"
     meta, vals = {}, {}
-    for line in PMC_SUMMARY.read_text().splitlines():
+    for line in summary.read_text().splitlines():
         if line.startswith("#"):
             for kv in line[1:].split(","):
                 if "=" in kv:
@@ -197,12 +216,15 @@ def measured_traffic(kernel: str, quad_m: int, positions_per_launch: float, summ
     if not meta.get("kernel", "").startswith(kernel):          # "k_sites" / "k_sites<true" (the > 2^31-row instantiation)
         return None, f"summary is for {meta.get('kernel')}, the run's dominant kernel is {kernel}"
     if meta.get("source_sha256") != source_hash():
-        return None, f"summary was measured on other kernel sources ({meta.get('source_sha256')} != {source_hash()}): re-run tools/profile_c2.sh"
+        return None, f"summary was measured on other kernel sources ({meta.get('source_sha256')} != {source_hash()}): re-run the PMC pass"
     if int(meta.get("site_core_length", -1)) != quad_m or abs(float(meta.get("positions_per_launch", 0)) - positions_per_launch) > 0.01 * positions_per_launch:
         return None, "summary was measured with another table or launch size"
     if "TCC_EA0_RDREQ_sum" not in vals:
         return None, "summary lacks TCC_EA0_RDREQ_sum"
-    return vals["TCC_EA0_RDREQ_sum"] * 128.0 + vals.get("TCC_EA0_WRREQ_sum", 0.0) * 64.0, str(PMC_SUMMARY.relative_to(ROOT))
+    return vals["TCC_EA0_RDREQ_sum"] * 128.0 + vals.get("TCC_EA0_WRREQ_sum", 0.0) * 64.0, str(summary.relative_to(ROOT))
+
+
+KINDS = {0: "search", 1: "segment", 2: "k_repeat_probe_coarse", 3: "k_repeat_probe", 4: "k_resolve"}
 
 
 class Run:
@@ -251,25 +273,24 @@ class Run:
         for j, (so, seg_len, cnt, oo, i) in enumerate(segs):
             self.ix.min_unique_segment_dev(sp + so, seg_len, cnt, self.KMIN, self.KMAX, True, 1, op + oo, st + 64 * i, streams[j % len(streams)])
 
-    def max_over_ranks(self, x: float) -> float:
+    def _reduce(self, x, op):
         if self.world == 1:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.torch.device("cpu") if self.rehearse else self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        t = self.torch.tensor(x, dtype=self.torch.float64, device=self.torch.device("cpu") if self.rehearse else self.dev)
+        self.dist.all_reduce(t, op=op)
+        return t.cpu().tolist()
+
+    def max_over_ranks(self, x: float) -> float:
+        return x if self.world == 1 else float(self._reduce([x], self.dist.ReduceOp.MAX)[0])
 
     def sum_over_ranks(self, x: float) -> float:
-        if self.world == 1:
-            return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.torch.device("cpu") if self.rehearse else self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
+        return x if self.world == 1 else float(self._reduce([x], self.dist.ReduceOp.SUM)[0])
 
     def timed(self, steps, warmup, segs=None, kernel_events=True):
         """`steps` passes between barrier + synchronize on both sides.  Kernel times (HIP events on the launch stream,
-        read_timing kinds 0 and 1) are taken in the timed passes themselves when a pass runs on ONE stream (the headline:
-        one launch per pass); passes whose segments overlap on several streams get one extra pass on one stream for
-        them afterwards (outside `elapsed`), since events around overlapping kernels time each other's work."""
+        read_timing kinds 0 .. 4) are taken in the timed passes themselves when a pass runs on ONE stream (one launch per
+        pass); passes whose segments overlap on several streams get one extra pass on one stream for them afterwards
+        (outside `elapsed`), since events around overlapping kernels time each other's work."""
         torch = self.torch
         n_segs = len(self.segs if segs is None else segs)
         overlapped = len(self.streams) > 1 and n_segs > 1
@@ -285,7 +306,7 @@ class Run:
         torch.cuda.synchronize()
         self.barrier()
         elapsed = time.perf_counter() - t0
-        k0 = k1 = (0, 0.0, 0.0)
+        kinds = {k: (0, 0.0, 0.0) for k in KINDS}
         if kernel_events:
             if overlapped:
                 snap = self.d_out.clone()                         # what the overlapped passes left
@@ -297,10 +318,26 @@ class Run:
                 del snap
                 if not self.overlap_identical:
                     raise SystemExit("segments overlapped on several streams gave a different output than on one stream")
-            k0 = self.ix.read_timing(0)
-            k1 = self.ix.read_timing(1)
+            kinds = {k: self.ix.read_timing(k) for k in KINDS}
             self.ix.set_timing(False)
-        return self.max_over_ranks(elapsed), k0, k1
+        return self.max_over_ranks(elapsed), kinds
+
+    def spread(self, steps, segs=None):
+        """min / median / max of `steps` further passes, each bracketed by its own barrier + synchronize (slowest rank
+        per pass).  Separate from `value`: a synchronised pass cannot overlap its tail with the next one's head."""
+        torch = self.torch
+        ts = []
+        for _ in range(steps):
+            torch.cuda.synchronize()
+            self.barrier()
+            t0 = time.perf_counter()
+            self.step(segs)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        if self.world > 1:
+            ts = self._reduce(ts, self.dist.ReduceOp.MAX)
+        return {"min": min(ts), "median": statistics.median(ts), "max": max(ts), "passes": len(ts),
+                "note": "each pass synchronised on its own (slowest rank per pass); the timed region above runs its passes back to back"}
 
     def check_status(self):
         st = self.d_status.cpu().numpy()
@@ -332,8 +369,8 @@ class Run:
         return tallies, probe
 
     def verify_sample(self, samples=20000):
-        """No oracle fits a multi-Gbp genome: re-derive a sample of the outputs through the count seam -- at the
-        reported length the both-strand count is 1, one base shorter (if allowed) it is not."""
+        """No oracle fits a multi-Gbp both-strand text: re-derive a sample of the outputs through the count seam -- at
+        the reported length the both-strand count is 1, one base shorter (if allowed) it is not."""
         rng = np.random.default_rng(7 + self.rank)
         comp = bytes.maketrans(b"ACGT", b"TGCA")
         checked = 0
@@ -375,7 +412,9 @@ class Run:
         tg = time.perf_counter()
         dist.gather(pad, gathered, dst=0)
         torch.cuda.synchronize()
-        return {"ms": (time.perf_counter() - tg) * 1e3, "bytes_per_rank": per}
+        ms = (time.perf_counter() - tg) * 1e3
+        got = int(sum(int((g != 0).any()) for g in gathered)) if self.rank == 0 else 0
+        return {"ms": ms, "bytes_per_rank": per, "ranks_with_results": got}
 
     def close(self):
         self.ix.close()
@@ -383,37 +422,56 @@ class Run:
         self.torch.cuda.empty_cache()
 
 
-def roofline_block(run: Run, k0, tallies, config_key):
-    n_launch, kern_ms, _ = k0
-    kernel_name = {1: "k_min_unique", 5: "k_sites"}.get(run.ix.info()["last_range_kernel"], "?")
+def kernels_block(kinds):
+    return {KINDS[k]: {"launches": int(n), "total_ms": float(tot), "max_ms": float(mx)} for k, (n, tot, mx) in kinds.items() if n}
+
+
+def roofline_block(run: Run, kinds, tallies, probe, pmc_summary):
+    """`roofline` for the kernel with the LARGEST total time among the kernels of a segment: the search kernel (k_sites, or
+    k_min_unique), the repeat probes (coarse + fine share their counters) or k_resolve.  achieved = algorithmic bytes
+    per launch / mean launch duration (HIP events on the stream the kernel is launched on)."""
+    info = run.ix.info()
+    search_name = {1: "k_min_unique", 5: "k_sites"}.get(info["last_range_kernel"], "?")
     n_seg = max(len(run.segs), 1)
-    # algorithmic bytes of the DOMINANT kernel per launch (DESIGN.md "Measurement"): 8 B per table word it reads,
-    # 1 sequence byte in and one output element out per position.  k_min_unique (no quad table): + 16 B per rank structure
-    site_m = run.ix.info().get("last_site_core_length", 0)
-    if kernel_name == "k_sites":
-        alg = tallies[5] * 8 + run.my_positions * 2
+    site_m = info.get("last_site_core_length", 0)
+    lf_bytes = 16 if run.info["lf_blocks"] else 32
+    cand = {}
+    n0, t0, _ = kinds[0]
+    if search_name == "k_sites":       # 8 B per table word read, 1 sequence byte in, one output element out per position
+        cand[search_name] = (n0, t0, tallies[5] * 8 + run.my_positions * 2)
     else:
-        alg = tallies[4] * (16 if run.info["lf_blocks"] else 32) + tallies[5] * 8 + run.my_positions * 2
+        cand[search_name] = (n0, t0, tallies[4] * lf_bytes + tallies[5] * 8 + run.my_positions * 2)
+    # probes: one 32-byte encoded word + (seed entry 8 B) per probe that walks, 16 B per LF entry read; 4 B word out per stride
+    n2, t2, _ = kinds[2]
+    n3, t3, _ = kinds[3]
+    if n2 or n3:
+        cand["k_repeat_probe(_coarse)"] = (max(n3, 1), t2 + t3, probe["rank_blocks"] * lf_bytes + probe["seed_lookups"] * (8 + 32) + run.my_positions / 64 * 4)
+    n4, t4, _ = kinds[4]
+    if n4:                             # need bitmap in (1 bit per position), LF entries + seed / second-chance words, elements out
+        cand["k_resolve"] = (n4, t4, tallies[4] * lf_bytes + tallies[6] * 8 + run.my_positions / 8)
+    name = max(cand, key=lambda k_: cand[k_][1])
+    n_launch, total_ms, alg = cand[name]
     per_launch = alg / n_seg
-    avg_ms = kern_ms / max(n_launch, 1)
+    avg_ms = total_ms / max(n_launch, 1)
     achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    if config_key == "c2_100mbp":
-        traffic, src = measured_traffic(kernel_name, site_m, run.my_positions / n_seg)
-    elif config_key.startswith("ns_") and run.world == 1:
-        traffic, src = measured_traffic(kernel_name, site_m, run.my_positions / n_seg, PMC_SUMMARY_NS)   # mean over the launches of a pass
+    if name == "k_sites" and run.world == 1:
+        traffic, src = measured_traffic(name, site_m, run.my_positions / n_seg, pmc_summary)   # mean over the launches of a pass
     else:
-        traffic, src = None, "no PMC pass for this workload"
+        traffic, src = None, "no PMC pass for this kernel / workload"
     searched = max(int(tallies[7]), 1)
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src, "kernel": kernel_name, "scope": "the dominant kernel alone (HIP events around it); "
-            "encode pass, repeat probes and k_resolve are in `pipeline`", "avg_launch_ms": avg_ms, "launches": n_launch,
-            "algorithmic_bytes_per_launch": per_launch, "site_core_length": site_m,
-            "positions_per_table_line": run.my_positions / max(tallies[5] / 4.0, 1.0) if kernel_name == "k_sites" else None,
-            "table_words_per_position": float(tallies[5] / searched)}
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": src, "kernel": name,
+           "scope": "the kernel with the largest total time of a pass (HIP events around it on its launch stream); all kernels are in `kernels` / `pipeline`",
+           "avg_launch_ms": avg_ms, "launches": int(n_launch), "algorithmic_bytes_per_launch": per_launch,
+           "kernel_share_of_pass": {k_: v_[1] / max(sum(c[1] for c in cand.values()), 1e-12) for k_, v_ in cand.items()}}
+    if name == "k_sites":
+        out.update({"site_core_length": site_m, "positions_per_table_line": run.my_positions / max(tallies[5] / 4.0, 1.0),
+                    "table_words_per_position": float(tallies[5] / searched)})
+    return out
 
 
-def pipeline_block(run: Run, k1, tallies, probe):
-    n_seg_launch, all_ms, _ = k1
+def pipeline_block(run: Run, kinds, tallies, probe):
+    n_seg_launch, all_ms, _ = kinds[1]
     searched = max(int(tallies[7]), 1)
     rank_bytes = 16 if run.info["lf_blocks"] else 32
     alg_all = tallies[5] * 8 + tallies[6] * 8 + tallies[4] * rank_bytes + probe["seed_lookups"] * 8 + probe["rank_blocks"] * rank_bytes + run.my_positions * 2
@@ -426,30 +484,47 @@ def pipeline_block(run: Run, k1, tallies, probe):
                               "seed_lookups_per_position": probe["seed_lookups"] / max(run.my_positions, 1)}}
 
 
-def cpu_baseline(args, genome: np.ndarray, gpu_out: np.ndarray, KMIN: int, KMAX: int):
+def cpu_baseline(args, wl: Workload, gpu_out: np.ndarray, KMIN: int, KMAX: int):
     """The oracle's C/OpenMP port of the reference algorithm (forward-strand FM-index, restart per probe, forward +
     reverse-complement queries, 4^12 seed table, 32 queries in flight per thread with software prefetch --
-    src/newmap-count.c:196 awFmParallelSearchCount as published) on a bounded sample, checked against the GPU output."""
+    src/newmap-count.c:196 awFmParallelSearchCount as published; schedule newmap/search.py:464-544) on an FM-index of the
+    WHOLE workload genome (all records, forward strand: what `newmap index` builds), timed on a bounded sample -- the
+    first positions of the first record -- and compared bit for bit with the GPU output of the same positions."""
     from oracle import ref_driver as rd
     threads = rd.lib().or_num_threads()
-    log(f"[bench] cpu baseline: building the oracle's forward-strand FM-index on {threads} threads ...")
+    if wl.total + len(wl.records) >= (1 << 32) - 64:
+        return {"value": None, "note": "the oracle's 32-bit suffix array holds texts below 2^32 symbols"}
+    log(f"[bench] cpu baseline: building the oracle's forward-strand FM-index of {wl.total / 1e6:g} Mbp on {threads} threads ...")
     t0 = time.time()
-    oracle = rd.OracleIndex([genome.tobytes()])
+    recs = [wl.record(i) for i in range(len(wl.records))]
+    t_gen = time.time() - t0
+    t0 = time.time()
+    oracle = rd.OracleIndex(recs)
+    t_sa = time.time() - t0
+    t0 = time.time()
     oracle.enable_fm(12)
-    t_index = time.time() - t0
-    calib = min(2_000_000, len(genome) // 4)
+    oracle.drop_suffix_array()
+    t_fm = time.time() - t0
+    genome = recs[0]
+    for i in range(1, len(wl.records)):
+        wl.drop(i)
+    del recs
+    avail = len(genome) - KMAX
+    calib = max(min(1_000_000, avail // 4), 1)
     t0 = time.time()
     rd.ref_binary_search_segment_c(oracle, genome[:calib + KMAX - 1].tobytes(), calib, KMIN, KMAX, fm=True)
     rate = calib / max(time.time() - t0, 1e-6)
-    sample = int(min(max(rate * args.cpu_seconds, calib), len(genome) - KMAX))
+    sample = int(min(max(rate * args.cpu_seconds, calib), avail, 100_000_000, gpu_out.size))
     sample = sample // 1_000_000 * 1_000_000 if sample > 2_000_000 else sample
     t0 = time.time()
     got, _, stats = rd.ref_binary_search_segment_c(oracle, genome[:sample + KMAX - 1].tobytes(), sample, KMIN, KMAX, fm=True)
     dt = time.time() - t0
     same = bool(np.array_equal(got.astype(np.uint8), gpu_out[:sample]))
-    log(f"[bench] cpu baseline: {sample} positions in {dt:.1f}s on {threads} threads (oracle index {t_index:.1f}s); bit-exact vs GPU: {same}")
+    log(f"[bench] cpu baseline: {sample} positions in {dt:.1f}s on {threads} threads (records {t_gen:.1f}s, suffix array {t_sa:.1f}s, "
+        f"FM blocks + seed table {t_fm:.1f}s); bit-exact vs GPU: {same}")
     if not same:
         raise SystemExit("GPU output differs from the CPU oracle on the baseline sample")
+    del oracle
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -461,15 +536,18 @@ def cpu_baseline(args, genome: np.ndarray, gpu_out: np.ndarray, KMIN: int, KMAX:
     return {"value": sample / dt, "unit": "positions/s", "cores": threads, "kind": "port",
             "host": f"{cpu_model}, {os.cpu_count()} logical CPUs visible, oracle built -O3 -march=x86-64-v3 (AVX2, POPCNT), OpenMP, "
                     "32 backward searches in flight per thread with software prefetch",
-            "sample": f"first {sample} positions of the {len(genome)}-base workload, {KMIN}:{KMAX}, "
+            "index": f"forward-strand FM-index of all {len(wl.records)} records of the workload genome ({wl.total} bases; 128-byte blocks of 256 rows, "
+                     f"4^12 seed table), built in {t_sa + t_fm:.1f}s (not timed in `value`)",
+            "sample": f"first {sample} positions of record {wl.records[0][0]} of the {wl.total}-base workload, {KMIN}:{KMAX}, "
                       f"{stats['probes'] / sample:.1f} probes and {2 * stats['probe_len'] / sample:.0f} LF steps "
                       "per position (reference schedule), index build excluded; output bit-exact vs the GPU's",
+            "extrapolated": sample < wl.total, "sample_positions": sample, "sample_seconds": dt,
             "bit_exact_vs_gpu": same}
 
 
 def end_to_end(args, wl: Workload, fa, idx, dev_index, gpu_run: Run):
-    """the same genome through the native driver: FASTA in -> <id>.unique.uint8 files out (index already open, the
-    one-shot CLI's small tables); files compared with the bench outputs of the first units"""
+    """the same genome through the native driver: FASTA in -> <id>.unique.uint8 files out (the one-shot CLI's small
+    tables); files compared with the bench outputs of the first units"""
     from newmap_amd.engine import Index
     out = Path(args.workdir) / f"{wl.key}_e2e_out"
     shutil.rmtree(out, ignore_errors=True)
@@ -491,23 +569,63 @@ def end_to_end(args, wl: Workload, fa, idx, dev_index, gpu_run: Run):
             raise SystemExit(f"end-to-end output of {name} differs from the bench pass")
         checked += n
     files = sorted(out.iterdir())
-    res = {"what": "nm_search_fasta: FASTA in -> <id>.unique.uint8 files out, index already open (auto-small tables), 1 GPU",
+    res = {"what": "nm_search_fasta: FASTA in -> <id>.unique.uint8 files out (auto-small tables), 1 GPU",
            "cli_search_s": t_search, "index_open_s": t_open, "positions": int(total["positions"]),
-           "positions_per_s": total["positions"] / t_search, "files": len(files), "bytes_written": int(sum(f.stat().st_size for f in files)),
+           "positions_per_s": total["positions"] / t_search, "positions_per_s_with_index_open": total["positions"] / (t_search + t_open),
+           "files": len(files), "bytes_written": int(sum(f.stat().st_size for f in files)),
            "verified_bytes_equal_bench_pass": checked}
     shutil.rmtree(out, ignore_errors=True)
     return res
 
 
+def configs1_block(args, rank, dev, barrier, dist, rehearse):
+    """BASELINE configs[1] (round 2's headline): 100 Mbp single record, 20:200, ONE launch of 100 M positions per pass,
+    plus the same passes cut into the reference's 10 M batch"""
+    from newmap_amd import parallel
+    wl = configs1_workload()
+    KMIN, KMAX = wl.krange
+    fa, idx_path, prep = prepare_index(args, wl, rank, barrier)
+    ranges = [(0, wl.total)]
+    units = parallel.units_for_ranges(wl.lengths, ranges, wl.total, KMAX)
+    run = Run(args, wl, idx_path, units, rank, 1, dev, barrier, dist, rehearse, args.seed_length)
+    steps = max(args.steps, 50)
+    elapsed, kinds = run.timed(steps, args.warmup)
+    run.check_status()
+    ref_units = parallel.units_for_ranges(wl.lengths, ranges, REFERENCE_BATCH, KMAX)
+    row0 = run.more_status_rows(len(ref_units))
+    ref_segs = [(ru.start, ru.seg_len, ru.count, ru.start, row0 + j) for j, ru in enumerate(ref_units)]
+    ref_elapsed, _ = run.timed(steps, 1, ref_segs, kernel_events=False)
+    ref_batch = {"batch": REFERENCE_BATCH, "value": wl.total * steps / ref_elapsed, "unit": "positions/s",
+                 "ms_per_step": ref_elapsed / steps * 1e3, "launches_per_step": len(ref_segs), "streams": len(run.streams)}
+    if len(run.streams) > 1:
+        saved, run.streams = run.streams, run.streams[:1]
+        one_elapsed, _ = run.timed(steps, 1, ref_segs, kernel_events=False)
+        run.streams = saved
+        ref_batch["value_one_stream"] = wl.total * steps / one_elapsed
+    run.check_status()
+    tallies, probe = run.counters()
+    block = {"workload": wl.desc + f", search-range {KMIN}:{KMAX}, both strands, one launch per pass", "positions": wl.total,
+             "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "value": wl.total * steps / elapsed, "unit": "positions/s",
+             "index_bytes_hbm": run.info["device_bytes"], "index_open_s": run.t_open,
+             "seed_length": run.info["seed_length"], "quad_core_length": run.info.get("quad_core_length", 0),
+             "quad_small_core_length": run.info.get("quad_small_core_length", 0),
+             "roofline": roofline_block(run, kinds, tallies, probe, PMC_SUMMARIES["c2"]), "kernels": kernels_block(kinds),
+             "pipeline": pipeline_block(run, kinds, tallies, probe), "reference_batch": ref_batch,
+             "verify": run.verify_sample(),
+             "host": {"fasta_write_s": prep["fasta_write_s"], "index_build_s": prep["index_build_s"], "index_builder": args.index_builder}}
+    run.close()
+    wl.drop()
+    return block
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))          # nothing below has run: no torch import, no HIP call in this process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
     import torch                                   # first: libnewmap_amd.so binds to torch's HIP runtime
     import torch.distributed as dist
@@ -516,63 +634,45 @@ def main():
     # one rank per GPU.  NEWMAP_AMD_BENCH_REHEARSE=1 (rehearsal of the N > 1 code path on a box with fewer GPUs
     # than ranks): ranks share the devices and the collectives go over gloo -- RCCL refuses two ranks on one GPU
     rehearse = os.environ.get("NEWMAP_AMD_BENCH_REHEARSE") == "1"
-    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if rehearse else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+            ones = torch.ones(1, device=dev)
+            dist.all_reduce(ones)                   # the world RCCL actually formed
+            rccl_ranks = int(ones.item())
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     t_bench = time.time()
-    # ------------------------------------------------------------------ headline
-    wl = headline_workload(args, world)
+    wl = headline_workload(args)
     KMIN, KMAX = wl.krange
     fa, idx_path, prep = prepare_index(args, wl, rank, barrier)
-    if world == 1 or args.config != "c2":
-        ranges = parallel.interleaved_ranges(wl.total, world, max(args.batch, 1))[rank] if world > 1 else [(0, wl.total)]
-    else:                                           # weak scaling: rank r owns record r
-        base = int(sum(wl.lengths[:rank]))
-        ranges = [(base, base + wl.lengths[rank])]
-    units = parallel.units_for_ranges(wl.lengths, ranges, args.batch, KMAX)
+    # fixed genome at every N: interleaved ~64 M chunks, chunk c owned by rank c mod N (one rank: the records themselves)
+    ranges = parallel.interleaved_ranges(wl.total, world, CHUNK)[rank] if world > 1 else [(0, wl.total)]
+    units = parallel.units_for_ranges(wl.lengths, ranges, max(args.batch, 1), KMAX)
     run = Run(args, wl, idx_path, units, rank, world, dev, barrier, dist, rehearse, args.seed_length)
-    elapsed, k0, k1 = run.timed(args.steps, args.warmup)
+    keep = {u.record for u in units[:3]} | {0}
+    for i in range(len(wl.records)):               # the device holds the units now
+        if i not in keep:
+            wl.drop(i)
+    elapsed, kinds = run.timed(args.steps, args.warmup)
     run.check_status()
     total_positions = run.sum_over_ranks(run.my_positions)
     if rank == 0:
-        log(f"[bench] {wl.key}: {args.steps} steps in {elapsed:.3f}s; {k0[0]} launches of the dominant kernel, {k0[1]:.2f} ms in it "
-            f"(max {k0[2]:.3f} ms); all kernels of the segments {k1[1]:.2f} ms")
-    ref_batch = None
-    if args.batch > REFERENCE_BATCH and not args.no_reference_batch:
-        # the same passes cut into the reference's default batch (10 M positions per launch), for comparison
-        ref_units = parallel.units_for_ranges(wl.lengths, ranges, REFERENCE_BATCH, KMAX)
-        by_unit = {}
-        for i, u in enumerate(units):
-            by_unit[(u.record, u.start)] = i
-        ref_segs = []
-        row0 = run.more_status_rows(len(ref_units))
-        for ru in ref_units:                        # a reference-sized unit lies inside one of the resident units
-            j = max(i for (r, s), i in by_unit.items() if r == ru.record and s <= ru.start)
-            u = units[j]
-            d = ru.start - u.start
-            ref_segs.append((int(run.seg_off[j]) + d, ru.seg_len, ru.count, int(run.out_off[j]) + d, row0 + len(ref_segs)))
-        ref_elapsed, _, _ = run.timed(args.steps, 1, ref_segs, kernel_events=False)
-        ref_batch = {"batch": REFERENCE_BATCH, "value": total_positions * args.steps / ref_elapsed, "unit": "positions/s",
-                     "ms_per_step": ref_elapsed / args.steps * 1e3, "launches_per_step": len(ref_segs), "streams": len(run.streams)}
-        if len(run.streams) > 1:                    # the same on one stream
-            saved, run.streams = run.streams, run.streams[:1]
-            one_elapsed, _, _ = run.timed(args.steps, 1, ref_segs, kernel_events=False)
-            run.streams = saved
-            ref_batch["value_one_stream"] = total_positions * args.steps / one_elapsed
-        run.check_status()
+        log(f"[bench] {wl.key}: {args.steps} steps in {elapsed:.3f}s; kernel events: {kernels_block(kinds)}")
+    pass_ms = None if args.no_spread else run.spread(min(args.steps, 20))
     gather = run.final_gather()
     tallies, probe = run.counters()
+    verify = run.verify_sample()
     result = None
     if rank == 0:
         result = {
@@ -581,82 +681,48 @@ def main():
             "unit": "positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl.desc + f", search-range {KMIN}:{KMAX}, both strands",
-                       "records": len(wl.records), "positions": int(total_positions), "positions_per_gpu": run.my_positions,
-                       "batch": args.batch, "segments_per_rank": len(run.segs),
+            "config": {"workload": wl.desc + f", search-range {KMIN}:{KMAX}, both strands; the genome is fixed as N grows: its positions are dealt "
+                                             f"to the ranks in interleaved chunks of ~{CHUNK >> 20} M",
+                       "records": len(wl.records), "positions": int(total_positions), "positions_this_rank": run.my_positions,
+                       "batch": args.batch, "launches_per_step_per_rank": len(run.segs),
                        "streams": len(run.streams) if len(run.segs) > 1 else 1,
                        "streams_output_identical_to_one_stream": run.overlap_identical,
                        "seed_length": run.info["seed_length"], "quad_core_length": run.info.get("quad_core_length", 0),
                        "quad_small_core_length": run.info.get("quad_small_core_length", 0),
-                       "index_bytes_hbm": run.info["device_bytes"],
+                       "index_bytes_hbm": run.info["device_bytes"], "index_open_s": run.t_open, "bwt_rows": run.info["bwt_length"],
                        "parallelism": f"independent work units over {world} GPU(s), index replicated, no data-path collective"},
-            "roofline": roofline_block(run, k0, tallies, wl.key),
-            "pipeline": pipeline_block(run, k1, tallies, probe),
+            "pass_ms": pass_ms,
+            "roofline": roofline_block(run, kinds, tallies, probe, PMC_SUMMARIES.get(args.config) if args.mbp is None else None),
+            "kernels": kernels_block(kinds),
+            "pipeline": pipeline_block(run, kinds, tallies, probe),
+            "verify": verify,
             "host": {"fasta_write_s": prep["fasta_write_s"], "index_build_s": prep["index_build_s"], "index_builder": args.index_builder,
                      "index_open_s": run.t_open, "sequence_upload_s": run.t_upload},
         }
-        if ref_batch is not None:
-            result["reference_batch"] = ref_batch
-        if gather is not None:
-            result["final_gather_ms"] = gather["ms"]      # one RCCL gather of all results to rank 0, outside `value`
+        if world > 1:
+            result["rccl_ranks"] = rccl_ranks
+            result["collective_backend"] = "gloo (rehearsal: ranks share a GPU)" if rehearse else "nccl (RCCL)"
+            result["final_gather_ms"] = gather["ms"]      # one gather of all results to rank 0, outside `value`
             result["final_gather_bytes_per_rank"] = gather["bytes_per_rank"]
-    if world == 1 and not args.no_cpu_baseline and args.config == "c2":
-        gpu_out = run.d_out[:wl.lengths[0]].cpu().numpy()
-        result["cpu_baseline"] = cpu_baseline(args, wl.record(0), gpu_out, KMIN, KMAX)
+            result["final_gather_ranks_with_results"] = gather["ranks_with_results"]
+    if world == 1:
+        gpu_sample = run.d_out[:min(run.segs[0][2], 100_000_000)].cpu().numpy() if run.segs and units[0].record == 0 and units[0].start == 0 else None
+        if not args.no_end_to_end:
+            result["end_to_end"] = end_to_end(args, wl, fa, idx_path, dev_index, run)
+        run.close()
+        del run
+        if not args.no_cpu_baseline and gpu_sample is not None:
+            result["cpu_baseline"] = cpu_baseline(args, wl, gpu_sample, KMIN, KMAX)
+            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"] if result["cpu_baseline"].get("value") else None
+        wl.drop()
+        if not args.no_configs1 and args.config == "ns":
+            t1 = time.time()
+            result["configs1"] = configs1_block(args, rank, dev, barrier, dist, rehearse)
+            log(f"[bench] configs1 block: {time.time() - t1:.1f}s")
     else:
-        v = run.verify_sample()
-        if rank == 0:
-            result["verify"] = v
-    run.close()
-    del run
-    # ------------------------------------------------------------------ north star: ~3 Gbp at 20:200
-    if not args.no_north_star and args.config == "c2":
-        ns = north_star_workload(args)
-        t_ns = time.time()
-        nfa, nidx, nprep = prepare_index(args, ns, rank, barrier)
-        nranges = parallel.interleaved_ranges(ns.total, world, 64 << 20)[rank] if world > 1 else [(0, ns.total)]
-        # (one launch per record and range: the largest record has 249 M positions)
-        nunits = parallel.units_for_ranges(ns.lengths, nranges, max(args.batch, 1 << 28), ns.krange[1])
-        nrun = Run(args, ns, nidx, nunits, rank, world, dev, barrier, dist, rehearse, args.seed_length)
-        for i in range(len(ns.records)):           # the device holds the units now
-            if ns.lengths[i] > 150_000_000:
-                ns.drop(i)
-        n_steps, n_warm = min(args.steps, 10), min(args.warmup, 2)
-        n_elapsed, nk0, nk1 = nrun.timed(n_steps, n_warm)
-        nrun.check_status()
-        n_total = nrun.sum_over_ranks(nrun.my_positions)
-        n_gather = nrun.final_gather()
-        n_tallies, n_probe = nrun.counters()
-        n_verify = nrun.verify_sample()
-        if rank == 0:
-            block = {"workload": ns.desc, "positions": int(n_total), "n_gpus": world, "scaling": "strong (fixed genome, units dealt to the ranks in interleaved chunks)",
-                     "steps": n_steps, "warmup": n_warm, "ms_per_step": n_elapsed / n_steps * 1e3, "value": n_total * n_steps / n_elapsed,
-                     "unit": "positions/s", "launches_per_step_per_rank": len(nrun.segs),
-                     "streams": len(nrun.streams) if len(nrun.segs) > 1 else 1, "streams_output_identical_to_one_stream": nrun.overlap_identical,
-                     "index_bytes_hbm": nrun.info["device_bytes"], "bwt_rows": nrun.info["bwt_length"],
-                     "roofline": roofline_block(nrun, nk0, n_tallies, ns.key), "pipeline": pipeline_block(nrun, nk1, n_tallies, n_probe),
-                     "verify": n_verify,
-                     "host": {"fasta_write_s": nprep["fasta_write_s"], "index_build_s": nprep["index_build_s"], "index_builder": args.index_builder,
-                              "index_open_s": nrun.t_open, "sequence_upload_s": nrun.t_upload}}
-            if n_gather is not None:
-                block["final_gather_ms"] = n_gather["ms"]
-            cb = result.get("cpu_baseline")
-            if cb:
-                block["cpu_baseline_extrapolated"] = {
-                    "value": cb["value"], "unit": "positions/s", "cores": cb["cores"], "kind": "port",
-                    "note": "EXTRAPOLATED: the rate the CPU port reaches on the 100 Mbp genome of configs[1] at the same 20:200 range "
-                            "(620 LF steps per position whatever the genome; its rank blocks for this genome would be 31x larger, so the real "
-                            "rate on these host cores is lower) -- SURVEY.md section 8(d) sanctions the prefix / extrapolation",
-                    "gpu_over_cpu": block["value"] / cb["value"]}
-            result["north_star"] = block
-        if world == 1 and not args.no_end_to_end:
-            e2e = end_to_end(args, ns, nfa, nidx, dev_index, nrun)
-            result["end_to_end"] = e2e
-        nrun.close()
-        if rank == 0:
-            log(f"[bench] north star block: {time.time() - t_ns:.1f}s")
+        run.close()
     if rank == 0:
         result["bench_wall_s"] = time.time() - t_bench
         print(json.dumps(result), flush=True)

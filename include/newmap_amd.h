@@ -165,9 +165,11 @@ enum {
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 
-/* NM_OPT_TIMING = 1 records HIP events on the launch stream, two kinds of start/stop pairs per segment:
- * kind 0 around the dominant search kernel alone (k_sites / k_min_unique / k_fixed_k -- the kernel the roofline
- * figure is quoted for), kind 1 around ALL kernels of the segment (encode pass, sites, repeat probes, resolve).
+/* NM_OPT_TIMING = 1 records HIP events on the launch stream, five kinds of start/stop pairs per segment:
+ * kind 0 around the search kernel alone (k_sites / k_min_unique / k_fixed_k), kind 1 around ALL kernels of the
+ * segment (encode pass, sites, repeat probes, resolve), kinds 2 / 3 / 4 around the coarse repeat probes, the fine
+ * repeat probes and k_resolve, each on the stream the kernel is launched on (bench.py quotes the roofline figure
+ * for the kind with the largest total).
  * nm_timing_read_kind waits for the events of one kind, returns their number, summed and longest duration in
  * ms, and resets that record; nm_timing_read = kind 0. */
 int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_ms, double *max_ms);

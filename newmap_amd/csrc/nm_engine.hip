@@ -659,6 +659,7 @@ struct nm_buffer {
 };
 
 #define NM_LANES 6
+#define NM_TIMING_KINDS 5
 struct nm_lane {
     hipStream_t owner = nullptr;          // the stream whose launches use this scratch
     bool ready = false;                   // side stream and events exist
@@ -709,12 +710,13 @@ struct nm_index {
     uint32_t site_d_cap = NM_SITE_MAX_D;  // measurement knob (NEWMAP_AMD_SITE_D): cap on d = kmin - window of the sites
     bool count_steps = false;
     int last_kernel = 0;                  // which range kernel the last launch used (nm_index_info 8)
-    // NM_OPT_TIMING: HIP events on the launch stream, two kinds of start/stop pairs:
+    // NM_OPT_TIMING: HIP events on the launch stream, NM_TIMING_KINDS kinds of start/stop pairs:
     // kind 0 around the dominant search kernel of a segment (k_sites / k_min_unique / k_fixed_k), kind 1 around ALL the
-    // kernels of the segment (encode pass, sites, probes, resolve)
+    // kernels of the segment (encode pass, sites, probes, resolve), kinds 2 / 3 / 4 around the coarse probes, the fine
+    // probes and k_resolve (each on the stream it is launched on: the probes may run on the lane's side stream)
     bool timing = false;
-    std::vector<hipEvent_t> ev_pool[2];   // start/stop pairs, reused
-    size_t ev_used[2] = {0, 0};           // events consumed since the last read
+    std::vector<hipEvent_t> ev_pool[NM_TIMING_KINDS];   // start/stop pairs, reused
+    size_t ev_used[NM_TIMING_KINDS] = {0, 0, 0, 0, 0};  // events consumed since the last read
 };
 
 struct nm_timed {                         // records start on construction, stop on destruction
@@ -1189,7 +1191,7 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
 extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
     if (option == NM_OPT_COUNT_STEPS) { ix->count_steps = value != 0; return NM_OK; }
-    if (option == NM_OPT_TIMING) { ix->timing = value != 0; ix->ev_used[0] = ix->ev_used[1] = 0; return NM_OK; }
+    if (option == NM_OPT_TIMING) { ix->timing = value != 0; for (size_t &u : ix->ev_used) u = 0; return NM_OK; }
     if (option == NM_OPT_LF_BLOCKS) {      // A/B: LF steps read the 16-byte LF entries (if built) or the packed blocks
         ix->view.lfb = value ? (const nm_lf_entry *)ix->d_lfb : nullptr;
         return NM_OK;
@@ -1232,7 +1234,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
 
 extern "C" int nm_timing_read_kind(nm_index *ix, int kind, uint64_t *n_launches, double *total_ms, double *max_ms) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
-    if (kind != 0 && kind != 1) { nm_set_error("timing kind must be 0 (dominant kernel) or 1 (all kernels of a segment)"); return NM_E_ARGUMENT; }
+    if (kind < 0 || kind >= NM_TIMING_KINDS) { nm_set_error("timing kind must be 0 (dominant kernel), 1 (all kernels of a segment), 2 (coarse probes), 3 (fine probes) or 4 (k_resolve)"); return NM_E_ARGUMENT; }
     HIP_TRY(hipSetDevice(ix->device));
     double total = 0.0, mx = 0.0;
     std::vector<hipEvent_t> &pool = ix->ev_pool[kind];
@@ -1311,12 +1313,16 @@ static int nm_launch_probes(nm_index *ix, const nm_view &view, uint64_t n, uint3
         const uint32_t cstride = ix->coarse_stride;
         const uint64_t n_coarse = (n + cstride - 1) / cstride;
         if ((rc = nm_grow(ix->cur->coarse, n_coarse * sizeof(uint32_t))) != NM_OK) return rc;
+        nm_timed timed(ix, st, 2);
         if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->cur->coarse.p, tally, need, n_probes, cstride);
         else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->cur->coarse.p, tally, need, n_probes, cstride);
         coarse = (const uint32_t *)ix->cur->coarse.p;
     }
-    if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->cur->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
-    else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->cur->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
+    {
+        nm_timed timed(ix, st, 3);
+        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe<BIG, true>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->cur->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
+        else                 hipLaunchKernelGGL((k_repeat_probe<BIG, false>), dim3(nm_grid(n_probes + 1)), block, 0, st, view, enc, n_probes, kmax, (uint32_t *)ix->cur->settled.p, tally, coarse, ix->d_repeats_seen, ix->d_seen_latch, need, n_probes, ix->coarse_stride);
+    }
     *words = (const uint32_t *)ix->cur->settled.p;
     return NM_OK;
 }
@@ -1416,8 +1422,11 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
     const dim3 rgrid((unsigned)((n_need + NM_RES_WORDS - 1) / NM_RES_WORDS)), rblock(NM_RES_BLOCK);
 #define NM_LAUNCH_RES(STATS_, LIST_) hipLaunchKernelGGL((k_resolve<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, \
                                                         d_status, (const uint64_t *)need, n_need, probe, (const unsigned long long *)work, seq_len, d_list, n_list)
-    if (d_list) { if (ix->count_steps) NM_LAUNCH_RES(true, true); else NM_LAUNCH_RES(false, true); }
-    else        { if (ix->count_steps) NM_LAUNCH_RES(true, false); else NM_LAUNCH_RES(false, false); }
+    {
+        nm_timed timed(ix, st, 4);
+        if (d_list) { if (ix->count_steps) NM_LAUNCH_RES(true, true); else NM_LAUNCH_RES(false, true); }
+        else        { if (ix->count_steps) NM_LAUNCH_RES(true, false); else NM_LAUNCH_RES(false, false); }
+    }
 #undef NM_LAUNCH_RES
     return NM_OK;
 }

@@ -52,6 +52,9 @@ def lib():
     vp, i64, u32, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
     L.or_build.restype = vp
     L.or_build.argtypes = [vp, vp, i64]
+    L.or_build_ptrs.restype = vp
+    L.or_build_ptrs.argtypes = [vp, vp, i64]
+    L.or_drop_sa.argtypes = [vp]
     L.or_free.argtypes = [vp]
     L.or_text_length.restype = i64
     L.or_text_length.argtypes = [vp]
@@ -157,16 +160,18 @@ def sequence_segments(path_or_lines, length: int, overlap: int = 0) -> Iterator[
 class OracleIndex:
     """Forward-strand text of all records + suffix array (+ optional FM port)."""
 
-    def __init__(self, records: Sequence[bytes]):
+    def __init__(self, records: Sequence):
+        """records: bytes objects or uint8 numpy arrays (not copied: a 3 Gbp genome stays where it is).  The mapped
+        text -- one separator per record included -- must stay below 2^32 symbols."""
         self._L = lib()
-        self.records = [bytes(r) for r in records if len(r)]
-        blob = b"".join(self.records)
-        offs = np.zeros(len(self.records) + 1, dtype=np.int64)
-        np.cumsum([len(r) for r in self.records], out=offs[1:])
-        self._blob = np.frombuffer(blob, dtype=np.uint8) if blob else np.zeros(0, np.uint8)
-        self._h = self._L.or_build(self._blob.ctypes.data, offs.ctypes.data, len(self.records))
+        self.records = [r for r in records if len(r)]
+        views = [np.frombuffer(r, dtype=np.uint8) if isinstance(r, (bytes, bytearray, memoryview)) else np.ascontiguousarray(r, dtype=np.uint8)
+                 for r in self.records]
+        ptrs = np.array([v.ctypes.data for v in views], dtype=np.uint64)
+        lens = np.array([v.size for v in views], dtype=np.int64)
+        self._h = self._L.or_build_ptrs(ptrs.ctypes.data if len(views) else None, lens.ctypes.data if len(views) else None, len(views))
         if not self._h:
-            raise MemoryError("oracle index build failed")
+            raise MemoryError("oracle index build failed (text of 2^32 symbols or more, or out of memory)")
         self._fm_seed = None
 
     @classmethod
@@ -183,6 +188,10 @@ class OracleIndex:
             if self._L.or_fm_build(self._h, seed_len) != 0:
                 raise MemoryError("oracle FM port build failed")
             self._fm_seed = seed_len
+
+    def drop_suffix_array(self):
+        """after enable_fm(): keep the FM port only (4 bytes per symbol less); or_count then answers 0"""
+        self._L.or_drop_sa(self._h)
 
     # counts at the FFI seam ---------------------------------------------------------
     def count(self, kmer: bytes, fm: bool = False) -> int:

@@ -46,16 +46,10 @@ def main():
     meta = {"kernel": kernel, "source_sha256": h.hexdigest()[:16], "git_commit": commit}
     try:
         r = json.loads(Path(bench_json).read_text().strip().splitlines()[-1])
-        if "<true" in kernel and "north_star" in r:          # the > 2^31-row instantiations: the north-star block of the same line
-            ns = r["north_star"]
-            meta["workload"] = "north_star block (3.09 Gbp, 20:200)"
-            meta["positions_per_launch"] = ns["positions"] // max(ns["launches_per_step_per_rank"], 1)
-            meta["site_core_length"] = ns["roofline"].get("site_core_length", 0)
-            meta["avg_launch_ms_hip_events"] = round(ns["roofline"]["avg_launch_ms"], 5)
-        else:
-            meta["positions_per_launch"] = r["config"]["positions_per_gpu"] // max(r["config"]["segments_per_rank"], 1)
-            meta["site_core_length"] = r["roofline"].get("site_core_length", 0)
-            meta["avg_launch_ms_hip_events"] = round(r["roofline"]["avg_launch_ms"], 5)
+        meta["workload"] = r["config"]["workload"].split(":")[0]
+        meta["positions_per_launch"] = r["config"]["positions_this_rank"] // max(r["config"]["launches_per_step_per_rank"], 1)
+        meta["site_core_length"] = r["roofline"].get("site_core_length", 0)
+        meta["avg_launch_ms_hip_events"] = round(r["roofline"]["avg_launch_ms"], 5)
     except (OSError, ValueError, KeyError, IndexError):
         pass
     with open(out, "w") as fh:

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=${1:-gpurun_out/prof_c2}
 shift
 mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --no-reference-batch --no-north-star --steps 20 --warmup 2 $*"
+B="python3 bench.py --config c2 --no-cpu-baseline --no-end-to-end --no-spread --steps 20 --warmup 2 $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $B > $O/trace.json 2> $O/trace.log || echo "trace failed"
 cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $O/pmc1 -o p -- $B > $O/pmc1.json 2> $O/pmc1.log || echo "pmc1 failed"

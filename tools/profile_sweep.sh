@@ -7,7 +7,7 @@ O=${1:-gpurun_out/sweep}
 mkdir -p $O
 for m in 13 14 15 16; do
   export NEWMAP_AMD_QUAD_M=$m NEWMAP_AMD_QUAD_SMALL_M=0
-  B="python3 bench.py --no-cpu-baseline --no-reference-batch --no-north-star --steps 10 --warmup 2"
+  B="python3 bench.py --config c2 --no-cpu-baseline --no-end-to-end --no-spread --steps 10 --warmup 2"
   $B > $O/m$m.json 2> $O/m$m.log || echo "m=$m bench failed"
   timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/m$m/p1 -o p -- $B > /dev/null 2> $O/m$m.p1.log || echo "p1 failed"
   timeout -k 10 300 rocprofv3 --pmc TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum GRBM_GUI_ACTIVE GRBM_UTCL2_BUSY --output-format csv -d $O/m$m/p2 -o p -- $B > /dev/null 2> $O/m$m.p2.log || echo "p2 failed"

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="also capture a pass into a HIP graph (torch.cuda.CUDAGraph) and replay it")
     a = ap.parse_args()
     args = bench.parse(["--config", a.config, "--batch", str(a.batch)])
-    wl = bench.headline_workload(args, 1)
+    wl = bench.headline_workload(args)
     fa, idx, _ = bench.prepare_index(args, wl, 0, lambda: None)
     dev = torch.device("cuda:0")
     KMIN, KMAX = wl.krange

@@ -865,6 +865,18 @@ NM_HD uint32_t nm_quad_bits(const uint32_t b[4], const uint64_t e[4]) {
            ((uint32_t)((e[2] >> (b[2] & 63u)) & 1ULL) << 3) | ((uint32_t)((e[3] >> (b[3] & 63u)) & 1ULL) << 4);
 }
 
+// One HALF of a lookup: h = 0: windows 0 and 1 (the 16 bytes at nm_quad_pair01), h = 1: windows 3 and 4 (nm_quad_pair34).
+// The kernels give the two halves of a lookup to two neighbouring lanes of ONE load instruction: the coalescer then sees
+// one 128-byte line per lane pair.  (Two load instructions of one lane to the same line cost a fifth of the line rate:
+// tools/gather_ceiling, 38 vs 48 G lines/s on a 32 GiB table.)
+NM_HD const uint64_t *nm_quad_half(const uint64_t *entry, const uint32_t b[4], uint32_t h) {
+    return h ? nm_quad_pair34(entry, b) : nm_quad_pair01(entry, b);
+}
+NM_HD uint32_t nm_quad_half_bits(const uint32_t b[4], uint32_t h, uint64_t e0, uint64_t e1) {
+    const uint32_t x = (uint32_t)((e0 >> (b[2 * h] & 63u)) & 1ULL) | ((uint32_t)((e1 >> (b[2 * h + 1] & 63u)) & 1ULL) << 1);
+    return h ? x << 3 : x;
+}
+
 // ---- sites: one quad entry settles 5 + d positions (nm_engine.hip: k_sites, k_resolve) -----------
 // A string that contains a string occurring once occurs once itself.  If the w-mer (w = m + 4) that starts at P + i
 // occurs exactly once, then every position q with  q <= P + i  and  P + i + w <= q + kmin  has a kmin-mer that
@@ -895,6 +907,15 @@ NM_HD uint32_t nm_site_bits(const nm_window &w, uint32_t m, const uint32_t b[4],
 #pragma unroll
     for (uint32_t i = 0; i < 5; i++) ok |= (uint32_t)(((w.amb >> i) & wm) == 0) << i;
     return once & ok & NM_QUAD_OFFSETS;
+}
+
+// the same for the two windows of one half of a lookup (nm_quad_half_bits): bits 0, 1 or bits 3, 4
+NM_HD uint32_t nm_site_half_bits(const nm_window &w, uint32_t m, const uint32_t b[4], uint32_t h, uint64_t e0, uint64_t e1) {
+    const uint32_t once = nm_quad_half_bits(b, h, e0, e1);
+    const uint64_t wm = (1ULL << (m + NM_QUAD_EXT)) - 1ULL;
+    const uint32_t i0 = h ? 3u : 0u;
+    const uint32_t ok = ((uint32_t)(((w.amb >> i0) & wm) == 0) << i0) | ((uint32_t)(((w.amb >> (i0 + 1)) & wm) == 0) << (i0 + 1));
+    return once & ok;
 }
 
 // bit t of the result: position t of the group (t = 0 .. d + 4) is settled by one of the site's windows

@@ -44,6 +44,23 @@ static __device__ __forceinline__ uint64_t nm_seed_load_policy(const nm_view &ix
     return *p;
 }
 
+// 16 bytes of a quad-table entry.  The entries of a launch are read once, at random, from a table far larger than the
+// caches: non-temporal loads (measured with tools/gather_ceiling: +8 % lines/s on a 32 GiB table, nothing lost on a
+// 2 GiB one).  -DNM_QUAD_NT=0 (measurement builds): default cache policy.
+#ifndef NM_QUAD_NT
+#define NM_QUAD_NT 1
+#endif
+typedef unsigned long long nm_u64x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void nm_quad_load16(const uint64_t *p, uint64_t &a, uint64_t &b) {
+    const nm_u64x2 *q = reinterpret_cast<const nm_u64x2 *>(p);
+#if NM_QUAD_NT
+    const nm_u64x2 v = __builtin_nontemporal_load(q);
+#else
+    const nm_u64x2 v = *q;
+#endif
+    a = v.x; b = v.y;
+}
+
 #define NM_WAVE 64
 #define NM_BLOCK 256
 
@@ -330,32 +347,35 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         }
         return w;
     };
-    // ---- phase 1: the sites
-    nm_window win[NM_SITE_PER_LANE];
-    uint64_t e[NM_SITE_PER_LANE][4];                                   // one word per window of the entry
-    uint32_t bidx[NM_SITE_PER_LANE][4];
-    bool go[NM_SITE_PER_LANE];
+    // ---- phase 1: the sites.  A lookup reads two 16-byte halves of one 128-byte entry (windows 0, 1 and windows 3, 4); the
+    // halves go to two NEIGHBOURING LANES of one load instruction, so the coalescer sees one line per lane pair: lane t
+    // takes half t & 1 of the groups (t >> 1) + 128 s, s = 0 .. 3 -- four loads in flight per lane.  Each lane ORs what
+    // its own two windows settle into the bitmap; the halves never have to meet.
+    constexpr uint32_t NS = 2 * NM_SITE_PER_LANE;                      // half-sites per lane
+    const uint32_t half = tid & 1u;
+    nm_window win[NS];
+    uint64_t e[NS][2];
+    uint32_t bidx[NS][4];
+    bool go[NS];
     uint32_t n_entries = 0;
 #pragma unroll
-    for (int s = 0; s < NM_SITE_PER_LANE; s++) {
-        const uint32_t g = (uint32_t)s * NM_SITE_BLOCK + tid;          // group g: positions base + g G .. + G - 1, site at + d
+    for (uint32_t s = 0; s < NS; s++) {
+        const uint32_t g = s * (NM_SITE_BLOCK / 2) + (tid >> 1);       // group g: positions base + g G .. + G - 1, site at + d
         win[s] = lds_window(g * G + d);
         go[s] = base + (uint64_t)g * G < num_kmers && nm_site_core_valid(win[s], m) && !(ix.seed_policy & 0x200u);
         nm_quad_index(win[s], m, bidx[s]);
-        e[s][0] = e[s][1] = e[s][2] = e[s][3] = 0;
+        e[s][0] = e[s][1] = 0;
         if (go[s]) {
-            const uint64_t *entry = ix.quad + nm_quad_slot(win[s], m) * NM_QUAD_WORDS;     // one 128-byte line, two 16-byte loads
-            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(nm_quad_pair01(entry, bidx[s]));
-            const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(nm_quad_pair34(entry, bidx[s]));
-            e[s][0] = a.x; e[s][1] = a.y; e[s][2] = c.x; e[s][3] = c.y;
-            n_entries += 4;
+            const uint64_t *entry = ix.quad + nm_quad_slot(win[s], m) * NM_QUAD_WORDS;     // one 128-byte line per lane pair
+            nm_quad_load16(nm_quad_half(entry, bidx[s], half), e[s][0], e[s][1]);
+            n_entries += 2;
         }
     }
 #pragma unroll
-    for (int s = 0; s < NM_SITE_PER_LANE; s++) {
-        const uint64_t settled = go[s] ? nm_site_settled(nm_site_bits(win[s], m, bidx[s], e[s]), d) : 0ULL;
+    for (uint32_t s = 0; s < NS; s++) {
+        const uint64_t settled = go[s] ? nm_site_settled(nm_site_half_bits(win[s], m, bidx[s], half, e[s][0], e[s][1]), d) : 0ULL;
         if (settled) {
-            const uint32_t o = ((uint32_t)s * NM_SITE_BLOCK + tid) * G;   // bit offset of the group in the block
+            const uint32_t o = (s * (NM_SITE_BLOCK / 2) + (tid >> 1)) * G;   // bit offset of the group in the block
             const uint32_t wi = o >> 5, sh = o & 31;
             atomicOr(&s_set[wi], (uint32_t)(settled << sh));
             const uint64_t rest = sh ? settled >> (32 - sh) : settled >> 16 >> 16;
@@ -407,10 +427,29 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         const uint32_t n_q = s_qn;
         __syncthreads();
         if (tid == 0) s_qn = 0;
-        if (tid < n_q) {
-            const uint32_t rel = s_q[tid];
-            n_entries += 4;
-            if (nm_second_chance(ix, lds_window(rel), kmin)) {
+        // (a lookup = two lanes, as in phase 1: lane pair j takes the open positions j and j + 128)
+        const uint32_t m2 = ix.quad2_m, reach = kmin - (m2 + NM_QUAD_EXT);  // windows p + i with i <= reach lie inside the kmin-mer
+        const uint32_t usable = reach >= 4 ? 0x1Fu : (1u << (reach + 1)) - 1u;
+#pragma unroll
+        for (uint32_t r = 0; r < NM_SITE_CHANCE_MAX / (NM_SITE_BLOCK / 2); r++) {
+            const uint32_t qi = r * (NM_SITE_BLOCK / 2) + (tid >> 1);
+            uint32_t bits = 0, rel = 0;
+            if (qi < n_q && (usable & (half ? 0x18u : 0x03u))) {
+                rel = s_q[qi];
+                const nm_window w = lds_window(rel);
+                if (nm_site_core_valid(w, m2)) {
+                    uint32_t b[4];
+                    nm_quad_index(w, m2, b);
+                    uint64_t a0, a1;
+                    nm_quad_load16(nm_quad_half(ix.quad2 + nm_quad_slot(w, m2) * NM_QUAD_WORDS, b, half), a0, a1);
+                    n_entries += 2;
+                    bits = nm_site_half_bits(w, m2, b, half, a0, a1) & usable;
+                }
+            } else if (qi < n_q) {
+                rel = s_q[qi];
+            }
+            const uint32_t other = (uint32_t)__shfl_xor((int)bits, 1, NM_WAVE);
+            if (half == 0 && qi < n_q && (bits | other)) {
                 nm_store(out, elem_bytes, base + rel, kmin);
                 atomicAnd(&s_need[rel >> 5], ~(1u << (rel & 31)));
                 atomicSub(&s_open_total, 1u);

@@ -459,6 +459,55 @@ NM_HD bool nm_coarse_covers(uint32_t coarse_settled, uint32_t offset_in_coarse, 
     return coarse_settled >= offset_in_coarse + fine_stride;
 }
 
+// ---- tandem repeats: a whole coarse stride settled by ONE walk per run -------------------------------------------
+// If the text is u-periodic over a stretch -- S[i] == S[i + u], unambiguous, for every i in [P, P + len) -- every
+// kmax-mer that starts in [P, P + len + u - kmax] is one of the u rotations of a single string.  A tandem array of
+// period u that runs over many coarse strides is then ONE run of such stretches, and one walk of kmax + u - 1 bases from
+// its first stride proves the whole run: if S[P .. P + kmax + u - 1) still occurs twice, each of the u rotations does,
+// and every position of every stride of the run gets 0 (U_q = kmax: the stretch is free of ambiguous bytes).  The
+// coarse probes would walk kmax + 511 bases for EACH stride of the run (nm_repeat_probe_ex).  The period is read off
+// the encoded words alone; the index decides -- a sequence that is periodic but foreign to the index fails the walk
+// and is searched the ordinary way.
+#define NM_PERIOD_MAX 256u
+#define NM_PERIOD_INHERIT 0x80000000u      /* coarse[] of a stride inside a run: take the value of the run's first stride */
+
+// positions [64 w + u, 64 w + u + 64) of the planes, as a word
+NM_HD nm_window nm_shifted_word(const nm_enc_word *enc, uint64_t w, uint32_t u) {
+    const nm_enc_word &a = enc[w + (u >> 6)];
+    return nm_window_from(a, enc[w + (u >> 6) + 1], u & 63u);
+}
+
+// least period u in [1, NM_PERIOD_MAX] of the stretch [P, P + len) in the sense above (P a multiple of 64), 0 = none.
+// n_words: words of `enc` (positions past the data are ambiguous there, so a stretch that leaves the data fails).
+NM_HD uint32_t nm_period_of(const nm_enc_word *enc, uint64_t n_words, uint64_t P, uint32_t len) {
+    const uint64_t w0 = P >> 6;
+    const uint32_t n_w = (len + 63u) >> 6;
+    if (w0 + n_w + (NM_PERIOD_MAX >> 6) + 2 > n_words) return 0;
+    const nm_enc_word first = enc[w0];
+    const uint32_t head = len < 64u ? len : 64u;
+    const uint64_t hmask = head == 64 ? ~0ULL : (1ULL << head) - 1ULL;
+    if (first.amb & hmask) return 0;
+    for (uint32_t j = 0; j <= (NM_PERIOD_MAX >> 6); j++) {
+        const nm_enc_word a = enc[w0 + j], b = enc[w0 + j + 1];
+        for (uint32_t sh = j ? 0u : 1u; sh < 64u && 64u * j + sh <= NM_PERIOD_MAX; sh++) {
+            const nm_window y = nm_window_from(a, b, sh);
+            if ((((first.lo ^ y.lo) | (first.hi ^ y.hi) | y.amb) & hmask) != 0) continue;
+            // the first word agrees with itself u bases on: check the whole stretch
+            const uint32_t u = 64u * j + sh;
+            bool ok = true;
+            for (uint32_t k = 1; k < n_w && ok; k++) {
+                const nm_enc_word x = enc[w0 + k];
+                const nm_window z = nm_shifted_word(enc, w0 + k, u);
+                const uint32_t left = len - 64u * k;
+                const uint64_t mk = left >= 64 ? ~0ULL : (1ULL << left) - 1ULL;
+                ok = (((x.lo ^ z.lo) | (x.hi ^ z.hi) | x.amb | z.amb) & mk) == 0;
+            }
+            if (ok) return u;
+        }
+    }
+    return 0;
+}
+
 // What the probe words of a position's stride (wj) and of the next stride (wj1) say about the position at
 // offset o of the stride: its least unique length (kmax + 1 standing for "none up to kmax"), or NM_PROBE_OPEN.
 NM_HD uint32_t nm_probe_kstar(uint32_t wj, uint32_t wj1, uint32_t o, uint32_t stride, uint32_t kmax) {
@@ -865,18 +914,6 @@ NM_HD uint32_t nm_quad_bits(const uint32_t b[4], const uint64_t e[4]) {
            ((uint32_t)((e[2] >> (b[2] & 63u)) & 1ULL) << 3) | ((uint32_t)((e[3] >> (b[3] & 63u)) & 1ULL) << 4);
 }
 
-// One HALF of a lookup: h = 0: windows 0 and 1 (the 16 bytes at nm_quad_pair01), h = 1: windows 3 and 4 (nm_quad_pair34).
-// The kernels give the two halves of a lookup to two neighbouring lanes of ONE load instruction: the coalescer then sees
-// one 128-byte line per lane pair.  (Two load instructions of one lane to the same line cost a fifth of the line rate:
-// tools/gather_ceiling, 38 vs 48 G lines/s on a 32 GiB table.)
-NM_HD const uint64_t *nm_quad_half(const uint64_t *entry, const uint32_t b[4], uint32_t h) {
-    return h ? nm_quad_pair34(entry, b) : nm_quad_pair01(entry, b);
-}
-NM_HD uint32_t nm_quad_half_bits(const uint32_t b[4], uint32_t h, uint64_t e0, uint64_t e1) {
-    const uint32_t x = (uint32_t)((e0 >> (b[2 * h] & 63u)) & 1ULL) | ((uint32_t)((e1 >> (b[2 * h + 1] & 63u)) & 1ULL) << 1);
-    return h ? x << 3 : x;
-}
-
 // ---- sites: one quad entry settles 5 + d positions (nm_engine.hip: k_sites, k_resolve) -----------
 // A string that contains a string occurring once occurs once itself.  If the w-mer (w = m + 4) that starts at P + i
 // occurs exactly once, then every position q with  q <= P + i  and  P + i + w <= q + kmin  has a kmin-mer that
@@ -907,15 +944,6 @@ NM_HD uint32_t nm_site_bits(const nm_window &w, uint32_t m, const uint32_t b[4],
 #pragma unroll
     for (uint32_t i = 0; i < 5; i++) ok |= (uint32_t)(((w.amb >> i) & wm) == 0) << i;
     return once & ok & NM_QUAD_OFFSETS;
-}
-
-// the same for the two windows of one half of a lookup (nm_quad_half_bits): bits 0, 1 or bits 3, 4
-NM_HD uint32_t nm_site_half_bits(const nm_window &w, uint32_t m, const uint32_t b[4], uint32_t h, uint64_t e0, uint64_t e1) {
-    const uint32_t once = nm_quad_half_bits(b, h, e0, e1);
-    const uint64_t wm = (1ULL << (m + NM_QUAD_EXT)) - 1ULL;
-    const uint32_t i0 = h ? 3u : 0u;
-    const uint32_t ok = ((uint32_t)(((w.amb >> i0) & wm) == 0) << i0) | ((uint32_t)(((w.amb >> (i0 + 1)) & wm) == 0) << (i0 + 1));
-    return once & ok;
 }
 
 // bit t of the result: position t of the group (t = 0 .. d + 4) is settled by one of the site's windows
@@ -963,6 +991,12 @@ NM_HD uint32_t nm_valid4(AmbWord amb_word, uint64_t q, uint32_t kmin, uint32_t &
 // windows that are repeated.  A position they leave open first asks the table with longer cores: the entry at P = p
 // holds the windows at p + 0, 1, 3, 4, and any of them that occurs once inside the position's kmin-mer (i <= kmin - w2)
 // settles it.  One line instead of the seed entry plus the rank lines of a walk.  `w` = the 64 bases from p on.
+// (the same with the entry's words already fetched: b = nm_quad_index(w, quad2_m), e = both pairs of the entry)
+NM_HD bool nm_second_chance_bits(const nm_view &ix, const nm_window &w, uint32_t kmin, const uint32_t b[4], const uint64_t e[4]) {
+    const uint32_t m = ix.quad2_m, reach = kmin - (m + NM_QUAD_EXT);
+    const uint32_t usable = reach >= 4 ? 0x1Fu : (1u << (reach + 1)) - 1u;
+    return (nm_site_bits(w, m, b, e) & usable) != 0;
+}
 NM_HD bool nm_second_chance(const nm_view &ix, const nm_window &w, uint32_t kmin) {
     const uint32_t m = ix.quad2_m, len = m + NM_QUAD_EXT;
     if (!nm_site_core_valid(w, m)) return false;

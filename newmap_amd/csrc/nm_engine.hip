@@ -44,21 +44,58 @@ static __device__ __forceinline__ uint64_t nm_seed_load_policy(const nm_view &ix
     return *p;
 }
 
-// 16 bytes of a quad-table entry.  The entries of a launch are read once, at random, from a table far larger than the
-// caches: non-temporal loads (measured with tools/gather_ceiling: +8 % lines/s on a 32 GiB table, nothing lost on a
-// 2 GiB one).  -DNM_QUAD_NT=0 (measurement builds): default cache policy.
+// ---- one quad-table entry per lane, one LINE per lane pair and load instruction --------------------------------------
+// A lookup reads two 16-byte halves of its 128-byte entry (windows 0, 1 and windows 3, 4).  Two load instructions of one
+// lane to the same line cost a fifth of the line rate (tools/gather_ceiling: 38 vs 48 G lines/s on a 32 GiB table -- the
+// second request is a separate L1 -> L2 transaction); two LANES of one instruction that read the same line are coalesced.
+// So neighbouring lanes trade halves: lane 2 j hands the address of its second half to lane 2 j + 1 and takes the address
+// of that lane's first half; the first load instruction then reads both halves of lane 2 j's entry, the second both
+// halves of lane 2 j + 1's, and the foreign words travel back -- six DPP moves (quad_perm [1, 0, 3, 2]) per lookup.
+// Every lane of the wave must take part (go = false: no entry).  The entries of a launch are read once, at random, from
+// a table far larger than the caches: non-temporal loads (+8 % lines/s on a 32 GiB table, nothing lost on a 2 GiB one;
+// -DNM_QUAD_NT=0 for measurement builds).
 #ifndef NM_QUAD_NT
 #define NM_QUAD_NT 1
 #endif
 typedef unsigned long long nm_u64x2 __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ void nm_quad_load16(const uint64_t *p, uint64_t &a, uint64_t &b) {
-    const nm_u64x2 *q = reinterpret_cast<const nm_u64x2 *>(p);
+static __device__ __forceinline__ uint32_t nm_swap1(uint32_t v) {      // the value of lane ^ 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
+static __device__ __forceinline__ uint64_t nm_swap1_64(uint64_t v) {
+    return (uint64_t)nm_swap1((uint32_t)v) | ((uint64_t)nm_swap1((uint32_t)(v >> 32)) << 32);
+}
+// (addresses that went through a lane swap are plain integers: name the global address space, or the loads become flat ones)
+static __device__ __forceinline__ nm_u64x2 nm_quad_load16(uint64_t addr) {
+    typedef const nm_u64x2 __attribute__((address_space(1))) *gptr;
+    gptr q = (gptr)addr;
 #if NM_QUAD_NT
-    const nm_u64x2 v = __builtin_nontemporal_load(q);
+    return __builtin_nontemporal_load(q);
 #else
-    const nm_u64x2 v = *q;
+    return *q;
 #endif
-    a = v.x; b = v.y;
+}
+struct nm_quad_inflight { nm_u64x2 va, vb; };
+// first half of a lookup: trade addresses, issue both loads (nothing waits here: a lane keeps several lookups in flight)
+static __device__ __forceinline__ nm_quad_inflight nm_quad_issue_paired(const uint64_t *entry, bool go, const uint32_t b[4]) {
+    const bool even = (threadIdx.x & 1u) == 0;
+    const uint64_t p01 = go ? (uint64_t)nm_quad_pair01(entry, b) : 0ULL, p34 = go ? (uint64_t)nm_quad_pair34(entry, b) : 0ULL;
+    const uint64_t keep = even ? p01 : p34;                            // the half I load myself ...
+    const uint64_t theirs = nm_swap1_64(even ? p34 : p01);             // ... and the half my neighbour wants
+    const uint64_t pa = even ? keep : theirs, pb = even ? theirs : keep;   // instruction A: the even lane's line, B: the odd lane's
+    nm_quad_inflight f;
+    f.va = nm_u64x2{0, 0}; f.vb = nm_u64x2{0, 0};
+    if (pa) f.va = nm_quad_load16(pa);
+    if (pb) f.vb = nm_quad_load16(pb);
+    return f;
+}
+// second half: the foreign words travel back.  e[0], e[1] = the pair at nm_quad_pair01(entry, b), e[2], e[3] = the pair at
+// nm_quad_pair34(entry, b); zeros without an entry
+static __device__ __forceinline__ void nm_quad_finish_paired(const nm_quad_inflight &f, uint64_t e[4]) {
+    const bool even = (threadIdx.x & 1u) == 0;
+    const nm_u64x2 mine = even ? f.va : f.vb, foreign = even ? f.vb : f.va;
+    const uint64_t f0 = nm_swap1_64(foreign.x), f1 = nm_swap1_64(foreign.y);   // my other half, loaded next door
+    e[0] = even ? mine.x : f0; e[1] = even ? mine.y : f1;
+    e[2] = even ? f0 : mine.x; e[3] = even ? f1 : mine.y;
 }
 
 #define NM_WAVE 64
@@ -196,6 +233,63 @@ __global__ __launch_bounds__(NM_BLOCK) void k_repeat_probe_coarse(nm_view ix, co
             atomicAdd(&probe_tally[2], (unsigned long long)d);
         }
     }
+}
+
+// ---- tandem runs (nm_core.h: nm_period_of).  Stands in for the coarse probes on input that has shown long repeats:
+// a stride whose stretch [P, P + cstride + kmax - 1) is u-periodic belongs to a run; the FIRST stride of a run walks
+// kmax + u - 1 bases once, the others inherit (k_period_spread).  Strides outside runs get 0: the fine probes take them
+// (walks of at most kmax + 63 bases instead of kmax + 511 -- the launch lasts as long as its longest chain).
+template <bool BIG, bool STATS>
+__global__ __launch_bounds__(NM_BLOCK) void k_period_runs(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t n_enc_words, uint64_t n_coarse,
+                                                          uint32_t kmax, uint32_t *__restrict__ coarse,
+                                                          unsigned long long *__restrict__ probe_tally,
+                                                          const uint64_t *__restrict__ need, uint64_t n_need, uint32_t cstride) {
+    if (need && probe_tally[NM_WORK_OPEN - 1] == 0) return;
+    const uint64_t c = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    nm_tally t = {0, 0, 0, 0};
+    if (c < n_coarse) {
+        uint32_t word = 0;
+        const uint64_t j0 = c * (cstride / NM_PROBE_STRIDE);
+        if (!need || (j0 < n_need && nm_popc64(need[j0]) >= NM_PROBE_GATE_BITS)) {
+            const uint32_t len = cstride + kmax - 1;
+            const uint32_t u = nm_period_of(enc, n_enc_words, c * cstride, len);
+            if (u) {
+                const bool first = c == 0 || nm_period_of(enc, n_enc_words, (c - 1) * cstride, len) != u;
+                if (first) {
+                    uint32_t settled, exact;
+                    nm_repeat_probe_ex<BIG>(ix, enc, c * cstride, kmax, u, t, settled, exact);
+                    word = settled == u ? cstride : 0u;            // S[P .. P + kmax + u - 1) occurs twice: so does every rotation
+                } else {
+                    word = NM_PERIOD_INHERIT;
+                }
+            }
+        }
+        coarse[c] = word;
+    }
+    if (STATS) {
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), d = wave_sum(t.seeds);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&probe_tally[0], (unsigned long long)a);
+            atomicAdd(&probe_tally[1], (unsigned long long)b);
+            atomicAdd(&probe_tally[2], (unsigned long long)d);
+        }
+    }
+}
+
+// strides inside a run take the word of the run's first stride (runs are at most a few hundred strides long; a stride
+// whose predecessors are all markers up to the look-back limit stays undecided = 0)
+__global__ __launch_bounds__(NM_BLOCK) void k_period_spread(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n_coarse) {
+    const uint64_t c = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (c >= n_coarse) return;
+    uint32_t v = in[c];
+    if (v == NM_PERIOD_INHERIT) {
+        v = 0;
+        for (uint64_t j = c; j-- > 0 && c - j <= 8192;) {
+            const uint32_t x = in[j];
+            if (x != NM_PERIOD_INHERIT) { v = x; break; }
+        }
+    }
+    out[c] = v;
 }
 
 template <bool BIG, bool STATS>
@@ -347,35 +441,30 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         }
         return w;
     };
-    // ---- phase 1: the sites.  A lookup reads two 16-byte halves of one 128-byte entry (windows 0, 1 and windows 3, 4); the
-    // halves go to two NEIGHBOURING LANES of one load instruction, so the coalescer sees one line per lane pair: lane t
-    // takes half t & 1 of the groups (t >> 1) + 128 s, s = 0 .. 3 -- four loads in flight per lane.  Each lane ORs what
-    // its own two windows settle into the bitmap; the halves never have to meet.
-    constexpr uint32_t NS = 2 * NM_SITE_PER_LANE;                      // half-sites per lane
-    const uint32_t half = tid & 1u;
-    nm_window win[NS];
-    uint64_t e[NS][2];
-    uint32_t bidx[NS][4];
-    bool go[NS];
+    // ---- phase 1: the sites
+    nm_window win[NM_SITE_PER_LANE];
+    uint64_t e[NM_SITE_PER_LANE][4];                                   // one word per window of the entry
+    uint32_t bidx[NM_SITE_PER_LANE][4];
+    bool go[NM_SITE_PER_LANE];
+    nm_quad_inflight fly[NM_SITE_PER_LANE];
     uint32_t n_entries = 0;
 #pragma unroll
-    for (uint32_t s = 0; s < NS; s++) {
-        const uint32_t g = s * (NM_SITE_BLOCK / 2) + (tid >> 1);       // group g: positions base + g G .. + G - 1, site at + d
+    for (int s = 0; s < NM_SITE_PER_LANE; s++) {
+        const uint32_t g = (uint32_t)s * NM_SITE_BLOCK + tid;          // group g: positions base + g G .. + G - 1, site at + d
         win[s] = lds_window(g * G + d);
         go[s] = base + (uint64_t)g * G < num_kmers && nm_site_core_valid(win[s], m) && !(ix.seed_policy & 0x200u);
         nm_quad_index(win[s], m, bidx[s]);
-        e[s][0] = e[s][1] = 0;
-        if (go[s]) {
-            const uint64_t *entry = ix.quad + nm_quad_slot(win[s], m) * NM_QUAD_WORDS;     // one 128-byte line per lane pair
-            nm_quad_load16(nm_quad_half(entry, bidx[s], half), e[s][0], e[s][1]);
-            n_entries += 2;
-        }
+        // one 128-byte line; its two 16-byte halves are read by this lane and its neighbour (nm_quad_issue_paired)
+        fly[s] = nm_quad_issue_paired(ix.quad + nm_quad_slot(win[s], m) * NM_QUAD_WORDS, go[s], bidx[s]);
+        if (go[s]) n_entries += 4;
     }
 #pragma unroll
-    for (uint32_t s = 0; s < NS; s++) {
-        const uint64_t settled = go[s] ? nm_site_settled(nm_site_half_bits(win[s], m, bidx[s], half, e[s][0], e[s][1]), d) : 0ULL;
+    for (int s = 0; s < NM_SITE_PER_LANE; s++) nm_quad_finish_paired(fly[s], e[s]);
+#pragma unroll
+    for (int s = 0; s < NM_SITE_PER_LANE; s++) {
+        const uint64_t settled = go[s] ? nm_site_settled(nm_site_bits(win[s], m, bidx[s], e[s]), d) : 0ULL;
         if (settled) {
-            const uint32_t o = (s * (NM_SITE_BLOCK / 2) + (tid >> 1)) * G;   // bit offset of the group in the block
+            const uint32_t o = ((uint32_t)s * NM_SITE_BLOCK + tid) * G;   // bit offset of the group in the block
             const uint32_t wi = o >> 5, sh = o & 31;
             atomicOr(&s_set[wi], (uint32_t)(settled << sh));
             const uint64_t rest = sh ? settled >> (32 - sh) : settled >> 16 >> 16;
@@ -427,29 +516,19 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         const uint32_t n_q = s_qn;
         __syncthreads();
         if (tid == 0) s_qn = 0;
-        // (a lookup = two lanes, as in phase 1: lane pair j takes the open positions j and j + 128)
-        const uint32_t m2 = ix.quad2_m, reach = kmin - (m2 + NM_QUAD_EXT);  // windows p + i with i <= reach lie inside the kmin-mer
-        const uint32_t usable = reach >= 4 ? 0x1Fu : (1u << (reach + 1)) - 1u;
-#pragma unroll
-        for (uint32_t r = 0; r < NM_SITE_CHANCE_MAX / (NM_SITE_BLOCK / 2); r++) {
-            const uint32_t qi = r * (NM_SITE_BLOCK / 2) + (tid >> 1);
-            uint32_t bits = 0, rel = 0;
-            if (qi < n_q && (usable & (half ? 0x18u : 0x03u))) {
-                rel = s_q[qi];
-                const nm_window w = lds_window(rel);
-                if (nm_site_core_valid(w, m2)) {
-                    uint32_t b[4];
-                    nm_quad_index(w, m2, b);
-                    uint64_t a0, a1;
-                    nm_quad_load16(nm_quad_half(ix.quad2 + nm_quad_slot(w, m2) * NM_QUAD_WORDS, b, half), a0, a1);
-                    n_entries += 2;
-                    bits = nm_site_half_bits(w, m2, b, half, a0, a1) & usable;
-                }
-            } else if (qi < n_q) {
-                rel = s_q[qi];
-            }
-            const uint32_t other = (uint32_t)__shfl_xor((int)bits, 1, NM_WAVE);
-            if (half == 0 && qi < n_q && (bits | other)) {
+        {
+            // (every lane takes part in the exchange of halves, with or without a position of its own)
+            const bool have = tid < n_q;
+            const uint32_t rel = have ? s_q[tid] : 0u;
+            const nm_window w = lds_window(rel);
+            const uint32_t m2 = ix.quad2_m;
+            const bool go2 = have && nm_site_core_valid(w, m2);
+            uint32_t b2[4];
+            uint64_t e2[4];
+            nm_quad_index(w, m2, b2);
+            nm_quad_finish_paired(nm_quad_issue_paired(ix.quad2 + nm_quad_slot(w, m2) * NM_QUAD_WORDS, go2, b2), e2);
+            if (have) n_entries += 4;
+            if (go2 && nm_second_chance_bits(ix, w, kmin, b2, e2)) {
                 nm_store(out, elem_bytes, base + rel, kmin);
                 atomicAnd(&s_need[rel >> 5], ~(1u << (rel & 31)));
                 atomicSub(&s_open_total, 1u);
@@ -745,6 +824,7 @@ struct nm_index {
     int kernel_version = 0;               // 0 = automatic (sites when the quad table applies, else 1); 1 / 5 force a kernel
     uint32_t last_site_m = 0;             // core length of the table the sites of the last launch read (nm_index_info 20)
     bool probes_beside = true;            // NEWMAP_AMD_PROBES_BESIDE=0: the probes always follow k_sites on its stream (A/B)
+    bool periodic_runs = true;            // NEWMAP_AMD_PERIODIC=0: the coarse probes walk every stride (A/B) instead of one walk per tandem run
     int site_table = 0;                   // measurement knob (NM_OPT_SITE_TABLE): 0 = pick per launch, 1 = long cores, 2 = short cores
     uint32_t site_d_cap = NM_SITE_MAX_D;  // measurement knob (NEWMAP_AMD_SITE_D): cap on d = kmin - window of the sites
     bool count_steps = false;
@@ -1155,6 +1235,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (const char *cm = getenv("NEWMAP_AMD_COARSE")) ix->coarse_mode = atoi(cm);
     if (const char *cs = getenv("NEWMAP_AMD_COARSE_STRIDE")) { const int v = atoi(cs); if (v == 128 || v == 256 || v == 512) ix->coarse_stride = (uint32_t)v; }
     if (const char *pb = getenv("NEWMAP_AMD_PROBES_BESIDE")) ix->probes_beside = pb[0] != '0';
+    if (const char *pr = getenv("NEWMAP_AMD_PERIODIC")) ix->periodic_runs = pr[0] != '0';
     if (const char *sd = getenv("NEWMAP_AMD_SITE_D")) { ix->site_d_cap = (uint32_t)atoi(sd); if (ix->site_d_cap > NM_SITE_MAX_D) ix->site_d_cap = NM_SITE_MAX_D; }
     if (hipHostMalloc((void **)&ix->h_repeats_seen, 64, hipHostMallocMapped) == hipSuccess) {
         *ix->h_repeats_seen = 0;
@@ -1351,11 +1432,18 @@ static int nm_launch_probes(nm_index *ix, const nm_view &view, uint64_t n, uint3
     if (n >= ix->coarse_min && (ix->coarse_mode == 2 || (ix->coarse_mode == 1 && repeats_met))) {
         const uint32_t cstride = ix->coarse_stride;
         const uint64_t n_coarse = (n + cstride - 1) / cstride;
-        if ((rc = nm_grow(ix->cur->coarse, n_coarse * sizeof(uint32_t))) != NM_OK) return rc;
+        if ((rc = nm_grow(ix->cur->coarse, 2 * n_coarse * sizeof(uint32_t))) != NM_OK) return rc;
         nm_timed timed(ix, st, 2);
-        if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->cur->coarse.p, tally, need, n_probes, cstride);
-        else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, (uint32_t *)ix->cur->coarse.p, tally, need, n_probes, cstride);
-        coarse = (const uint32_t *)ix->cur->coarse.p;
+        uint32_t *c0 = (uint32_t *)ix->cur->coarse.p, *c1 = c0 + n_coarse;
+        if (ix->periodic_runs) {
+            if (ix->count_steps) hipLaunchKernelGGL((k_period_runs<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, ix->cur->enc_words, n_coarse, kmax, c1, tally, need, n_probes, cstride);
+            else                 hipLaunchKernelGGL((k_period_runs<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, ix->cur->enc_words, n_coarse, kmax, c1, tally, need, n_probes, cstride);
+            hipLaunchKernelGGL(k_period_spread, dim3(nm_grid(n_coarse)), block, 0, st, (const uint32_t *)c1, c0, n_coarse);
+        } else {
+            if (ix->count_steps) hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, true>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, c0, tally, need, n_probes, cstride);
+            else                 hipLaunchKernelGGL((k_repeat_probe_coarse<BIG, false>), dim3(nm_grid(n_coarse)), block, 0, st, view, enc, n_coarse, kmax, c0, tally, need, n_probes, cstride);
+        }
+        coarse = (const uint32_t *)c0;
     }
     {
         nm_timed timed(ix, st, 3);

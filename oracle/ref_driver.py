@@ -54,6 +54,8 @@ def lib():
     L.or_build.argtypes = [vp, vp, i64]
     L.or_build_ptrs.restype = vp
     L.or_build_ptrs.argtypes = [vp, vp, i64]
+    L.or_build_ptrs_depth.restype = vp
+    L.or_build_ptrs_depth.argtypes = [vp, vp, i64, i64]
     L.or_drop_sa.argtypes = [vp]
     L.or_free.argtypes = [vp]
     L.or_text_length.restype = i64
@@ -75,6 +77,8 @@ def lib():
     L.or_ref_binary_search_segment.restype = i32
     L.or_ref_binary_search_segment.argtypes = [vp, vp, i64, i64, u32, u32, u32, i32, i32,
                                                vp, vp, vp, vp, vp]
+    L.or_scan_counts.restype = i32
+    L.or_scan_counts.argtypes = [vp, vp, i64, vp, vp, i64, i32, vp]
     L.or_num_threads.restype = i32
     L.or_set_num_threads.argtypes = [i32]
     _lib = L
@@ -160,16 +164,18 @@ def sequence_segments(path_or_lines, length: int, overlap: int = 0) -> Iterator[
 class OracleIndex:
     """Forward-strand text of all records + suffix array (+ optional FM port)."""
 
-    def __init__(self, records: Sequence):
+    def __init__(self, records: Sequence, max_depth: int = 0):
         """records: bytes objects or uint8 numpy arrays (not copied: a 3 Gbp genome stays where it is).  The mapped
-        text -- one separator per record included -- must stay below 2^32 symbols."""
+        text -- one separator per record included -- must stay below 2^32 symbols.  max_depth > 0: order the suffixes
+        by their first max_depth symbols only (texts with very long exact repeats): counts of k-mers up to that length
+        stay exact, the FM port is not available."""
         self._L = lib()
         self.records = [r for r in records if len(r)]
         views = [np.frombuffer(r, dtype=np.uint8) if isinstance(r, (bytes, bytearray, memoryview)) else np.ascontiguousarray(r, dtype=np.uint8)
                  for r in self.records]
         ptrs = np.array([v.ctypes.data for v in views], dtype=np.uint64)
         lens = np.array([v.size for v in views], dtype=np.int64)
-        self._h = self._L.or_build_ptrs(ptrs.ctypes.data if len(views) else None, lens.ctypes.data if len(views) else None, len(views))
+        self._h = self._L.or_build_ptrs_depth(ptrs.ctypes.data if len(views) else None, lens.ctypes.data if len(views) else None, len(views), int(max_depth))
         if not self._h:
             raise MemoryError("oracle index build failed (text of 2^32 symbols or more, or out of memory)")
         self._fm_seed = None
@@ -222,6 +228,56 @@ class OracleIndex:
 
 
 _COMPLEMENT = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")     # newmap/search.py:22
+
+
+def scan_total_counts(records: Sequence, seq: bytes, starts, lens, seed: int, use_rc: bool = True) -> np.ndarray:
+    """newmap/search.py:647-697 totals (forward + reverse complement) of seq[s:s+l] over `records`, by ONE scan of the
+    records with no index (oracle/kmer_oracle.c or_scan_counts): for full-size genomes no suffix array fits.  Every
+    length must be >= seed (<= 32)."""
+    L = lib()
+    starts = np.asarray(starts, dtype=np.int64)
+    lens = np.asarray(lens, dtype=np.int64)
+    assert lens.size == 0 or int(lens.min()) >= seed
+    views = [np.frombuffer(r, dtype=np.uint8) if isinstance(r, (bytes, bytearray, memoryview)) else np.ascontiguousarray(r, dtype=np.uint8)
+             for r in records]
+    ptrs = np.array([v.ctypes.data for v in views], dtype=np.uint64)
+    rlens = np.array([v.size for v in views], dtype=np.int64)
+    nq = int(starts.size)
+    parts = [seq[int(s):int(s) + int(l)] for s, l in zip(starts, lens)]
+    if use_rc:
+        parts += [p.translate(_COMPLEMENT)[::-1] for p in parts]
+    blob = np.frombuffer(b"".join(parts) or b"\0", dtype=np.uint8)
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    np.cumsum([len(p) for p in parts], out=off[1:])
+    counts = np.zeros(max(len(parts), 1), dtype=np.uint32)
+    rc = L.or_scan_counts(ptrs.ctypes.data, rlens.ctypes.data, len(views), blob.ctypes.data, off.ctypes.data, len(parts), int(seed),
+                          counts.ctypes.data)
+    if rc != 0:
+        raise MemoryError(f"or_scan_counts failed ({rc})")
+    return (counts[:nq] + counts[nq:2 * nq]) if use_rc else counts[:nq]
+
+
+def closed_form_claims(seq: bytes, out: np.ndarray, kmin: int, kmax: int):
+    """What an output array asserts about counts, as (start, length, relation) queries over
+    the positions [0, len(out)) of `seq` (which carries its lookahead): out[p] = a > 0 claims total(p, a) == 1 and, for
+    a > kmin, total(p, a - 1) >= 2; out[p] == 0 at an unambiguous position with U_p >= kmin claims total(p, U_p) >= 2
+    (U_p = min(kmax, unambiguous bases from p on, newmap/search.py:769-882).  Because the total is >= 1 and does not
+    grow with the length, these claims hold if and only if `out` is the closed form."""
+    n = len(out)
+    amb = ~_ALLOWED[np.frombuffer(seq, dtype=np.uint8)]
+    idx = np.arange(len(seq), dtype=np.int64)
+    nxt = np.where(amb, idx, np.int64(len(seq)))
+    nxt = np.minimum.accumulate(nxt[::-1])[::-1]
+    room = np.minimum(nxt - idx, kmax)[:n]
+    o = out.astype(np.int64)
+    uniq = np.flatnonzero(o > 0)
+    shorter = uniq[o[uniq] > kmin]
+    zero = np.flatnonzero((o == 0) & ~amb[:n] & (room >= kmin))
+    assert (o[uniq] <= room[uniq]).all() and (o[uniq] >= kmin).all(), "a reported length lies outside [kmin, U_p]"
+    starts = np.concatenate([uniq, shorter, zero])
+    lens = np.concatenate([o[uniq], o[shorter] - 1, room[zero]])
+    rel = np.concatenate([np.zeros(uniq.size, np.int8), np.ones(shorter.size, np.int8), np.ones(zero.size, np.int8)])   # 0: == 1, 1: >= 2
+    return starts, lens, rel
 
 
 def total_counts(index: OracleIndex, seq: bytes, starts: np.ndarray, lens: np.ndarray,

@@ -42,6 +42,8 @@ def lib():
     L.hs_min_unique.argtypes = [vp, vp, u64, u64, u32, u32, i32, i32, vp, vp]
     L.hs_repeat_probes.restype = u64
     L.hs_repeat_probes.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, vp, vp]
+    L.hs_repeat_probes2.restype = u64
+    L.hs_repeat_probes2.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, vp, vp, i32, vp, vp]
     L.hs_fasta_open.restype = vp
     L.hs_fasta_open.argtypes = [ctypes.c_char_p, u32, u64]
     L.hs_fasta_close.argtypes = [vp]
@@ -116,6 +118,20 @@ class HostSim:
         steps = self.L.hs_repeat_probes(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, stride, coarse_stride,
                                         words.ctypes.data, decided.ctypes.data)
         return words[:n_probes], decided[:num_kmers], int(steps)
+
+    def repeat_probes_periodic(self, seq: bytes, num_kmers, kmin, kmax, stride=64, coarse_stride=512):
+        """the same with the coarse words taken from the tandem runs (k_period_runs / k_period_spread): also returns the period
+        found per coarse stride and the coarse words"""
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        n_probes = (num_kmers + stride - 1) // stride
+        n_coarse = (num_kmers + coarse_stride - 1) // coarse_stride
+        words = np.zeros(n_probes + 1, dtype=np.uint32)
+        decided = np.zeros(max(num_kmers, 1), dtype=np.uint32)
+        periods = np.zeros(max(n_coarse, 1), dtype=np.uint32)
+        coarse = np.zeros(max(n_coarse, 1), dtype=np.uint32)
+        steps = self.L.hs_repeat_probes2(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, stride, coarse_stride,
+                                         words.ctypes.data, decided.ctypes.data, 1, periods.ctypes.data, coarse.ctypes.data)
+        return words[:n_probes], decided[:num_kmers], int(steps), periods[:n_coarse], coarse[:n_coarse]
 
     def sites(self, seq: bytes, num_kmers, kmin, kmax, d_cap=59, probes=1, ks=None, dtype=np.uint8, chance_max=256, walk_max=64):
         """k_sites -> gated repeat probes -> k_resolve, as the device runs them (needs check_quad() first: it builds the

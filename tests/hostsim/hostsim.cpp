@@ -250,8 +250,53 @@ uint64_t hs_check_codes4(uint64_t rounds) {
 // the repeat probes of one segment (k_repeat_probe): the probe word of every stride, and what the consumers
 // make of them: decided[p] = the element nm_probe_kstar / nm_probe_element give position p, 0xFFFFFFFF where the
 // probes leave it open.  Returns the LF steps spent.
+// k_period_runs + k_period_spread (nm_engine.hip): coarse[c] = coarse_stride for every stride of a tandem run whose first
+// stride's walk of kmax + u - 1 bases still finds two occurrences, else 0.  periods (may be null): the period found per stride.
+uint64_t hs_period_runs(hs_index *ix, const std::vector<nm_enc_word> &enc, uint64_t num_kmers, uint32_t kmax, uint32_t coarse_stride,
+                        std::vector<uint32_t> &coarse, uint32_t *periods) {
+    uint64_t steps = 0;
+    const uint64_t n_coarse = (num_kmers + coarse_stride - 1) / coarse_stride;
+    std::vector<uint32_t> raw(n_coarse, 0);
+    coarse.assign(n_coarse, 0);
+    const uint32_t len = coarse_stride + kmax - 1;
+    for (uint64_t c = 0; c < n_coarse; c++) {
+        const uint32_t u = nm_period_of(enc.data(), enc.size(), c * coarse_stride, len);
+        if (periods) periods[c] = u;
+        if (!u) continue;
+        const bool first = c == 0 || nm_period_of(enc.data(), enc.size(), (c - 1) * coarse_stride, len) != u;
+        if (!first) { raw[c] = NM_PERIOD_INHERIT; continue; }
+        nm_tally t = {0, 0, 0, 0};
+        uint32_t settled, exact;
+        if (ix->big) nm_repeat_probe_ex<true>(ix->v, enc.data(), c * coarse_stride, kmax, u, t, settled, exact);
+        else nm_repeat_probe_ex<false>(ix->v, enc.data(), c * coarse_stride, kmax, u, t, settled, exact);
+        raw[c] = settled == u ? coarse_stride : 0u;
+        steps += t.steps;
+    }
+    for (uint64_t c = 0; c < n_coarse; c++) {
+        uint32_t v = raw[c];
+        if (v == NM_PERIOD_INHERIT) {
+            v = 0;
+            for (uint64_t j = c; j-- > 0 && c - j <= 8192;)
+                if (raw[j] != NM_PERIOD_INHERIT) { v = raw[j]; break; }
+        }
+        coarse[c] = v;
+    }
+    return steps;
+}
+
+// periodic != 0: the coarse words come from the tandem runs (k_period_runs) instead of the coarse probes
+uint64_t hs_repeat_probes2(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin,
+                           uint32_t kmax, uint32_t stride, uint32_t coarse_stride, uint32_t *words, uint32_t *decided, int periodic,
+                           uint32_t *periods, uint32_t *coarse_out);
+
 uint64_t hs_repeat_probes(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin,
                           uint32_t kmax, uint32_t stride, uint32_t coarse_stride, uint32_t *words, uint32_t *decided) {
+    return hs_repeat_probes2(ix, seq, seq_len, num_kmers, kmin, kmax, stride, coarse_stride, words, decided, 0, nullptr, nullptr);
+}
+
+uint64_t hs_repeat_probes2(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin,
+                           uint32_t kmax, uint32_t stride, uint32_t coarse_stride, uint32_t *words, uint32_t *decided, int periodic,
+                           uint32_t *periods, uint32_t *coarse_out) {
     std::vector<nm_enc_word> enc;
     hs_encode(seq, seq_len, enc);
     uint64_t steps = 0;
@@ -259,7 +304,10 @@ uint64_t hs_repeat_probes(hs_index *ix, const uint8_t *seq, uint64_t seq_len, ui
     // coarse probes first (k_repeat_probe_coarse; coarse_stride 0 = none): strides they settle completely get their
     // word without a walk (k_repeat_probe)
     std::vector<uint32_t> coarse;
-    if (coarse_stride) {
+    if (coarse_stride && periodic) {
+        steps += hs_period_runs(ix, enc, num_kmers, kmax, coarse_stride, coarse, periods);
+        if (coarse_out) for (size_t c = 0; c < coarse.size(); c++) coarse_out[c] = coarse[c];
+    } else if (coarse_stride) {
         coarse.resize((num_kmers + coarse_stride - 1) / coarse_stride);
         for (uint64_t c = 0; c < coarse.size(); c++) {
             nm_tally t = {0, 0, 0, 0};

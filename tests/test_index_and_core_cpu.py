@@ -305,6 +305,64 @@ def test_repeat_probes_decide_only_what_the_oracle_confirms(tmp_path):
         assert steps_coarse < steps_fine
 
 
+def _brute_period(rec: bytes, P: int, length: int, umax: int = 256) -> int:
+    a = np.frombuffer(rec, dtype=np.uint8)
+    ok = np.isin(a, np.frombuffer(b"ACGTacgt", np.uint8))
+    up = np.frombuffer(rec.upper(), dtype=np.uint8)
+    for u in range(1, umax + 1):
+        if P + length + u > len(rec):
+            return 0
+        if ok[P:P + length + u].all() and np.array_equal(up[P:P + length], up[P + u:P + u + length]):
+            return u
+    return 0
+
+
+def test_tandem_runs_settle_whole_strides_only_where_the_oracle_has_zeros(tmp_path):
+    """nm_period_of + the run logic of k_period_runs / k_period_spread (tandem repeats stand in for the coarse probes):
+    the period found per coarse stride equals a brute-force comparison of the bytes; every stride the runs settle holds
+    only zeros in the oracle's output; long tandem arrays ARE settled, at far fewer LF steps than the coarse probes walk;
+    a periodic sequence that is foreign to the index settles nothing (the index decides, not the sequence)."""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    rec = bytearray(bytes(alpha[rng.integers(0, 4, 60000)]))
+    arrays = [(2000, 9000, 7), (14000, 5000, 200), (22000, 12000, 31), (40000, 3000, 2), (47000, 2500, 64), (52000, 700, 5)]
+    for start, length, unit_len in arrays:
+        unit = bytes(alpha[rng.integers(0, 4, unit_len)])
+        rec[start:start + length] = (unit * (length // unit_len + 1))[:length]
+    rec[25000:25003] = b"NNN"                              # an ambiguous run inside an array: two runs
+    rec[30000] = ord("a") if rec[30000] != ord("A") else ord("c")   # (lower case is a base like any other)
+    rec = bytes(rec)
+    fa = _write(tmp_path, b">t\n" + rec + b"\n")
+    idx = tmp_path / "t.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    oracle = rd.OracleIndex([rec])
+    sim = HostSim(idx, 6)
+    for kmin, kmax, cs in ((20, 255, 512), (20, 60, 512), (24, 150, 256), (20, 200, 128)):
+        want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True).astype(np.int64)
+        words, decided, steps, periods, coarse = sim.repeat_probes_periodic(rec, len(rec), kmin, kmax, 64, cs)
+        length = cs + kmax - 1
+        for c in range(len(periods)):
+            assert periods[c] == _brute_period(rec, c * cs, length), (kmin, kmax, cs, c)
+        assert set(np.unique(coarse)) <= {0, cs}
+        for c in np.flatnonzero(coarse):
+            assert (want[c * cs:(c + 1) * cs] == 0).all(), (kmin, kmax, cs, c)
+        closed = decided != 0xFFFFFFFF
+        assert np.array_equal(decided[closed].astype(np.int64), want[closed]), (kmin, kmax, cs)
+        # the 12 kb array (period 31) holds ~ (12000 - 3 - kmax - cs) / cs full strides on either side of the N run
+        in_big = [c for c in np.flatnonzero(coarse) if 22000 <= c * cs < 34000]
+        assert len(in_big) >= (12000 - 2 * (kmax + 2 * cs) - 300) // cs - 2, (kmin, kmax, cs, len(in_big))
+        if cs == 512:
+            _, with_coarse, steps_coarse = sim.repeat_probes(rec, len(rec), kmin, kmax, 64, coarse_stride=512)
+            assert steps < steps_coarse
+    # a foreign sequence: the same arrays with other units are periodic all the same, but the walks fail
+    other = bytearray(rec)
+    for start, length, unit_len in arrays:
+        unit = bytes(alpha[rng.integers(0, 4, max(unit_len, 12))])
+        other[start:start + length] = (unit * (length // len(unit) + 1))[:length]
+    _, _, _, periods, coarse = sim.repeat_probes_periodic(bytes(other), len(other), 20, 255, 64, 512)
+    assert periods.any() and not coarse.any()
+
+
 @pytest.mark.parametrize("m,force_big", [(4, False), (6, False), (5, True)])
 def test_quad_table_bits_equal_direct_counts(tmp_path, m, force_big):
     """nm_quad_build_one / nm_quad_slot / nm_quad_bits (the quad table of k_quad_build and

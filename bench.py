@@ -48,6 +48,7 @@ BATCH = 1 << 28                # positions per launch: one launch per record (th
 REFERENCE_BATCH = 10_000_000
 CHUNK = 64 << 20               # interleaved chunk of the multi-GPU split (newmap_amd/parallel.py)
 C2_SEED, C2_BASES = 20260515, 100_000_000
+SW = 16                        # uint64 words of a segment's status row (include/newmap_amd.h NM_STATUS_WORDS)
 PROFILES = ROOT / "profiles" / "round3"
 PMC_SUMMARIES = {"ns": PROFILES / "pmc_ns_sites_kernel_summary.csv", "c2": PROFILES / "pmc_sites_kernel_summary.csv"}
 KERNEL_SOURCES = [ROOT / "newmap_amd" / "csrc" / "nm_engine.hip", ROOT / "newmap_amd" / "csrc" / "nm_core.h"]
@@ -249,7 +250,7 @@ class Run:
         self.my_positions = int(sum(u.count for u in units))
         self.d_seq = torch.empty(max(int(seg_off[-1]), 16), dtype=torch.uint8, device=dev)
         self.d_out = torch.zeros(max(int(out_off[-1]), 16), dtype=torch.uint8, device=dev)
-        self.d_status = torch.zeros((max(len(units), 1), 8), dtype=torch.int64, device=dev)
+        self.d_status = torch.zeros((max(len(units), 1), SW), dtype=torch.int64, device=dev)
         t0 = time.time()
         for u, o in zip(units, seg_off[:-1]):
             rec = wl.record(u.record)
@@ -271,7 +272,7 @@ class Run:
         if len(segs) < 2:
             streams = streams[:1]
         for j, (so, seg_len, cnt, oo, i) in enumerate(segs):
-            self.ix.min_unique_segment_dev(sp + so, seg_len, cnt, self.KMIN, self.KMAX, True, 1, op + oo, st + 64 * i, streams[j % len(streams)])
+            self.ix.min_unique_segment_dev(sp + so, seg_len, cnt, self.KMIN, self.KMAX, True, 1, op + oo, st + 8 * SW * i, streams[j % len(streams)])
 
     def _reduce(self, x, op):
         if self.world == 1:
@@ -349,7 +350,7 @@ class Run:
     def more_status_rows(self, n):
         """`n` further status rows (segments cut differently from the resident units get their own); returns the first"""
         first = self.d_status.shape[0]
-        self.d_status = self.torch.cat([self.d_status, self.torch.zeros((n, 8), dtype=self.torch.int64, device=self.dev)])
+        self.d_status = self.torch.cat([self.d_status, self.torch.zeros((n, SW), dtype=self.torch.int64, device=self.dev)])
         return first
 
     def counters(self):
@@ -357,7 +358,7 @@ class Run:
         [6] table words read by k_resolve (second chance + seed entries), [7] positions searched"""
         torch = self.torch
         self.ix.set_count_steps(True)
-        tallies = np.zeros(8, dtype=np.int64)
+        tallies = np.zeros(SW, dtype=np.int64)
         probe = {"lf_steps": 0, "rank_blocks": 0, "seed_lookups": 0, "settled": 0}
         for seg in self.segs:
             self.step([seg])

@@ -136,7 +136,9 @@ int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, u
  * caller stream (up to 5; further streams take over the least recently used set behind an event), so calls given
  * different streams -- independent segments with their own d_out / d_status -- may overlap on the device.  Host-side the
  * calls on one handle are still made one at a time (nm_set_option / info likewise). */
-#define NM_STATUS_WORDS 8
+#define NM_STATUS_WORDS 16
+#define NM_STATUS_HASH 8           /* [8]: fingerprint of the segment's num_kmers positions (csrc/nm_hash.h); the
+                                      driver joins the segments of a record (nm_hash_join) and asks nm_index_has_record */
 int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers,
                               uint32_t kmin, uint32_t kmax, int use_revcomp, int elem_bytes,
                               void *d_out, uint64_t *d_status, void *stream);
@@ -160,6 +162,11 @@ enum {
                                       default 1, 0 = always the list kernel, for A/B */
     NM_OPT_SITE_TABLE = 13,        /* measurement / tests: which quad table the sites read: 0 pick per launch (default), 1 the one
                                       with long cores, 2 the one with short cores (the other backs it up in k_resolve) */
+    NM_OPT_SEGMENT_GUARD = 15,     /* default 1: nm_min_unique_segment / nm_fixed_k_segment (host buffers: the seam of binary_search /
+                                      linear_search) run the exact zero-count guard unless the segment is a whole indexed record;
+                                      0: the caller checks whole records itself (what the drivers do) */
+    NM_OPT_INITIAL_LENGTH = 14,    /* --initial-search-length of the run (0 = none): the native drivers hand it to the exact guard, whose
+                                      replay of the reference's probe schedule depends on it; results never do */
     NM_OPT_SITE_D = 12             /* measurement / tests: cap (0..59, default 59) on d = kmin - (core length + 4); a site
                                       settles a group of d + 5 positions */
 };
@@ -221,6 +228,37 @@ int nm_dev_upload(int device, void *dst, const void *src, uint64_t bytes);
 int nm_dev_download(int device, void *dst, const void *src, uint64_t bytes);
 int nm_dev_sync(int device);
 int nm_device_count(void);
+
+/* ------------------------------------------------------------------ record fingerprints -----
+ * Replaces the unconditional zero-count check of newmap/search.py:699-722 by "is this record one of the indexed
+ * records?": an index file (format 2) lists the length and fingerprint of each of its records (csrc/nm_hash.h: a
+ * sum over the record's 64-base words of mix(planes) * R^word mod 2^64).  Every segment call leaves the fingerprint of
+ * its positions in d_status[NM_STATUS_HASH]; the driver joins the segments of a record -- H(a.b) = H(a) + R^(len(a)/64) *
+ * H(b) for segments that start at multiples of 64 bases of their record, which is how the native drivers cut them -- and
+ * looks the record up.  A record that is found holds no absent k-mer; any other record is searched again with every probe of the
+ * reference's schedule verified (nm_guard_segment_dev below). */
+int nm_index_has_record(const nm_index *ix, uint64_t length, uint64_t fingerprint);      /* 1 = indexed, 0 = not */
+/* The exact guard over one segment: replays, per position, the probe schedule of newmap/search.py:383-548 (range mode:
+ * ks = {kmin, kmax}; initial_len = --initial-search-length or 0) or :551-644 (list mode) and walks the longest probed
+ * k-mer; NM_E_KMER_NOT_FOUND (host-buffer form) / d_status[1], [2] (device form) exactly when the reference would raise. */
+int nm_guard_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks, uint32_t nk,
+                         int range_mode, uint32_t initial_len, int use_revcomp, uint64_t *d_status, void *stream);
+int nm_guard_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks, uint32_t nk,
+                     int range_mode, uint32_t initial_len, int use_revcomp, uint64_t *bad_pos);
+/* nm_search_fasta does all of this itself.  For jobs of several ranks: nm_search_fasta_shard_ex also hands back, per FASTA
+ * record with data (file order), rec_info[3 i + 0 .. 2] = {length, fingerprint summed over THIS rank's units, 1 if
+ * searched}; the caller adds the ranks' sums, asks nm_index_has_record, and runs nm_guard_fasta (flags[i] != 0 = guard
+ * record i) on one rank. */
+int nm_search_fasta_shard_ex(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks, uint32_t nk, int range_mode,
+                             int use_revcomp, uint64_t batch, const char *const *include_ids, uint32_t n_include,
+                             const char *const *exclude_ids, uint32_t n_exclude, nm_record_callback cb, void *user,
+                             nm_search_summary *total, int rank, int world, uint64_t *rec_info, uint64_t capacity, uint64_t *n_records);
+int nm_guard_fasta(nm_index *ix, const char *fasta_path, const uint32_t *ks, uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
+                   const char *const *include_ids, uint32_t n_include, const char *const *exclude_ids, uint32_t n_exclude,
+                   const uint8_t *flags, uint64_t n_flags);
+uint64_t nm_index_records(const nm_index *ix, uint64_t *lengths, uint64_t *fingerprints, uint64_t capacity);   /* returns their number */
+uint64_t nm_fingerprint_join(uint64_t fp_a, uint64_t len_a, uint64_t fp_b);
+uint64_t nm_fingerprint_sequence(const uint8_t *seq, uint64_t len);                      /* host loop, for small inputs and tests */
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ LIB_PATH = _HERE / "libnewmap_amd.so"
 NM_OK = 0
 NM_E_FILE_OPEN, NM_E_ALLOC, NM_E_FILE_EXISTS, NM_E_FILE_WRITE, NM_E_FILE_FORMAT = 1, 2, 3, 4, 5
 NM_E_ARGUMENT, NM_E_DEVICE, NM_E_KMER_NOT_FOUND, NM_E_TOO_LARGE = 6, 7, 8, 9
-NM_STATUS_WORDS = 8
+NM_STATUS_WORDS = 16
 NM_OPT_COUNT_STEPS = 1
 NM_OPT_TIMING = 3
 NM_OPT_KERNEL = 4
@@ -24,6 +24,8 @@ NM_OPT_REPEAT_PROBES = 10
 NM_OPT_LIST_VIA_RANGE = 11
 NM_OPT_SITE_D = 12
 NM_OPT_SITE_TABLE = 13
+NM_OPT_INITIAL_LENGTH = 14
+NM_OPT_SEGMENT_GUARD = 15
 
 EXPORTS = [
     "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_close",
@@ -31,6 +33,8 @@ EXPORTS = [
     "nm_fixed_k_segment", "nm_upper_bound_segment", "nm_min_unique_segment_dev",
     "nm_fixed_k_segment_dev", "nm_set_option", "nm_dev_alloc", "nm_dev_free", "nm_dev_upload",
     "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read", "nm_timing_read_kind", "nm_search_fasta", "nm_search_fasta_shard", "nm_track_file", "nm_search_segment_multi", "nm_index_build_device",
+    "nm_index_has_record", "nm_index_records", "nm_fingerprint_join", "nm_fingerprint_sequence", "nm_guard_segment_dev", "nm_guard_segment",
+    "nm_search_fasta_shard_ex", "nm_guard_fasta",
 ]
 
 _lib = None
@@ -138,6 +142,10 @@ def lib():
                                   RECORD_CALLBACK, vp, c.POINTER(SearchSummary)]
     L.nm_search_fasta_shard.restype = i32
     L.nm_search_fasta_shard.argtypes = L.nm_search_fasta.argtypes + [i32, i32]
+    L.nm_search_fasta_shard_ex.restype = i32
+    L.nm_search_fasta_shard_ex.argtypes = L.nm_search_fasta_shard.argtypes + [vp, u64, c.POINTER(u64)]
+    L.nm_guard_fasta.restype = i32
+    L.nm_guard_fasta.argtypes = [vp, c.c_char_p, vp, u32, i32, i32, u64, c.POINTER(c.c_char_p), u32, c.POINTER(c.c_char_p), u32, vp, u64]
     L.nm_search_segment_multi.restype = i32
     L.nm_search_segment_multi.argtypes = [vp, u32, vp, u32, u64, u64, vp, u32, i32, i32, i32, vp, vp, vp]
     L.nm_track_file.restype = i32
@@ -147,6 +155,18 @@ def lib():
     L.nm_timing_read.argtypes = [vp, c.POINTER(u64), c.POINTER(c.c_double), c.POINTER(c.c_double)]
     L.nm_timing_read_kind.restype = i32
     L.nm_timing_read_kind.argtypes = [vp, i32, c.POINTER(u64), c.POINTER(c.c_double), c.POINTER(c.c_double)]
+    L.nm_index_has_record.restype = i32
+    L.nm_index_has_record.argtypes = [vp, u64, u64]
+    L.nm_index_records.restype = u64
+    L.nm_index_records.argtypes = [vp, vp, vp, u64]
+    L.nm_fingerprint_join.restype = u64
+    L.nm_fingerprint_join.argtypes = [u64, u64, u64]
+    L.nm_fingerprint_sequence.restype = u64
+    L.nm_fingerprint_sequence.argtypes = [vp, u64]
+    L.nm_guard_segment_dev.restype = i32
+    L.nm_guard_segment_dev.argtypes = [vp, vp, u64, u64, vp, u32, i32, u32, i32, vp, vp]
+    L.nm_guard_segment.restype = i32
+    L.nm_guard_segment.argtypes = [vp, vp, u64, u64, vp, u32, i32, u32, i32, vp]
     _lib = L
     return L
 

@@ -25,6 +25,7 @@
 
 #include "../../include/newmap_amd.h"
 #include "nm_format.h"
+#include "nm_hash.h"
 #include "nm_internal.h"
 #include "nm_sais.hpp"
 #include "nm_pdsa.hpp"
@@ -39,7 +40,7 @@ void nm_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *nm_last_error(void) { return g_err; }
-extern "C" const char *nm_version(void) { return "newmap_amd 0.1 (gfx950, index format 1)"; }
+extern "C" const char *nm_version(void) { return "newmap_amd 0.2 (gfx950, index format 2)"; }
 
 namespace {
 
@@ -64,6 +65,8 @@ inline bool is_space(unsigned char c) {      // what bytes.rstrip() removes
 
 struct FastaText {
     std::vector<uint8_t> f;        // forward run text F: runs of SYM_A.. each followed by SYM_SEP
+    std::vector<nm_record_entry> records;   // (length, fingerprint) of every record with data (nm_hash.h)
+    uint64_t rec_len = 0, rec_hash = 0, rec_pw = 1, rec_lo = 0, rec_hi = 0, rec_amb = 0;
     uint64_t n_records = 0, raw_bases = 0, n_runs = 0;
     uint64_t base_count[4] = {0, 0, 0, 0};
     bool in_run = false;
@@ -83,23 +86,35 @@ struct FastaText {
         uint64_t cnt[4] = {0, 0, 0, 0};
         bool run = in_run;
         uint64_t runs = 0;
+        uint64_t wlo = rec_lo, whi = rec_hi, wamb = rec_amb;      // the record's current 64-base word (nm_hash.h)
+        unsigned bit = (unsigned)(rec_len & 63u);
         for (size_t i = 0; i < len; i++) {
             const uint8_t c = g_lut.code[p[i]];
-            if (c != 0xFF) { *out++ = (uint8_t)(SYM_A + c); cnt[c]++; run = true; }
-            else if (run) { *out++ = SYM_SEP; runs++; run = false; }
+            if (c != 0xFF) { *out++ = (uint8_t)(SYM_A + c); cnt[c]++; run = true; wlo |= (uint64_t)(c & 1u) << bit; whi |= (uint64_t)(c >> 1) << bit; }
+            else { wamb |= 1ULL << bit; if (run) { *out++ = SYM_SEP; runs++; run = false; } }
+            if (++bit == 64) { rec_hash += nm_hash_word(wlo, whi, wamb) * rec_pw; rec_pw *= NM_HASH_R; wlo = whi = wamb = 0; bit = 0; }
         }
+        rec_lo = wlo; rec_hi = whi; rec_amb = wamb;
+        rec_len += len;
         f.resize((size_t)(out - f.data()));
         in_run = run;
         n_runs += runs;
         for (int c = 0; c < 4; c++) base_count[c] += cnt[c];
     }
-    void header() { end_run(); record_has_data = false; }
+    void close_record() {
+        if (record_has_data) {
+            if (rec_len & 63u) rec_hash += nm_hash_word(rec_lo, rec_hi, rec_amb) * rec_pw;   // the last, partial word
+            records.push_back(nm_record_entry{rec_len, rec_hash});
+        }
+        rec_len = 0; rec_hash = 0; rec_pw = 1; rec_lo = rec_hi = rec_amb = 0;
+    }
+    void header() { end_run(); close_record(); record_has_data = false; }
     void line(const unsigned char *p, size_t len) {
         while (len && is_space(p[len - 1])) len--;
         if (len && (p[0] == '>' || p[0] == ';')) header();
         else data(p, len);
     }
-    void finish() { end_run(); }
+    void finish() { end_run(); close_record(); record_has_data = false; }
 };
 
 int read_fasta(const char *path, FastaText &ft) {
@@ -298,14 +313,17 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
     h.off_rank = sizeof h;
     h.off_strand = h.off_rank + rank.size() * sizeof(nm_rank_block);
     h.off_sep = h.off_strand + strand.size() * sizeof(nm_strand_block);
-    h.file_bytes = h.off_sep + sep.size() * sizeof(uint64_t);
+    h.off_records = h.off_sep + sep.size() * sizeof(uint64_t);
+    if (ft.records.size() != h.n_records) { nm_set_error("internal error: record count mismatch"); return NM_E_FILE_WRITE; }
+    h.file_bytes = h.off_records + ft.records.size() * sizeof(nm_record_entry);
 
     FILE *fp = fopen(index_path, "wb");        // overwrite, like the reference at its pinned version
     if (!fp) { nm_set_error("Could not write index file %s: %s", index_path, strerror(errno)); return NM_E_FILE_WRITE; }
     bool ok = fwrite(&h, sizeof h, 1, fp) == 1 &&
               fwrite(rank.data(), sizeof(nm_rank_block), rank.size(), fp) == rank.size() &&
               fwrite(strand.data(), sizeof(nm_strand_block), strand.size(), fp) == strand.size() &&
-              (sep.empty() || fwrite(sep.data(), sizeof(uint64_t), sep.size(), fp) == sep.size());
+              (sep.empty() || fwrite(sep.data(), sizeof(uint64_t), sep.size(), fp) == sep.size()) &&
+              (ft.records.empty() || fwrite(ft.records.data(), sizeof(nm_record_entry), ft.records.size(), fp) == ft.records.size());
     ok = (fclose(fp) == 0) && ok;
     if (!ok) { nm_set_error("Could not write index file %s", index_path); return NM_E_FILE_WRITE; }
     return NM_OK;

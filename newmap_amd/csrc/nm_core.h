@@ -25,6 +25,10 @@
 
 #include <stdint.h>
 #include "nm_format.h"
+#ifndef NM_HASH_FN
+#define NM_HASH_FN NM_HD
+#endif
+#include "nm_hash.h"
 
 #ifndef NM_HD
 #error "define NM_HD before including nm_core.h"
@@ -53,6 +57,7 @@ struct nm_view {                // the index as the kernels see it
     uint32_t quad_m;            // its core length; it answers windows of quad_m + 4 bases
     const uint64_t *quad2;      // a second quad table with longer cores (nullptr = none): k_resolve's second chance
     uint32_t quad2_m;
+    const uint64_t *hash_tab;   // NM_HASH_TAB_WORDS words (nm_hash.h): nibble tables + powers of the record fingerprint
 };
 
 struct nm_tally {               // counter build only
@@ -136,6 +141,15 @@ NM_HD nm_enc_word nm_encode_word(const uint8_t *seq, uint64_t seq_len, uint64_t 
 }
 
 NM_HD uint32_t nm_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+
+// fingerprint term of word w of a segment (nm_hash.h): its bases at positions below `end` (the segment's num_kmers; a
+// segment starts at a multiple of 64 of its record, so word w of the segment is word s / 64 + w of the record)
+NM_HD uint64_t nm_hash_segment_word(const uint64_t *tab, const nm_enc_word &x, uint64_t w, uint64_t end) {
+    const uint64_t p0 = w * 64;
+    if (p0 >= end) return 0;
+    const uint64_t take = end - p0 >= 64 ? ~0ULL : (1ULL << (end - p0)) - 1ULL;
+    return nm_hash_word(x.lo & take, x.hi & take, x.amb & take) * nm_hash_word_power(tab, w);
+}
 
 // number of separator positions s with a <= s < b (b - a <= 64); only reached for the rare
 // rank blocks flagged NM_SEP_FLAG
@@ -720,6 +734,113 @@ NM_HD uint32_t nm_count_fwd_one(const nm_view &ix, const uint8_t *kmer, uint64_t
     if (len == 0) return 0;
     t.strands += 2;
     return (uint32_t)(nm_strand_rank(ix, hi) - nm_strand_rank(ix, lo));
+}
+
+NM_HD uint32_t nm_upper_one(const nm_enc_word *enc, uint64_t p, uint32_t kmax);
+
+// forward-strand occurrences inside the interval [lo, hi) (both strands: its size)
+template <bool RC>
+NM_HD uint64_t nm_interval_count(const nm_view &ix, uint64_t lo, uint64_t hi) {
+    if (hi <= lo) return 0;
+    if (RC) return hi - lo;
+    return nm_strand_rank(ix, hi) - nm_strand_rank(ix, lo);
+}
+
+// ---- the exact zero-count guard (newmap/search.py:699-722) for a record that is NOT one of the indexed records -------
+// The reference raises when ANY k-mer its schedule asks the index about has a total of zero.  For a record whose
+// fingerprint is in the index (nm_hash.h) that cannot happen and the fast paths run unchecked; every other record goes
+// through these per-position functions after its search: they replay the reference's probe schedule for the position --
+// the bisection of binary_search (search.py:424-433, 464-544) is a function of the least unique length alone -- and
+// walk the LONGEST probed k-mer base by base: a prefix of a present string is present, so the reference raises for this
+// position if and only if that walk runs empty.  ~100 LF steps per position instead of ~0.01: the price of a FASTA
+// that is not the indexed genome, paid only then.
+
+// the longest length the reference's bisection probes for a position with upper bound U and least unique length L
+// (0 = no unique length up to U); initial_len = --initial-search-length (0 = none)
+NM_HD uint32_t nm_ref_longest_probe(uint32_t kmin, uint32_t U, uint32_t L, uint32_t initial_len) {
+    uint32_t lower = kmin, upper = U, q = (upper + lower) >> 1;          // :424-426
+    if (initial_len && q > initial_len) q = initial_len;                  // :429-433
+    uint32_t longest = 0;
+    for (uint32_t it = 0; it < 64; it++) {
+        if (q > longest) longest = q;
+        if (L && q >= L) {                                                // total == 1
+            if (q == lower || q == 0) break;                              // :504-508
+            upper = q - 1;                                                // :524-527
+        } else {                                                          // total > 1
+            if (q == upper) break;                                        // :513-517
+            lower = q + 1;                                                // :532-535
+        }
+        if (upper < lower && !(L && q >= L)) break;                       // (cannot happen for kmin <= U; keeps the loop finite)
+        q = (upper + lower) >> 1;                                         // :540-542
+    }
+    return longest;
+}
+
+// range mode: would the reference raise for position p?  (U_p < kmin and ambiguous positions are never probed, :437)
+template <bool BIG, bool RC>
+NM_HD bool nm_guard_range_one(const nm_view &ix, const nm_enc_word *enc, uint64_t p, uint32_t kmin, uint32_t kmax,
+                              uint32_t initial_len, nm_tally &t) {
+    nm_window w = nm_load_window(enc, p);
+    if (w.amb & 1ULL) return false;
+    const uint32_t U = nm_upper_one(enc, p, kmax);
+    if (U < kmin) return false;
+    uint64_t lo = 0, hi = ix.n;
+    uint32_t k = 0, kbase = 0, L = 0;
+    while (k < U) {                                                       // least k with a total of one; an empty interval on the way: absent
+        uint32_t j = k - kbase;
+        if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+        t.steps++;
+        nm_lf_interval<BIG>(ix, 3u - nm_window_code(w, j), lo, hi);
+        k++;
+        const uint64_t c = nm_interval_count<RC>(ix, lo, hi);
+        if (c == 0) return true;                                          // S[p .. p+k) is absent and k <= U: the bisection climbs to a probe >= k
+        if (c == 1) { L = k; break; }
+    }
+    const uint32_t longest = nm_ref_longest_probe(kmin, U, L, initial_len);
+    while (k < longest) {                                                 // (longest <= U: the window stays unambiguous)
+        uint32_t j = k - kbase;
+        if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+        t.steps++;
+        nm_lf_interval<BIG>(ix, 3u - nm_window_code(w, j), lo, hi);
+        k++;
+        if (nm_interval_count<RC>(ix, lo, hi) == 0) return true;
+    }
+    return false;
+}
+
+// list mode (search.py:551-644): every listed length is asked in turn until one has a total of one (:639) or the k-mer
+// holds an ambiguous byte (:593-596, dropped for good); k-mers are cut at the end of the data (:590)
+template <bool BIG, bool RC>
+NM_HD bool nm_guard_list_one(const nm_view &ix, const nm_enc_word *enc, uint64_t p, uint64_t seq_len, const uint32_t *ks, uint32_t nk,
+                             nm_tally &t) {
+    nm_window w = nm_load_window(enc, p);
+    if (w.amb & 1ULL) return false;
+    const uint64_t rem = seq_len - p;
+    uint64_t lo = 0, hi = ix.n;
+    uint32_t k = 0, kbase = 0, checked = 1;
+    for (uint32_t q = 0; q < nk; q++) {
+        const uint32_t K = ks[q];
+        const uint32_t L = (uint64_t)K < rem ? K : (uint32_t)rem;
+        if (L > checked) {
+            nm_window w2 = w;
+            uint32_t kb2 = kbase;
+            if (!nm_all_valid(enc, p, w2, kb2, checked, L)) return false;
+            checked = L;
+        }
+        if (L < k) { lo = 0; hi = ix.n; k = 0; }
+        while (k < L) {
+            uint32_t j = k - kbase;
+            if (j >= 64 || k < kbase) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+            t.steps++;
+            nm_lf_interval<BIG>(ix, 3u - nm_window_code(w, j), lo, hi);
+            k++;
+            if (hi <= lo) return true;
+        }
+        const uint64_t c = nm_interval_count<RC>(ix, lo, hi);
+        if (c == 0) return true;
+        if (c == 1) return false;                                         // finished: nothing longer is asked
+    }
+    return false;
 }
 
 // per-position inclusive upper search length (ambiguous positions keep kmax)

@@ -31,6 +31,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include <fcntl.h>
@@ -41,6 +42,7 @@
 
 #include "../../include/newmap_amd.h"
 #include "nm_fasta_scan.hpp"
+#include "nm_hash.h"
 #include "nm_internal.h"
 
 #define HIP_TRY(expr)                                                                         \
@@ -68,6 +70,7 @@ struct Slot {                                 // one segment in flight
     uint64_t seg_len = 0, num_kmers = 0;
     uint64_t rec_index = 0;                   // which output file
     uint64_t rec_offset = 0;                  // first position of the segment inside its record
+    int64_t rec_ordinal = -1;                 // which record (fingerprints)
 };
 
 struct Driver {
@@ -87,7 +90,7 @@ struct Driver {
     int next_slot = 0;
     // current record
     std::string cur_id;
-    bool have_record = false, record_wanted = false, any_processed = false;
+    bool have_record = false, record_wanted = false, any_processed = false, new_record = false;
     std::vector<uint8_t> buf;                 // record bytes not yet handed to the device
     uint64_t buf_offset = 0;                  // position of buf[0] in the record
     FILE *cur_file = nullptr;
@@ -97,6 +100,14 @@ struct Driver {
     std::vector<nm_search_summary> pending_sums;   // per file serial
     std::vector<std::string> pending_ids;
     std::vector<int> outstanding;             // segments in flight per file serial
+    // record fingerprints (nm_hash.h): ordinal = number of the record among the records with data, in file order
+    int64_t rec_ordinal = -1;
+    std::vector<uint64_t> rec_hash, rec_len;  // per ordinal: sum of the segments' fingerprints, bases
+    std::vector<uint8_t> rec_searched;        // per ordinal: the record was searched (wanted)
+    // guard pass (records that are not among the indexed ones): no files, nm_guard_segment_dev instead of the search
+    bool guard_mode = false;
+    const std::vector<uint8_t> *guard_set = nullptr;   // per ordinal: 1 = guard this record
+    uint32_t initial_len = 0;
 
     static void reset(nm_search_summary &s, uint32_t kmin, uint32_t kmax) {
         memset(&s, 0, sizeof s);
@@ -149,8 +160,13 @@ int drain_slot(Driver &d, Slot &s) {
         const uint64_t len = s.seg_len - at < d.kmin ? s.seg_len - at : d.kmin;
         nm_set_error("The following generated k-mer was not found in the index:\n%.*s\nPossibly a mismatch between the sequence "
                      "and the index. (record '%s', position %llu)", (int)len, (const char *)s.h_in + at,      // newmap/search.py:719-722
-                     d.pending_ids[serial].c_str(), (unsigned long long)(s.rec_offset + at));
+                     d.guard_mode ? d.cur_id.c_str() : d.pending_ids[serial].c_str(), (unsigned long long)(s.rec_offset + at));
         return NM_E_KMER_NOT_FOUND;
+    }
+    if (d.guard_mode) return NM_OK;
+    if (s.rec_ordinal >= 0) {                              // (a segment that does not start at a word of its record cannot be joined)
+        if (s.rec_offset & 63u) d.rec_searched[(size_t)s.rec_ordinal] = 2;
+        d.rec_hash[(size_t)s.rec_ordinal] += nm_hash_pow(s.rec_offset >> 6) * s.h_status[NM_STATUS_HASH];
     }
     FILE *fp = d.open_files[serial];
     const uint64_t bytes = s.num_kmers * (uint64_t)d.elem_bytes;
@@ -201,9 +217,20 @@ int submit(Driver &d, uint64_t seg_len, uint64_t num_kmers) {
     memcpy(s.h_in, d.buf.data(), seg_len);
     s.seg_len = seg_len;
     s.num_kmers = num_kmers;
-    s.rec_index = d.file_serial - 1;
+    s.rec_index = d.guard_mode ? 0 : d.file_serial - 1;
     s.rec_offset = d.buf_offset;
+    s.rec_ordinal = d.rec_ordinal;
     HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, seg_len, hipMemcpyHostToDevice, d.stream));
+    if (d.guard_mode) {
+        const uint32_t two[2] = {d.kmin, d.kmax};
+        rc = nm_guard_segment_dev(d.ix, s.d_in, seg_len, num_kmers, d.range_mode ? two : d.ks.data(), d.range_mode ? 2u : (uint32_t)d.ks.size(),
+                                  d.range_mode, d.initial_len, d.use_rc, s.d_status, d.stream);
+        if (rc != NM_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_status, s.d_status, NM_STATUS_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipEventRecord(s.done, d.stream));
+        s.busy = true;
+        return NM_OK;
+    }
     if (d.range_mode)
         rc = nm_min_unique_segment_dev(d.ix, s.d_in, seg_len, num_kmers, d.kmin, d.kmax, d.use_rc, d.elem_bytes, s.d_out, s.d_status, d.stream);
     else
@@ -243,6 +270,7 @@ int end_record(Driver &d) {
 
 // a record's first data byte arrived (newmap/search.py:268-305)
 int begin_output(Driver &d) {
+    if (d.guard_mode) return NM_OK;
     if (d.cur_file && d.pending_ids.back() == d.cur_id) return NM_OK;   // same id as the previous record: keep appending
     const std::string path = d.out_dir + "/" + d.cur_id + ".unique." + d.suffix;
     FILE *fp = fopen(path.c_str(), "wb");                 // truncate on a new id (:304-305)
@@ -273,7 +301,15 @@ int on_data(Driver &d, const unsigned char *p, size_t len) {
         d.cur_id.clear();
         d.record_wanted = wanted(d, d.cur_id);
         d.buf_offset = 0;
+        d.new_record = true;
     }
+    if (d.new_record) {                                   // the record's first data byte: it counts (records without data do not)
+        d.new_record = false;
+        d.rec_ordinal++;
+        if (!d.guard_mode) { d.rec_hash.push_back(0); d.rec_len.push_back(0); d.rec_searched.push_back(d.record_wanted ? 1 : 0); }
+        else d.record_wanted = d.record_wanted && (size_t)d.rec_ordinal < d.guard_set->size() && (*d.guard_set)[(size_t)d.rec_ordinal];
+    }
+    if (!d.guard_mode) d.rec_len[(size_t)d.rec_ordinal] += len;
     if (!d.record_wanted) return NM_OK;
     if (d.buf.empty() && d.buf_offset == 0) {
         int rc = begin_output(d);
@@ -293,6 +329,7 @@ int on_header(Driver &d, const unsigned char *p, size_t len) {
     d.have_record = true;
     d.record_wanted = wanted(d, d.cur_id);
     d.buf_offset = 0;
+    d.new_record = true;
     return NM_OK;
 }
 
@@ -408,6 +445,8 @@ struct FastDriver {
     std::atomic<int> error{NM_OK};
     std::string error_text;
     std::mutex sum_mu;
+    std::vector<uint64_t> rec_hash;       // per record of `recs`: sum of its segments' fingerprints (nm_hash.h), under sum_mu
+    std::vector<uint8_t> rec_unaligned;   // ... a segment of it did not start at a multiple of 64: the sum means nothing
 
     void fail(int code, const std::string &text) {
         int expect = NM_OK;
@@ -448,6 +487,8 @@ void fast_writer(FastDriver *d) {
                     done += (uint64_t)w;
                 }
                 std::lock_guard<std::mutex> g(d->sum_mu);
+                d->rec_hash[(size_t)s.rec] += nm_hash_pow(s.rec_start >> 6) * s.h_status[NM_STATUS_HASH];
+                if (s.rec_start & 63u) d->rec_unaligned[(size_t)s.rec] = 1;   // (cannot be joined: the record goes to the guard)
                 nm_search_summary &rs = f.sum;                 // newmap/search.py:331-347
                 const uint64_t uniq = s.h_sum[0];
                 rs.positions += s.count;
@@ -470,9 +511,12 @@ void fast_writer(FastDriver *d) {
 }
 
 // returns NM_OK, an error, or -1 when this front-end does not apply (gzip input, a file that cannot be mapped)
+// rec_info (may be null): per record WITH data, in file order, {length, fingerprint summed over THIS rank's units, 1 if the
+// record was searched}; *n_rec_info = their number (filled up to rec_cap records)
 int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks, uint32_t nk, int range_mode,
              int use_revcomp, uint64_t batch, const std::vector<std::string> &include, const std::vector<std::string> &exclude,
-             nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world) {
+             nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world,
+             std::vector<uint64_t> *rec_info) {
     const int fd = open(fasta_path, O_RDONLY);
     if (fd < 0) { nm_set_error("could not open %s: %s", fasta_path, strerror(errno)); return NM_E_FILE_OPEN; }
     struct stat st;
@@ -505,6 +549,8 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
 
     // ---- records, their pieces, the bases in front of each piece (nm_fasta_scan.hpp; threaded)
     d.recs = nm_fasta::scan(base, size, threads);
+    d.rec_hash.assign(d.recs.size(), 0);
+    d.rec_unaligned.assign(d.recs.size(), 0);
     // ---- output files: one per run of adjacent records (that hold data and are wanted) with one id; an id that
     // comes back later truncates the file again (newmap/search.py:268-305), so only its LAST run is searched
     auto wanted = [&](const std::string &id) {
@@ -517,7 +563,8 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         std::string cur_id;
         for (FastRecord &rec : d.recs) {
             if (rec.n_bases == 0) continue;                     // a record without data yields nothing (newmap/fasta.py:173-188)
-            if (!wanted(rec.id)) { cur = -1; continue; }
+            if (!wanted(rec.id)) continue;                      // (a skipped record does not end the current run: newmap/search.py:268-305
+                                                                //  never updates its current id on one; same as the streaming front-end)
             if (cur < 0 || rec.id != cur_id) {
                 d.files.emplace_back();
                 cur = (int)d.files.size() - 1;
@@ -532,9 +579,11 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
             rec.file_offset = d.files[cur].n_elems;
             d.files[cur].n_elems += rec.n_bases;
         }
-        for (size_t a = 0; a < d.files.size(); a++)
-            for (size_t b = a + 1; b < d.files.size(); b++)
-                if (d.files[b].id == d.files[a].id) { d.files[a].n_elems = 0; break; }     // superseded by a later run
+        {   // a run whose id comes back in a later run is superseded (one pass over the ids)
+            std::unordered_map<std::string, size_t> last_run;
+            for (size_t a = 0; a < d.files.size(); a++) last_run[d.files[a].id] = a;
+            for (size_t a = 0; a < d.files.size(); a++) if (last_run[d.files[a].id] != a) d.files[a].n_elems = 0;
+        }
         for (FastRecord &rec : d.recs) if (rec.file >= 0 && d.files[rec.file].n_elems == 0) rec.file = -1;
         for (size_t r = 0; r < d.recs.size(); r++) if (d.recs[r].file >= 0) d.files[d.recs[r].file].last_record = (int)r;
     }
@@ -638,7 +687,10 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         for (auto &rg : ranges) {
             const uint64_t lo = rg.first > rec.global ? rg.first : rec.global;
             const uint64_t hi = rg.second < rec.global + rec.n_bases ? rg.second : rec.global + rec.n_bases;
-            if (hi > lo) mine.push_back({lo - rec.global, hi - rec.global});
+            // (a part starts and ends at a multiple of 64 bases of its record -- or at the record's end --, so that the segments'
+            // fingerprints can be joined (nm_hash.h); every rank rounds a shared boundary the same way)
+            auto word_edge = [&](uint64_t x) { return x == rec.n_bases ? x : x & ~63ull; };
+            if (hi > lo && word_edge(hi - rec.global) > word_edge(lo - rec.global)) mine.push_back({word_edge(lo - rec.global), word_edge(hi - rec.global)});
         }
         for (auto &part : mine) {
             // strip the pieces that hold [part.first, part.second + lookahead) into rec_buf
@@ -733,6 +785,15 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         fprintf(stderr, "[driver] total %.3fs: strip %.3f, copy to pinned %.3f, wait for a slot %.3f, submit %.3f (main thread)\n",
                 now() - t_begin, t_strip, t_copy, t_slot, t_submit);
     if (rc != NM_OK) return rc;
+    if (rec_info) {
+        rec_info->clear();
+        for (size_t ri = 0; ri < d.recs.size(); ri++) {
+            if (d.recs[ri].n_bases == 0) continue;
+            rec_info->push_back(d.recs[ri].n_bases);
+            rec_info->push_back(d.rec_hash[ri]);
+            rec_info->push_back(d.recs[ri].file >= 0 ? (d.rec_unaligned[ri] ? 2 : 1) : 0);
+        }
+    }
     report_ready();
     // ---- summaries in file order (this rank's share when world > 1), then the totals
     nm_search_summary tot;
@@ -761,11 +822,61 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
 
 }  // namespace
 
+// The exact guard over the records flagged in `flags` (per record with data, in file order): the streaming reader with
+// nm_guard_segment_dev in the place of the search, nothing written.  NM_E_KMER_NOT_FOUND with the reference's message
+// when one of its probes is absent (newmap/search.py:699-722).
+static int guard_pass(nm_index *ix, const char *fasta_path, const uint32_t *ks, uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
+                      const std::vector<std::string> &include, const std::vector<std::string> &exclude, const std::vector<uint8_t> &flags) {
+    Driver d;
+    d.ix = ix;
+    d.device = (int)nm_index_info(ix, 10);
+    d.ks.assign(ks, ks + nk);
+    d.range_mode = range_mode != 0;
+    d.use_rc = use_revcomp != 0;
+    d.kmin = d.kmax = ks[0];
+    for (uint32_t i = 1; i < nk; i++) { if (ks[i] < d.kmin) d.kmin = ks[i]; if (ks[i] > d.kmax) d.kmax = ks[i]; }
+    d.elem_bytes = 1;
+    d.batch = batch;
+    d.lookahead = d.kmax - 1;
+    d.include = include;
+    d.exclude = exclude;
+    d.cb = nullptr;
+    d.user = nullptr;
+    d.guard_mode = true;
+    d.guard_set = &flags;
+    d.initial_len = (uint32_t)nm_index_info(ix, 22);
+    Driver::reset(d.total, d.kmin, d.kmax);
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(hipStreamCreate(&d.stream));
+    int rc = NM_OK;
+    for (auto &s : d.slots)
+        if ((rc = alloc_slot(d, s)) != NM_OK) break;
+    if (rc == NM_OK) rc = run(d, fasta_path);
+    for (int i = 0; i < 2; i++) {
+        Slot &s = d.slots[d.next_slot ^ i];
+        if (rc == NM_OK) rc = drain_slot(d, s);
+        else if (s.busy) (void)hipEventSynchronize(s.done);
+    }
+    for (auto &s : d.slots) free_slot(s);
+    (void)hipStreamDestroy(d.stream);
+    return rc;
+}
+
+// which of the searched records are NOT among the indexed ones (info = {length, fingerprint, searched} per record)
+static bool unverified_records(const nm_index *ix, const std::vector<uint64_t> &info, std::vector<uint8_t> &flags) {
+    bool any = false;
+    flags.assign(info.size() / 3, 0);
+    for (size_t i = 0; i + 2 < info.size(); i += 3)
+        if (info[i + 2] && (info[i + 2] == 2 || !nm_index_has_record(ix, info[i], info[i + 1]))) { flags[i / 3] = 1; any = true; }   // (2: not joinable)
+    return any;
+}
+
 static int search_fasta_impl(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks,
                              uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
                              const char *const *include_ids, uint32_t n_include,
                              const char *const *exclude_ids, uint32_t n_exclude,
-                             nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world) {
+                             nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world,
+                             std::vector<uint64_t> *rec_info_out = nullptr) {
     if (!ix || !fasta_path || !out_dir || !ks || nk == 0) { nm_set_error("null argument"); return NM_E_ARGUMENT; }
     if (batch == 0) { nm_set_error("batch must be positive"); return NM_E_ARGUMENT; }
     if (world < 1 || rank < 0 || rank >= world) { nm_set_error("rank %d of %d", rank, world); return NM_E_ARGUMENT; }
@@ -778,7 +889,15 @@ static int search_fasta_impl(nm_index *ix, const char *fasta_path, const char *o
     for (uint32_t i = 0; i < n_exclude; i++) exclude.emplace_back(exclude_ids[i]);
     const char *stream_only = getenv("NEWMAP_AMD_STREAMING_DRIVER");
     if (!(stream_only && stream_only[0] == '1')) {
-        const int rc = fast_run(ix, fasta_path, out_dir, ks, nk, range_mode, use_revcomp, batch, include, exclude, cb, user, total, rank, world);
+        std::vector<uint64_t> info;
+        int rc = fast_run(ix, fasta_path, out_dir, ks, nk, range_mode, use_revcomp, batch, include, exclude, cb, user, total, rank, world, &info);
+        if (rc == NM_OK && world == 1) {
+            // a record that is one of the indexed records holds no absent k-mer; every other one is searched again by the
+            // exact guard (nm_hash.h).  With several ranks the caller joins the ranks' shares first (newmap_amd/parallel.py).
+            std::vector<uint8_t> flags;
+            if (unverified_records(ix, info, flags)) rc = guard_pass(ix, fasta_path, ks, nk, range_mode, use_revcomp, batch, include, exclude, flags);
+        }
+        if (rec_info_out) *rec_info_out = info;
         if (rc != -1) return rc;
     }
     if (world > 1) {
@@ -832,6 +951,13 @@ static int search_fasta_impl(nm_index *ix, const char *fasta_path, const char *o
             if (cb) cb(d.pending_ids[i].c_str(), &rs, user);
         }
         if (total) *total = d.total;
+        {   // (streaming front-end: the same record check)
+            std::vector<uint64_t> info;
+            for (size_t o = 0; o < d.rec_hash.size(); o++) { info.push_back(d.rec_len[o]); info.push_back(d.rec_hash[o]); info.push_back(d.rec_searched[o]); }
+            std::vector<uint8_t> flags;
+            if (unverified_records(ix, info, flags)) rc = guard_pass(ix, fasta_path, ks, nk, range_mode, use_revcomp, batch, include, exclude, flags);
+            if (rec_info_out) *rec_info_out = info;
+        }
         if (!d.any_processed) {
             nm_set_error(d.include.empty() ? "The excluded sequences were too strict and nothing was processed"
                                            : "None of the included sequences were found");
@@ -859,4 +985,34 @@ extern "C" int nm_search_fasta_shard(nm_index *ix, const char *fasta_path, const
                                      nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world) {
     return search_fasta_impl(ix, fasta_path, out_dir, ks, nk, range_mode, use_revcomp, batch, include_ids, n_include, exclude_ids, n_exclude,
                              cb, user, total, rank, world);
+}
+
+// the sharded search with the record fingerprints handed back: rec_info[3 i + 0 .. 2] = {length, fingerprint summed over THIS
+// rank's units, searched} of record i (records with data, in file order), *n_records = their number (rec_info holds up to
+// `capacity` records).  The caller adds the ranks' fingerprints (mod 2^64), asks nm_index_has_record and runs nm_guard_fasta
+// over the records that are not indexed.
+extern "C" int nm_search_fasta_shard_ex(nm_index *ix, const char *fasta_path, const char *out_dir, const uint32_t *ks,
+                                        uint32_t nk, int range_mode, int use_revcomp, uint64_t batch,
+                                        const char *const *include_ids, uint32_t n_include,
+                                        const char *const *exclude_ids, uint32_t n_exclude,
+                                        nm_record_callback cb, void *user, nm_search_summary *total, int rank, int world,
+                                        uint64_t *rec_info, uint64_t capacity, uint64_t *n_records) {
+    std::vector<uint64_t> info;
+    const int rc = search_fasta_impl(ix, fasta_path, out_dir, ks, nk, range_mode, use_revcomp, batch, include_ids, n_include, exclude_ids, n_exclude,
+                                     cb, user, total, rank, world, &info);
+    if (n_records) *n_records = info.size() / 3;
+    if (rec_info) for (size_t i = 0; i < info.size() && i < 3 * capacity; i++) rec_info[i] = info[i];
+    return rc;
+}
+
+// the exact guard over the records with flags[i] != 0 (records with data, in file order; nm_guard_segment_dev per segment)
+extern "C" int nm_guard_fasta(nm_index *ix, const char *fasta_path, const uint32_t *ks, uint32_t nk, int range_mode, int use_revcomp,
+                              uint64_t batch, const char *const *include_ids, uint32_t n_include, const char *const *exclude_ids,
+                              uint32_t n_exclude, const uint8_t *flags, uint64_t n_flags) {
+    if (!ix || !fasta_path || !ks || nk == 0 || (!flags && n_flags)) { nm_set_error("null argument"); return NM_E_ARGUMENT; }
+    if (batch == 0) { nm_set_error("batch must be positive"); return NM_E_ARGUMENT; }
+    std::vector<std::string> include, exclude;
+    for (uint32_t i = 0; i < n_include; i++) include.emplace_back(include_ids[i]);
+    for (uint32_t i = 0; i < n_exclude; i++) exclude.emplace_back(exclude_ids[i]);
+    return guard_pass(ix, fasta_path, ks, nk, range_mode, use_revcomp, batch, include, exclude, std::vector<uint8_t>(flags, flags + n_flags));
 }

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -30,7 +31,9 @@
 #include "nm_format.h"
 #include "nm_internal.h"
 
+extern "C" int nm_index_has_record(const nm_index *ix, uint64_t length, uint64_t hash);
 #define NM_HD __device__ __forceinline__
+#define NM_HASH_FN __host__ __device__ __forceinline__      /* the fingerprint helpers also run on the host (tables, joins) */
 struct nm_view;
 static __device__ __forceinline__ uint64_t nm_seed_load_policy(const nm_view &ix, uint64_t slot);
 #define NM_SEED_LOAD(ix, slot) nm_seed_load_policy((ix), (slot))
@@ -76,7 +79,16 @@ static __device__ __forceinline__ nm_u64x2 nm_quad_load16(uint64_t addr) {
 }
 struct nm_quad_inflight { nm_u64x2 va, vb; };
 // first half of a lookup: trade addresses, issue both loads (nothing waits here: a lane keeps several lookups in flight)
+#ifndef NM_QUAD_PAIRED
+#define NM_QUAD_PAIRED 1            /* -DNM_QUAD_PAIRED=0 (measurement builds): every lane reads both halves of its own entry */
+#endif
 static __device__ __forceinline__ nm_quad_inflight nm_quad_issue_paired(const uint64_t *entry, bool go, const uint32_t b[4]) {
+#if !NM_QUAD_PAIRED
+    nm_quad_inflight g;
+    g.va = nm_u64x2{0, 0}; g.vb = nm_u64x2{0, 0};
+    if (go) { g.va = nm_quad_load16((uint64_t)nm_quad_pair01(entry, b)); g.vb = nm_quad_load16((uint64_t)nm_quad_pair34(entry, b)); }
+    return g;
+#endif
     const bool even = (threadIdx.x & 1u) == 0;
     const uint64_t p01 = go ? (uint64_t)nm_quad_pair01(entry, b) : 0ULL, p34 = go ? (uint64_t)nm_quad_pair34(entry, b) : 0ULL;
     const uint64_t keep = even ? p01 : p34;                            // the half I load myself ...
@@ -91,6 +103,10 @@ static __device__ __forceinline__ nm_quad_inflight nm_quad_issue_paired(const ui
 // second half: the foreign words travel back.  e[0], e[1] = the pair at nm_quad_pair01(entry, b), e[2], e[3] = the pair at
 // nm_quad_pair34(entry, b); zeros without an entry
 static __device__ __forceinline__ void nm_quad_finish_paired(const nm_quad_inflight &f, uint64_t e[4]) {
+#if !NM_QUAD_PAIRED
+    e[0] = f.va.x; e[1] = f.va.y; e[2] = f.vb.x; e[3] = f.vb.y;
+    return;
+#endif
     const bool even = (threadIdx.x & 1u) == 0;
     const nm_u64x2 mine = even ? f.va : f.vb, foreign = even ? f.vb : f.va;
     const uint64_t f0 = nm_swap1_64(foreign.x), f1 = nm_swap1_64(foreign.y);   // my other half, loaded next door
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
                                                          uint64_t num_kmers, uint32_t kmin, uint32_t kmax, uint32_t d, void *__restrict__ out,
                                                          int elem_bytes, uint64_t *__restrict__ status, uint64_t *__restrict__ need,
                                                          unsigned long long *__restrict__ work,
-                                                         const uint32_t *__restrict__ list, uint32_t n_list) {
+                                                         const uint32_t *__restrict__ list, uint32_t n_list, int hash_on) {
     extern __shared__ uint64_t s_mem[];
     __shared__ uint32_t s_open_total, s_qn;
     __shared__ uint32_t s_q[NM_SITE_CHANCE_MAX];
@@ -420,6 +436,13 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
     for (uint32_t i = tid; i < BP / 16; i += NM_SITE_BLOCK) s_set[i] = 0;          // both bitmaps
     if (tid == 0) { s_open_total = 0; s_qn = 0; }
     __syncthreads();
+    // the fingerprint of the block's own positions (nm_hash.h; status[NM_STATUS_HASH] of the segment sums all blocks)
+    if (hash_on) {
+        uint64_t term = 0;
+        for (uint32_t i = tid; i < BP / 64; i += NM_SITE_BLOCK) term += nm_hash_segment_word(ix.hash_tab, s_enc[i], w0 + i, num_kmers);
+        for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, NM_WAVE);
+        if ((tid & 63) == 0 && term) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)term);
+    }
     // the block's own words go to the segment's encoded array; the last block also writes what follows its stretch
     // (lookahead and padding words of the segment)
     if (enc_out) {
@@ -731,6 +754,21 @@ __global__ __launch_bounds__(NM_BLOCK) void k_count(nm_view ix, const uint8_t *_
     out[q] = nm_count_fwd_one<BIG>(ix, seq + starts[q], lens[q], t);
 }
 
+// the exact zero-count guard, one lane per position (nm_core.h: nm_guard_range_one / nm_guard_list_one); nk == 0: range mode
+template <bool BIG, bool RC>
+__global__ __launch_bounds__(NM_BLOCK) void k_guard(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t seq_len, uint64_t num_kmers,
+                                                    uint32_t kmin, uint32_t kmax, uint32_t initial_len, const uint32_t *__restrict__ ks,
+                                                    uint32_t nk, uint64_t *__restrict__ status) {
+    const uint64_t p = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    nm_tally t = {0, 0, 0, 0};
+    const bool bad = p < num_kmers && (nk ? nm_guard_list_one<BIG, RC>(ix, enc, p, seq_len, ks, nk, t)
+                                          : nm_guard_range_one<BIG, RC>(ix, enc, p, kmin, kmax, initial_len, t));
+    if (__ballot(bad)) {
+        if (bad) atomicMin((unsigned long long *)&status[2], (unsigned long long)p);
+        if ((threadIdx.x & 63) == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
+    }
+}
+
 __global__ __launch_bounds__(NM_BLOCK) void k_upper(const nm_enc_word *__restrict__ enc, uint64_t num_kmers,
                                                     uint32_t kmax, uint32_t *__restrict__ out) {
     const uint64_t p = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
@@ -752,6 +790,16 @@ __global__ __launch_bounds__(NM_BLOCK) void k_multi(nm_multi_args a, uint64_t se
         nm_store(out, elem_bytes, p, r);
     }
     nm_epilogue<false>(inb, amb0, err, p, t, status);
+}
+
+// fingerprint of the positions [0, end) of a segment from its encoded words (the paths that do not run k_sites, or run it
+// over a part of the positions only: list mode); status[NM_STATUS_HASH] += the sum of the words' terms
+__global__ __launch_bounds__(NM_BLOCK) void k_segment_hash(const uint64_t *__restrict__ tab, const nm_enc_word *__restrict__ enc, uint64_t end,
+                                                           uint64_t *__restrict__ status) {
+    const uint64_t w = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    uint64_t term = w * 64 < end ? nm_hash_segment_word(tab, enc[w], w, end) : 0ULL;
+    for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, NM_WAVE);
+    if ((threadIdx.x & 63) == 0 && term) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)term);
 }
 
 __global__ void k_reset_status(uint64_t *__restrict__ status, unsigned long long *__restrict__ work) {
@@ -801,6 +849,8 @@ struct nm_index {
     void *d_quad_small = nullptr;         // a second one with shorter cores: larger groups per line on small genomes
     uint32_t quad_small_m = 0;
     void *d_lfb = nullptr;                // LF blocks
+    void *d_hash_tab = nullptr;           // tables of the record fingerprint (nm_hash.h)
+    std::vector<nm_record_entry> records; // (length, fingerprint) of the indexed records, sorted
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     // Launch scratch comes in LANES, one per stream the caller launches on: segments given on different streams have
@@ -829,6 +879,10 @@ struct nm_index {
     uint32_t site_d_cap = NM_SITE_MAX_D;  // measurement knob (NEWMAP_AMD_SITE_D): cap on d = kmin - window of the sites
     bool count_steps = false;
     int last_kernel = 0;                  // which range kernel the last launch used (nm_index_info 8)
+    uint64_t guard_segments = 0;          // segments that went through the exact guard (nm_index_info 23; tests)
+    bool segment_guard = true;            // NM_OPT_SEGMENT_GUARD: the host-buffer segment calls run the exact guard themselves
+    uint32_t initial_len = 0;             // --initial-search-length (NM_OPT_INITIAL_LENGTH): shapes the reference's probe schedule, hence the guard
+    uint64_t last_fingerprint = 0;        // status[NM_STATUS_HASH] of the last host-buffer segment call (nm_index_info 21)
     // NM_OPT_TIMING: HIP events on the launch stream, NM_TIMING_KINDS kinds of start/stop pairs:
     // kind 0 around the dominant search kernel of a segment (k_sites / k_min_unique / k_fixed_k), kind 1 around ALL the
     // kernels of the segment (encode pass, sites, probes, resolve), kinds 2 / 3 / 4 around the coarse probes, the fine
@@ -1155,6 +1209,23 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
         nm_set_error("could not upload the superblock table");
         return fail(NM_E_DEVICE);
     }
+    {   // the record list (format 2) and the fingerprint tables
+        ix->records.resize(h.n_records);
+        if (h.n_records && (fseeko(fp, (off_t)h.off_records, SEEK_SET) != 0 ||
+                            fread(ix->records.data(), sizeof(nm_record_entry), h.n_records, fp) != h.n_records)) {
+            nm_set_error("%s is truncated (record list)", index_path);
+            return fail(NM_E_FILE_FORMAT);
+        }
+        std::sort(ix->records.begin(), ix->records.end(), [](const nm_record_entry &a, const nm_record_entry &b) {
+            return a.length != b.length ? a.length < b.length : a.hash < b.hash; });
+        std::vector<uint64_t> tab(NM_HASH_TAB_WORDS);
+        nm_hash_fill_tables(tab.data());
+        if (hipMalloc(&ix->d_hash_tab, tab.size() * sizeof(uint64_t)) != hipSuccess ||
+            hipMemcpy(ix->d_hash_tab, tab.data(), tab.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
+            nm_set_error("could not upload the fingerprint tables");
+            return fail(NM_E_DEVICE);
+        }
+    }
     fclose(fp);
     fp = nullptr;
     NM_PHASE(t_open, "device init + index file read + upload");
@@ -1176,6 +1247,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.quad_m = 0;
     v.quad2 = nullptr;
     v.quad2_m = 0;
+    v.hash_tab = (const uint64_t *)ix->d_hash_tab;
 
     if (seed_len_override < -1 && h.n >= 2) {
         const char *off = getenv("NEWMAP_AMD_LF_BLOCKS");
@@ -1260,7 +1332,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     (void)hipDeviceSynchronize();                              // launches on caller streams and side streams included
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->d_hash_tab, ix->seq.p,
                     ix->out.p, ix->status.p, ix->starts.p, ix->lens.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1298,6 +1370,9 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 18: return ix->view.quad_m;
         case 19: return ix->quad_small_m;
         case 20: return ix->last_site_m;
+        case 21: return ix->last_fingerprint;
+        case 22: return ix->initial_len;
+        case 23: return ix->guard_segments;
         case 14: case 15: case 16: case 17: {              // probe tally of the last range-mode launch
             unsigned long long v = 0;
             if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
@@ -1341,6 +1416,12 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
     if (option == NM_OPT_SITE_TABLE) {
         if (value < 0 || value > 2) { nm_set_error("site table must be 0 (pick per launch), 1 (long cores) or 2 (short cores)"); return NM_E_ARGUMENT; }
         ix->site_table = (int)value;
+        return NM_OK;
+    }
+    if (option == NM_OPT_SEGMENT_GUARD) { ix->segment_guard = value != 0; return NM_OK; }
+    if (option == NM_OPT_INITIAL_LENGTH) {
+        if (value < 0 || value > 0xFFFFFFFFLL) { nm_set_error("initial search length out of range"); return NM_E_ARGUMENT; }
+        ix->initial_len = (uint32_t)value;
         return NM_OK;
     }
     if (option == NM_OPT_KERNEL) {
@@ -1399,6 +1480,15 @@ static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStrea
     else
         hipLaunchKernelGGL(k_encode, dim3(nm_grid(n_words * 64)), dim3(NM_BLOCK), 0, st, (const uint8_t *)d_seq, seq_len,
                            (nm_enc_word *)ix->cur->enc.p, n_words, d_status, work);
+    HIP_TRY(hipGetLastError());
+    return NM_OK;
+}
+
+// status[NM_STATUS_HASH] += fingerprint of positions [0, end) of the segment whose encoded words the lane holds
+static int nm_hash_positions(nm_index *ix, uint64_t end, uint64_t *d_status, hipStream_t st) {
+    if (end == 0) return NM_OK;
+    hipLaunchKernelGGL(k_segment_hash, dim3(nm_grid((end + 63) >> 6)), dim3(NM_BLOCK), 0, st, (const uint64_t *)ix->d_hash_tab,
+                       (const nm_enc_word *)ix->cur->enc.p, end, d_status);
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }
@@ -1502,7 +1592,7 @@ static void nm_pick_site_tables(nm_index *ix, nm_view &view, uint32_t kmin) {
 template <bool BIG>
 static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq, uint64_t seq_len, uint64_t n, uint32_t kmin, uint32_t kmax,
                         void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st, bool status_ready,
-                        const uint32_t *d_list = nullptr, uint32_t n_list = 0) {
+                        const uint32_t *d_list = nullptr, uint32_t n_list = 0, bool hash = true) {
     int rc = nm_prepare_enc(ix, seq_len);
     if (rc != NM_OK) return rc;
     const nm_enc_word *enc = (const nm_enc_word *)ix->cur->enc.p;
@@ -1530,6 +1620,7 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
     if (beside) {
         // (the probes start before k_sites has encoded anything: this launch takes the separate encode pass)
         if ((rc = nm_encode(ix, d_seq, seq_len, st, status_ready ? nullptr : d_status)) != NM_OK) return rc;
+        if (hash && (rc = nm_hash_positions(ix, n, d_status, st)) != NM_OK) return rc;
         enc_out = nullptr;
         HIP_TRY(hipEventRecord(ix->cur->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(ix->cur->side, ix->cur->ev_fork, 0));
@@ -1539,7 +1630,7 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
     {
         nm_timed timed(ix, st);
 #define NM_LAUNCH_SITES(STATS_, LIST_) hipLaunchKernelGGL((k_sites<BIG, STATS_, LIST_>), sgrid, sblock, lds, st, view, (const uint8_t *)d_seq, seq_len, \
-                                                          enc_out, ix->cur->enc_words, n, kmin, kmax, d, d_out, elem_bytes, d_status, need, work, d_list, n_list)
+                                                          enc_out, ix->cur->enc_words, n, kmin, kmax, d, d_out, elem_bytes, d_status, need, work, d_list, n_list, hash && enc_out != nullptr)
         if (d_list) { if (ix->count_steps) NM_LAUNCH_SITES(true, true); else NM_LAUNCH_SITES(false, true); }
         else        { if (ix->count_steps) NM_LAUNCH_SITES(true, false); else NM_LAUNCH_SITES(false, false); }
 #undef NM_LAUNCH_SITES
@@ -1562,11 +1653,12 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
 // the encode pass + one lane per position.  status_ready: the caller has reset the status words already.
 template <bool BIG, bool RC>
 static int launch_min_unique(nm_index *ix, const nm_view &view, const void *d_seq, uint64_t seq_len, uint64_t num_kmers, uint32_t kmin,
-                             uint32_t kmax, void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st, bool status_ready) {
+                             uint32_t kmax, void *d_out, int elem_bytes, uint64_t *d_status, hipStream_t st, bool status_ready, bool hash = true) {
     if (RC && nm_sites_apply(ix, view, kmin))
-        return launch_sites<BIG>(ix, view, d_seq, seq_len, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st, status_ready);
+        return launch_sites<BIG>(ix, view, d_seq, seq_len, num_kmers, kmin, kmax, d_out, elem_bytes, d_status, st, status_ready, nullptr, 0, hash);
     int rc = nm_encode(ix, d_seq, seq_len, st, status_ready ? nullptr : d_status);
     if (rc != NM_OK) return rc;
+    if (hash && (rc = nm_hash_positions(ix, num_kmers, d_status, st)) != NM_OK) return rc;
     const dim3 block(NM_BLOCK);
     const nm_enc_word *enc = (const nm_enc_word *)ix->cur->enc.p;
     // one lane per position; on both strands the repeat probes run first (every stride: there is no bitmap to gate them)
@@ -1652,8 +1744,8 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     if (nk == 1 && use_revcomp && ix->list_via_range && view.quad && seq_len >= ks[0]) {
         const uint64_t head = num_kmers < seq_len - ks[0] + 1 ? num_kmers : seq_len - ks[0] + 1;
         if (head) {
-            rc = ix->big ? launch_min_unique<true, true>(ix, view, d_seq, seq_len, head, ks[0], ks[0], d_out, elem_bytes, d_status, st, true)
-                         : launch_min_unique<false, true>(ix, view, d_seq, seq_len, head, ks[0], ks[0], d_out, elem_bytes, d_status, st, true);
+            rc = ix->big ? launch_min_unique<true, true>(ix, view, d_seq, seq_len, head, ks[0], ks[0], d_out, elem_bytes, d_status, st, true, false)
+                         : launch_min_unique<false, true>(ix, view, d_seq, seq_len, head, ks[0], ks[0], d_out, elem_bytes, d_status, st, true, false);
             if (rc != NM_OK) return rc;
             first = head;
             encoded = true;
@@ -1665,8 +1757,8 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
     if (nk > 1 && use_revcomp && ix->list_via_range && nm_sites_apply(ix, view, ks[0]) && seq_len >= kmax) {
         const uint64_t head = num_kmers < seq_len - kmax + 1 ? num_kmers : seq_len - kmax + 1;
         if (head) {
-            rc = ix->big ? launch_sites<true>(ix, view, d_seq, seq_len, head, ks[0], kmax, d_out, elem_bytes, d_status, st, true, d_ks, nk)
-                         : launch_sites<false>(ix, view, d_seq, seq_len, head, ks[0], kmax, d_out, elem_bytes, d_status, st, true, d_ks, nk);
+            rc = ix->big ? launch_sites<true>(ix, view, d_seq, seq_len, head, ks[0], kmax, d_out, elem_bytes, d_status, st, true, d_ks, nk, false)
+                         : launch_sites<false>(ix, view, d_seq, seq_len, head, ks[0], kmax, d_out, elem_bytes, d_status, st, true, d_ks, nk, false);
             if (rc != NM_OK) return rc;
             first = head;
             encoded = true;
@@ -1677,6 +1769,7 @@ extern "C" int nm_fixed_k_segment_dev(nm_index *ix, const void *d_seq, uint64_t 
         if (ix->big) { if (use_revcomp) launch_fixed_k<true, true>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<true, false>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
         else         { if (use_revcomp) launch_fixed_k<false, true>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); else launch_fixed_k<false, false>(ix, view, seq_len, first, num_kmers, d_ks, nk, d_out, elem_bytes, d_status, st); }
     }
+    if ((rc = nm_hash_positions(ix, num_kmers, d_status, st)) != NM_OK) return rc;   // (list mode: one pass over the encoded words)
     HIP_TRY(hipGetLastError());
     return nm_lane_done(ix, st);
 }
@@ -1690,12 +1783,30 @@ static int nm_finish_segment(nm_index *ix, void *out, uint64_t out_bytes, uint64
     HIP_TRY(hipStreamSynchronize(ix->stream));
     if (n_ambiguous) *n_ambiguous = status[0];
     if (bad_pos) *bad_pos = status[2];
+    ix->last_fingerprint = status[NM_STATUS_HASH];
     if (status[1]) {
         nm_set_error("a generated k-mer was not found in the index (first at segment position %llu); "
                      "possibly a mismatch between the sequence and the index", (unsigned long long)status[2]);
         return NM_E_KMER_NOT_FOUND;
     }
     return NM_OK;
+}
+
+extern "C" int nm_guard_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks, uint32_t nk,
+                                    int range_mode, uint32_t initial_len, int use_revcomp, uint64_t *d_status, void *stream);
+
+// The host-buffer segment calls are the seam of newmap/search.py's binary_search / linear_search, which raise on an absent
+// probe (:699-722): unless the segment is, by length and fingerprint, a whole indexed record, the staged segment goes
+// through the exact guard as well.  NM_OPT_SEGMENT_GUARD = 0: the caller checks whole records itself (the drivers).
+static int nm_seam_guard(nm_index *ix, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks, uint32_t nk, int range_mode,
+                         uint32_t initial_len, int use_revcomp, uint64_t *bad_pos) {
+    if (!ix->segment_guard || num_kmers == 0) return NM_OK;
+    if (num_kmers == seq_len && nm_index_has_record(ix, seq_len, ix->last_fingerprint)) return NM_OK;
+    const uint64_t fp = ix->last_fingerprint;
+    int rc = nm_guard_segment_dev(ix, ix->seq.p, seq_len, num_kmers, ks, nk, range_mode, initial_len, use_revcomp, (uint64_t *)ix->status.p, ix->stream);
+    if (rc == NM_OK) rc = nm_finish_segment(ix, nullptr, 0, nullptr, bad_pos);
+    ix->last_fingerprint = fp;
+    return rc;
 }
 
 static int nm_stage_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t out_bytes) {
@@ -1719,7 +1830,9 @@ extern "C" int nm_min_unique_segment(nm_index *ix, const uint8_t *seq, uint64_t 
     rc = nm_min_unique_segment_dev(ix, ix->seq.p, seq_len, num_kmers, kmin, kmax, use_revcomp, elem_bytes, ix->out.p,
                                    (uint64_t *)ix->status.p, ix->stream);
     if (rc != NM_OK) return rc;
-    return nm_finish_segment(ix, out, out_bytes, n_ambiguous, bad_pos);
+    if ((rc = nm_finish_segment(ix, out, out_bytes, n_ambiguous, bad_pos)) != NM_OK) return rc;
+    const uint32_t two[2] = {kmin, kmax};
+    return nm_seam_guard(ix, seq_len, num_kmers, two, 2, 1, initial_len, use_revcomp, bad_pos);
 }
 
 extern "C" int nm_fixed_k_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
@@ -1733,7 +1846,54 @@ extern "C" int nm_fixed_k_segment(nm_index *ix, const uint8_t *seq, uint64_t seq
     rc = nm_fixed_k_segment_dev(ix, ix->seq.p, seq_len, num_kmers, ks, nk, use_revcomp, elem_bytes, ix->out.p,
                                 (uint64_t *)ix->status.p, ix->stream);
     if (rc != NM_OK) return rc;
-    return nm_finish_segment(ix, out, out_bytes, n_ambiguous, bad_pos);
+    if ((rc = nm_finish_segment(ix, out, out_bytes, n_ambiguous, bad_pos)) != NM_OK) return rc;
+    return nm_seam_guard(ix, seq_len, num_kmers, ks, nk, 0, 0, use_revcomp, bad_pos);
+}
+
+// ---- the exact zero-count guard over one segment (records that are not among the indexed ones; include/newmap_amd.h) ----
+extern "C" int nm_guard_segment_dev(nm_index *ix, const void *d_seq, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks, uint32_t nk,
+                                    int range_mode, uint32_t initial_len, int use_revcomp, uint64_t *d_status, void *stream) {
+    int rc = nm_check_segment_args(ix, seq_len, num_kmers, 4);
+    if (rc != NM_OK) return rc;
+    if (!ks || nk == 0 || (range_mode && nk != 2)) { nm_set_error("the guard takes kmin, kmax (range mode) or the list of lengths"); return NM_E_ARGUMENT; }
+    for (uint32_t i = 0; i < nk; i++) if (ks[i] < 1) { nm_set_error("k-mer lengths must be >= 1"); return NM_E_ARGUMENT; }
+    if (!d_status) { nm_set_error("d_status is required"); return NM_E_ARGUMENT; }
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    if ((rc = nm_lane_for(ix, st)) != NM_OK) return rc;
+    if ((rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
+    if (num_kmers == 0) return NM_OK;
+    ix->guard_segments++;
+    if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;
+    nm_view view = ix->view;                               // the walks start from the first base: no tables
+    const uint32_t *d_ks = nullptr;
+    uint32_t kmin = ks[0], kmax = ks[0];
+    for (uint32_t i = 1; i < nk; i++) { if (ks[i] < kmin) kmin = ks[i]; if (ks[i] > kmax) kmax = ks[i]; }
+    if (!range_mode) {
+        if ((rc = nm_grow(ix->cur->ks, (uint64_t)nk * sizeof(uint32_t))) != NM_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->cur->ks.p, ks, (uint64_t)nk * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        d_ks = (const uint32_t *)ix->cur->ks.p;
+    }
+    const dim3 grid(nm_grid(num_kmers)), block(NM_BLOCK);
+    const nm_enc_word *enc = (const nm_enc_word *)ix->cur->enc.p;
+    const uint32_t n_list = range_mode ? 0u : nk;
+#define NM_LAUNCH_GUARD(BIG_, RC_) hipLaunchKernelGGL((k_guard<BIG_, RC_>), grid, block, 0, st, view, enc, seq_len, num_kmers, kmin, kmax, initial_len, d_ks, n_list, d_status)
+    if (ix->big) { if (use_revcomp) NM_LAUNCH_GUARD(true, true); else NM_LAUNCH_GUARD(true, false); }
+    else         { if (use_revcomp) NM_LAUNCH_GUARD(false, true); else NM_LAUNCH_GUARD(false, false); }
+#undef NM_LAUNCH_GUARD
+    HIP_TRY(hipGetLastError());
+    return nm_lane_done(ix, st);
+}
+
+extern "C" int nm_guard_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks, uint32_t nk,
+                                int range_mode, uint32_t initial_len, int use_revcomp, uint64_t *bad_pos) {
+    int rc = nm_check_segment_args(ix, seq_len, num_kmers, 4);
+    if (rc != NM_OK) return rc;
+    if (!seq && seq_len) { nm_set_error("null buffer"); return NM_E_ARGUMENT; }
+    if ((rc = nm_stage_segment(ix, seq, seq_len, 0)) != NM_OK) return rc;
+    rc = nm_guard_segment_dev(ix, ix->seq.p, seq_len, num_kmers, ks, nk, range_mode, initial_len, use_revcomp, (uint64_t *)ix->status.p, ix->stream);
+    if (rc != NM_OK) return rc;
+    return nm_finish_segment(ix, nullptr, 0, nullptr, bad_pos);
 }
 
 extern "C" int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers,
@@ -1887,4 +2047,42 @@ extern "C" int nm_dev_sync(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipDeviceSynchronize());
     return NM_OK;
+}
+
+// record fingerprints (nm_hash.h) ---------------------------------------------------------------
+
+extern "C" int nm_index_has_record(const nm_index *ix, uint64_t length, uint64_t hash) {
+    if (!ix) return 0;
+    const nm_record_entry key{length, hash};
+    return std::binary_search(ix->records.begin(), ix->records.end(), key, [](const nm_record_entry &a, const nm_record_entry &b) {
+        return a.length != b.length ? a.length < b.length : a.hash < b.hash; }) ? 1 : 0;
+}
+
+extern "C" uint64_t nm_index_records(const nm_index *ix, uint64_t *lengths, uint64_t *hashes, uint64_t capacity) {
+    if (!ix) return 0;
+    for (uint64_t i = 0; i < ix->records.size() && i < capacity; i++) {
+        if (lengths) lengths[i] = ix->records[i].length;
+        if (hashes) hashes[i] = ix->records[i].hash;
+    }
+    return ix->records.size();
+}
+
+extern "C" uint64_t nm_fingerprint_join(uint64_t ha, uint64_t len_a, uint64_t hb) {
+    return nm_hash_join(ha, len_a / 64, hb);               // (len_a must be a multiple of 64: a segment starts at a word of its record)
+}
+
+extern "C" uint64_t nm_fingerprint_sequence(const uint8_t *seq, uint64_t len) {
+    uint64_t h = 0, pw = 1;
+    for (uint64_t w = 0; w * 64 < len; w++) {
+        uint64_t lo = 0, hi = 0, amb = 0;
+        for (uint64_t j = 0; j < 64 && w * 64 + j < len; j++) {
+            const uint32_t u = seq[w * 64 + j] & 0xDFu;
+            const uint32_t c = u == 'A' ? 0 : (u == 'C' ? 1 : (u == 'G' ? 2 : (u == 'T' ? 3 : 4)));
+            if (c > 3) amb |= 1ULL << j;
+            else { lo |= (uint64_t)(c & 1u) << j; hi |= (uint64_t)(c >> 1) << j; }
+        }
+        h += nm_hash_word(lo, hi, amb) * pw;
+        pw *= NM_HASH_R;
+    }
+    return h;
 }

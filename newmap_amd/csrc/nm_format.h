@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define NM_MAGIC "NMAPGFX1"
-#define NM_FORMAT_VERSION 1u
+#define NM_FORMAT_VERSION 2u        /* 2: + the record list (length, fingerprint) behind the separators */
 #define NM_SUPER_SHIFT 31
 #define NM_MAX_SUPER 16            /* up to 2^35 BWT positions */
 #define NM_SEP_FLAG 0x80000000u
@@ -72,7 +72,13 @@ struct nm_file_header {            /* 1024 bytes */
     uint8_t  sa_ratio, seed_len, pad8[6];
     uint64_t n_super;
     uint64_t super_cnt[NM_MAX_SUPER][4];   /* A,C,G,T before each superblock */
-    uint8_t  reserved[1024 - 8 - 8 - 8 * 3 - 32 - 8 * 5 - 8 * 4 - 8 - 8 - NM_MAX_SUPER * 32];
+    uint64_t off_records;          /* n_records entries of nm_record_entry (format 2, nm_hash.h) */
+    uint8_t  reserved[1024 - 8 - 8 - 8 * 3 - 32 - 8 * 5 - 8 * 4 - 8 - 8 - NM_MAX_SUPER * 32 - 8];
+};
+
+struct nm_record_entry {           /* one FASTA record with data: its length in bytes and the fingerprint of nm_hash.h */
+    uint64_t length;
+    uint64_t hash;
 };
 
 #ifdef __cplusplus

@@ -228,12 +228,68 @@ class Index:
         _lib.raise_for(rc)
         return out[:num_kmers]
 
+    # record fingerprints and the exact guard (include/newmap_amd.h, csrc/nm_hash.h) ----------------
+    def records(self):
+        """(lengths, fingerprints) of the indexed records, sorted by (length, fingerprint)"""
+        n = int(self._L.nm_index_records(self.handle, None, None, 0))
+        lens, fps = np.zeros(max(n, 1), dtype=np.uint64), np.zeros(max(n, 1), dtype=np.uint64)
+        self._L.nm_index_records(self.handle, lens.ctypes.data, fps.ctypes.data, n)
+        return lens[:n], fps[:n]
+
+    def has_record(self, length: int, fingerprint: int) -> bool:
+        return bool(self._L.nm_index_has_record(self.handle, int(length), int(fingerprint) & 0xFFFFFFFFFFFFFFFF))
+
+    def guard_segments(self) -> int:
+        """segments that have gone through the exact guard on this handle (0 while every searched record is an indexed one)"""
+        return int(self._L.nm_index_info(self.handle, 23))
+
+    def last_fingerprint(self) -> int:
+        """fingerprint of the positions of the last host-buffer segment call (min_unique_segment / fixed_k_segment)"""
+        return int(self._L.nm_index_info(self.handle, 21))
+
+    def guard_segment(self, seq, num_kmers: int, kmer_lengths: Sequence[int], is_range: bool, use_revcomp: bool = True,
+                      initial_search_length: int = 0):
+        """The exact zero-count check of newmap/search.py:699-722 over one segment: raises RuntimeError exactly when some
+        k-mer of the reference's probe schedule is absent from the index."""
+        ks = np.ascontiguousarray([min(kmer_lengths), max(kmer_lengths)] if is_range else list(kmer_lengths), dtype=np.uint32)
+        buf = _as_u8(seq)
+        bad = ctypes.c_uint64(0)
+        with self._lock:
+            rc = self._L.nm_guard_segment(self.handle, buf.ctypes.data, buf.size, int(num_kmers), ks.ctypes.data, ks.size,
+                                          int(bool(is_range)), int(initial_search_length), int(bool(use_revcomp)), ctypes.byref(bad))
+        _lib.raise_for(rc, self._not_found(buf, int(bad.value), int(ks.min())) if rc == _lib.NM_E_KMER_NOT_FOUND else None)
+
     # native driver ------------------------------------------------------------------------------
+    def set_segment_guard(self, on: bool):
+        """on (default): min_unique_segment / fixed_k_segment raise like the reference's binary_search / linear_search for ANY
+        absent probe (the exact guard runs unless the segment is a whole indexed record); off: the caller checks whole
+        records itself (newmap_amd/search.py's Python driver)"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SEGMENT_GUARD, int(bool(on))))
+
+    def set_initial_search_length(self, n: int):
+        """--initial-search-length of the run: shapes the reference's probe schedule, which the exact guard replays"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_INITIAL_LENGTH, int(n or 0)))
+
+    def guard_fasta(self, fasta_path, kmer_lengths, is_range: bool, use_revcomp: bool, batch: int, include, exclude, flags):
+        """nm_guard_fasta: the exact zero-count check over the records with flags[i] != 0 (records with data, file order)"""
+        ks = np.ascontiguousarray([min(kmer_lengths), max(kmer_lengths)] if is_range else list(kmer_lengths), dtype=np.uint32)
+        inc = (ctypes.c_char_p * max(len(include), 1))(*[bytes(x) for x in include])
+        exc = (ctypes.c_char_p * max(len(exclude), 1))(*[bytes(x) for x in exclude])
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        with self._lock:
+            rc = self._L.nm_guard_fasta(self.handle, os.fsencode(fasta_path), ks.ctypes.data, ks.size, int(bool(is_range)),
+                                        int(bool(use_revcomp)), int(batch), inc, len(include), exc, len(exclude), fl.ctypes.data, fl.size)
+        _lib.raise_for(rc)
+
     def search_fasta(self, fasta_path, out_dir, kmer_lengths, is_range: bool, use_revcomp: bool = True,
-                     batch: int = 10_000_000, include=(), exclude=(), on_record=None, rank: int = 0, world: int = 1):
+                     batch: int = 10_000_000, include=(), exclude=(), on_record=None, rank: int = 0, world: int = 1,
+                     record_info: list | None = None):
         """nm_search_fasta(_shard): FASTA in -> `<id>.unique.<dtype>` files out, natively.  `on_record(id: bytes,
         summary: dict)` is called once per output file.  world > 1: this process is one rank of a job with one
-        process per GPU and searches / writes only its own interleaved share.  Returns the totals as a dict."""
+        process per GPU and searches / writes only its own interleaved share; `record_info` (a list) then receives one
+        (length, fingerprint of this rank's share, searched) per FASTA record with data -- the caller joins the ranks
+        (newmap_amd/parallel.py).  With one rank the record check and the exact guard run inside the call.  Returns the
+        totals as a dict."""
         ks = np.ascontiguousarray([min(kmer_lengths), max(kmer_lengths)] if is_range else list(kmer_lengths),
                                   dtype=np.uint32)
         fields = [f[0] for f in _lib.SearchSummary._fields_]
@@ -246,11 +302,19 @@ class Index:
         inc = (ctypes.c_char_p * max(len(include), 1))(*[bytes(x) for x in include])
         exc = (ctypes.c_char_p * max(len(exclude), 1))(*[bytes(x) for x in exclude])
         total = _lib.SearchSummary()
+        cap = 1 << 20
+        info = np.zeros(3 * cap if record_info is not None else 3, dtype=np.uint64)
+        n_info = ctypes.c_uint64(0)
         with self._lock:
-            rc = self._L.nm_search_fasta_shard(self.handle, os.fsencode(fasta_path), os.fsencode(out_dir), ks.ctypes.data,
-                                               ks.size, int(bool(is_range)), int(bool(use_revcomp)), int(batch),
-                                               inc, len(include), exc, len(exclude), cb, None, ctypes.byref(total),
-                                               int(rank), int(world))
+            rc = self._L.nm_search_fasta_shard_ex(self.handle, os.fsencode(fasta_path), os.fsencode(out_dir), ks.ctypes.data,
+                                                  ks.size, int(bool(is_range)), int(bool(use_revcomp)), int(batch),
+                                                  inc, len(include), exc, len(exclude), cb, None, ctypes.byref(total),
+                                                  int(rank), int(world), info.ctypes.data if record_info is not None else None,
+                                                  cap if record_info is not None else 0, ctypes.byref(n_info))
+        if record_info is not None:
+            if n_info.value > cap:
+                raise OverflowError(f"{n_info.value} FASTA records: more than the sharded search keeps fingerprints for")
+            record_info.extend((int(info[3 * i]), int(info[3 * i + 1]), int(info[3 * i + 2])) for i in range(int(n_info.value)))
         if rc == _lib.NM_E_ARGUMENT:
             msg = _lib.last_error()
             if "nothing was processed" in msg or "included sequences" in msg:
@@ -273,6 +337,19 @@ class Index:
         rc = self._L.nm_fixed_k_segment_dev(self.handle, d_seq, seq_len, num_kmers, ks.ctypes.data, ks.size,
                                             int(bool(use_revcomp)), elem_bytes, d_out, d_status, stream or None)
         _lib.raise_for(rc)
+
+
+def fingerprint(seq) -> int:
+    """csrc/nm_hash.h on the host (small inputs, tests)"""
+    buf = _as_u8(seq)
+    return int(_lib.lib().nm_fingerprint_sequence(buf.ctypes.data, buf.size))
+
+
+def fingerprint_join(fp_a: int, len_a: int, fp_b: int) -> int:
+    """fingerprint of a . b from that of a (len_a bases, a multiple of 64) and that of b"""
+    if len_a % 64:
+        raise ValueError("segments join at multiples of 64 bases of their record")
+    return int(_lib.lib().nm_fingerprint_join(int(fp_a), int(len_a), int(fp_b)))
 
 
 def search_segment_multi(indexes: Sequence[Index], seqs: Sequence, num_kmers: int, kmer_lengths: Sequence[int],

@@ -215,6 +215,49 @@ def search_records_sharded(records: Sequence[tuple[bytes, bytes]], compute: Call
     return out
 
 
+def _raise_together(world: int, rank: int, failure: Exception | None) -> None:
+    """every rank learns whether any rank failed (one small all-reduce in the place of a bare barrier): the failing rank
+    re-raises its own exception, the others raise a RuntimeError naming it -- nobody is left waiting in a collective"""
+    if world <= 1:
+        if failure is not None:
+            raise failure
+        return
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    bad = torch.tensor([rank + 1 if failure is not None else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if failure is not None:
+        raise failure
+    if int(bad.item()):
+        raise RuntimeError(f"the search failed on rank {int(bad.item()) - 1} (see its message); the output files are incomplete")
+
+
+def unverified_records(index, info, world: int) -> list[int]:
+    """flags per FASTA record with data: 1 = searched but not one of the indexed records (exact guard needed).  `info` =
+    this rank's (length, fingerprint of its share, searched) per record; the shares are added up over the ranks mod 2^64
+    (as four 16-bit limbs each, so that no backend's integer sum can overflow)."""
+    n = len(info)
+    fps = np.array([fp for _, fp, _ in info], dtype=np.uint64)
+    searched = np.array([s for _, _, s in info], dtype=np.int64)
+    if world > 1 and n:
+        import torch
+        import torch.distributed as dist
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        limbs = np.stack([(fps >> np.uint64(16 * j)) & np.uint64(0xFFFF) for j in range(4)] + [searched.astype(np.uint64)]).astype(np.int64)
+        t = torch.from_numpy(limbs).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        limbs = t.cpu().numpy().astype(np.uint64)
+        with np.errstate(over="ignore"):
+            fps = limbs[0] + (limbs[1] << np.uint64(16)) + (limbs[2] << np.uint64(32)) + (limbs[3] << np.uint64(48))
+        # searched: 1 per rank for a searched record, 2 where a rank could not join its segments
+        unjoinable = limbs[4] > np.uint64(world)
+        searched = (limbs[4] > 0).astype(np.int64)
+    else:
+        unjoinable = searched == 2
+    return [int(bool(searched[i]) and (bool(unjoinable[i]) or not index.has_record(info[i][0], int(fps[i])))) for i in range(n)]
+
+
 def write_unique_counts_distributed(config) -> None:
     """`newmap search` over all ranks of the current torch.distributed job (or a single process).
     Output files are identical to newmap_amd.search.write_unique_counts."""
@@ -264,10 +307,27 @@ def write_unique_counts_distributed(config) -> None:
     if not gather and not gzipped and os.environ.get("NEWMAP_AMD_PYTHON_DRIVER", "") != "1":
         # every rank runs the native driver on its own interleaved share of the position space
         index = cached_index(config.fmindex_filepaths[0], local_rank if config.device is None else config.device)
-        total = index.search_fasta(config.fasta_filepaths[0], config.output_directory, config.kmer_lengths,
-                                   config.is_binary_search, config.use_reverse_complement, config.kmer_batch_size,
-                                   config.include_sequence_ids, config.exclude_sequence_ids, None, rank, world)
-        barrier()
+        index.set_initial_search_length(config.initial_search_length)
+        info: list = []
+        total, failure = None, None
+        try:
+            total = index.search_fasta(config.fasta_filepaths[0], config.output_directory, config.kmer_lengths,
+                                       config.is_binary_search, config.use_reverse_complement, config.kmer_batch_size,
+                                       config.include_sequence_ids, config.exclude_sequence_ids, None, rank, world, info)
+        except Exception as e:                      # (a rank that fails still meets the others below: nobody waits for ever)
+            failure = e
+        _raise_together(world, rank, failure)
+        # a record whose fingerprint -- the ranks' shares added up -- is in the index holds no absent k-mer; the others are
+        # searched again by the exact guard on rank 0 (newmap/search.py:699-722; csrc/nm_hash.h)
+        flags = unverified_records(index, info, world)
+        failure = None
+        if rank == 0 and any(flags):
+            try:
+                index.guard_fasta(config.fasta_filepaths[0], config.kmer_lengths, config.is_binary_search, config.use_reverse_complement,
+                                  config.kmer_batch_size, config.include_sequence_ids, config.exclude_sequence_ids, flags)
+            except Exception as e:
+                failure = e
+        _raise_together(world, rank, failure)
         if total["records"] == 0 and (config.include_sequence_ids or config.exclude_sequence_ids):
             nothing_found()
         return

@@ -221,6 +221,7 @@ def _write_unique_counts_native(config: SearchConfig):
     max_kmer_length, min_kmer_length = max(config.kmer_lengths), min(config.kmer_lengths)
     _check_range(config, min_kmer_length, max_kmer_length)
     index = _index(config)
+    index.set_initial_search_length(config.initial_search_length)      # (the exact guard replays the reference's schedule)
     running = _Summary(min_kmer_length, max_kmer_length)
 
     def on_record(rec_id: bytes, s: dict):
@@ -296,8 +297,22 @@ def _write_unique_counts_python(config: SearchConfig):
     processed_any = False
     summary = _Summary(min_kmer_length, max_kmer_length)
     current_id, current_path = None, None
+    # the record being searched: its fingerprint joined from the segments' (csrc/nm_hash.h) and the segments themselves, kept
+    # until its end -- a record that is not one of the indexed ones goes through the exact guard (newmap/search.py:699-722)
+    rec_fp, rec_pos, rec_joinable, rec_segments = 0, 0, True, []
+
+    def end_of_record():
+        nonlocal rec_fp, rec_pos, rec_joinable, rec_segments
+        if rec_segments and not (rec_joinable and index.has_record(rec_pos, rec_fp)):
+            for data, num_kmers in rec_segments:
+                index.guard_segment(data, num_kmers, config.kmer_lengths, config.is_binary_search, config.use_reverse_complement,
+                                    config.initial_search_length)
+        rec_fp, rec_pos, rec_joinable, rec_segments = 0, 0, True, []
+
     with ExitStack() as stack:
         fasta = stack.enter_context(optional_gzip_open(config.fasta_filepaths[0], "rb"))
+        index.set_segment_guard(False)                                # (whole records are checked below, not every segment)
+        stack.callback(index.set_segment_guard, True)
         for seg in sequence_segments(fasta, requested, lookahead):
             if seg.id != current_id:
                 if not _wanted(config, seg.id):
@@ -323,6 +338,15 @@ def _write_unique_counts_python(config: SearchConfig):
                 config.log("No unique lengths found for this sequence segment")
             with open(current_path, "ab") as fh:                      # :356-357
                 arr.tofile(fh)
+            if rec_pos % 64:
+                rec_joinable = False
+            else:
+                from .engine import fingerprint_join
+                rec_fp = (rec_fp + fingerprint_join(0, rec_pos, index.last_fingerprint())) & 0xFFFFFFFFFFFFFFFF
+            rec_pos += num_kmers
+            rec_segments.append((seg.data, num_kmers))
+            if seg.epilogue:
+                end_of_record()
         if current_id is not None:
             summary.report(config, current_id)
     if not processed_any:                                             # :368-380

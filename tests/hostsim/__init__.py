@@ -44,6 +44,10 @@ def lib():
     L.hs_repeat_probes.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, vp, vp]
     L.hs_repeat_probes2.restype = u64
     L.hs_repeat_probes2.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, vp, vp, i32, vp, vp]
+    L.hs_segment_hash.restype = u64
+    L.hs_segment_hash.argtypes = [vp, u64, u64]
+    L.hs_guard.restype = u64
+    L.hs_guard.argtypes = [vp, vp, u64, u64, vp, u32, i32, u32, i32]
     L.hs_fasta_open.restype = vp
     L.hs_fasta_open.argtypes = [ctypes.c_char_p, u32, u64]
     L.hs_fasta_close.argtypes = [vp]
@@ -65,6 +69,12 @@ def lib():
     L.hs_multi.argtypes = [vp, u32, vp, u32, u64, u64, u32, u32, vp, u32, i32, i32, vp, vp]
     _lib = L
     return L
+
+
+def segment_hash(seq: bytes, end: int) -> int:
+    """fingerprint of positions [0, end) of a segment, computed from its encoded words as the device does (nm_hash.h)"""
+    buf = np.frombuffer(seq, dtype=np.uint8)
+    return int(lib().hs_segment_hash(buf.ctypes.data, buf.size, end))
 
 
 class HostSim:
@@ -132,6 +142,13 @@ class HostSim:
         steps = self.L.hs_repeat_probes2(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, stride, coarse_stride,
                                          words.ctypes.data, decided.ctypes.data, 1, periods.ctypes.data, coarse.ctypes.data)
         return words[:n_probes], decided[:num_kmers], int(steps), periods[:n_coarse], coarse[:n_coarse]
+
+    def guard(self, seq: bytes, num_kmers, ks, is_range: bool, initial_len: int = 0, use_rc: bool = True):
+        """nm_guard_range_one / nm_guard_list_one: first position of the segment for which the reference would raise, or None"""
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        k = np.asarray([min(ks), max(ks)] if is_range else list(ks), dtype=np.uint32)
+        p = int(self.L.hs_guard(self.h, buf.ctypes.data, buf.size, num_kmers, k.ctypes.data, k.size, int(is_range), initial_len, int(use_rc)))
+        return None if p == 0xFFFFFFFFFFFFFFFF else p
 
     def sites(self, seq: bytes, num_kmers, kmin, kmax, d_cap=59, probes=1, ks=None, dtype=np.uint8, chance_max=256, walk_max=64):
         """k_sites -> gated repeat probes -> k_resolve, as the device runs them (needs check_quad() first: it builds the

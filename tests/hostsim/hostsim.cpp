@@ -250,6 +250,35 @@ uint64_t hs_check_codes4(uint64_t rounds) {
 // the repeat probes of one segment (k_repeat_probe): the probe word of every stride, and what the consumers
 // make of them: decided[p] = the element nm_probe_kstar / nm_probe_element give position p, 0xFFFFFFFF where the
 // probes leave it open.  Returns the LF steps spent.
+// k_segment_hash / the fingerprint stage of k_sites: the fingerprint of positions [0, end) of a segment from its encoded words
+uint64_t hs_segment_hash(const uint8_t *seq, uint64_t seq_len, uint64_t end) {
+    std::vector<nm_enc_word> enc;
+    hs_encode(seq, seq_len, enc);
+    std::vector<uint64_t> tab(NM_HASH_TAB_WORDS);
+    nm_hash_fill_tables(tab.data());
+    uint64_t h = 0;
+    for (uint64_t w = 0; w * 64 < end && w < enc.size(); w++) h += nm_hash_segment_word(tab.data(), enc[w], w, end);
+    return h;
+}
+
+// nm_guard_range_one / nm_guard_list_one over a segment: returns the first position for which the reference would raise, or ~0
+uint64_t hs_guard(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_kmers, const uint32_t *ks, uint32_t nk, int range_mode,
+                  uint32_t initial_len, int use_rc) {
+    std::vector<nm_enc_word> enc;
+    hs_encode(seq, seq_len, enc);
+    nm_view v = ix->v;
+    uint32_t kmin = ks[0], kmax = ks[0];
+    for (uint32_t i = 1; i < nk; i++) { if (ks[i] < kmin) kmin = ks[i]; if (ks[i] > kmax) kmax = ks[i]; }
+    for (uint64_t p = 0; p < num_kmers; p++) {
+        nm_tally t = {0, 0, 0, 0};
+        bool bad;
+        if (range_mode) bad = use_rc ? nm_guard_range_one<true, true>(v, enc.data(), p, kmin, kmax, initial_len, t) : nm_guard_range_one<true, false>(v, enc.data(), p, kmin, kmax, initial_len, t);
+        else bad = use_rc ? nm_guard_list_one<true, true>(v, enc.data(), p, seq_len, ks, nk, t) : nm_guard_list_one<true, false>(v, enc.data(), p, seq_len, ks, nk, t);
+        if (bad) return p;
+    }
+    return ~0ULL;
+}
+
 // k_period_runs + k_period_spread (nm_engine.hip): coarse[c] = coarse_stride for every stride of a tandem run whose first
 // stride's walk of kmax + u - 1 bases still finds two occurrences, else 0.  periods (may be null): the period found per stride.
 uint64_t hs_period_runs(hs_index *ix, const std::vector<nm_enc_word> &enc, uint64_t num_kmers, uint32_t kmax, uint32_t coarse_stride,

@@ -216,17 +216,20 @@ def test_zero_count_guard_raises(tmp_path, eng):
 
 
 def test_zero_count_guard_scope(tmp_path, eng):
-    """newmap/search.py:699-722 raises when ANY probe of its bisection schedule is absent from the index.  The engine asks
-    the index about far fewer k-mers (conscious divergence 4): it raises when a k-mer it walks or a
-    window its sites look up is absent -- which a FASTA that does not match the index trips at once: a different genome,
-    and a genome with a single substituted base at 20:200 (every window over the base is absent, and with groups of at
-    most 12 positions a site looks at one of them).  It does not re-derive the reference's longest probe per position."""
+    """newmap/search.py:699-722 raises when ANY probe of its bisection schedule is absent from the index.  The engine's
+    fast paths ask the index about far fewer k-mers, so exactness comes from the record check (csrc/nm_hash.h): a
+    segment / record that is, by length and fingerprint, one of the indexed records cannot hold an absent k-mer; any
+    other one goes through the exact guard (nm_guard_*), which replays the reference's probe schedule.  A different
+    genome, a single substituted base (range mode AND fixed k = 36 on a small genome, where a group of sites is larger
+    than a window and the base can fall between the looked-up windows), a chimeric join of two indexed pieces: all
+    raise; a piece of an indexed record -- not an indexed record, but free of absent k-mers -- does not, and equals the
+    oracle."""
     rng = np.random.default_rng(99)
     genome = _random_dna(rng, 300_000)
     fa, idx = _build_index(tmp_path, b">g\n" + genome + b"\n", "guard")
     with eng.Index(idx, 0) as ix:
         ok, _ = ix.min_unique_segment(genome, len(genome), 20, 200)
-        assert ok[:-19].min() >= 20
+        assert ok[:-19].min() >= 20 and ix.guard_segments() == 0          # an indexed record: no guard
         with pytest.raises(RuntimeError, match="not found in the index"):
             ix.min_unique_segment(_random_dna(rng, 100_000), 100_000, 20, 200)
         for at in (1234, 150_001, 299_000):
@@ -234,6 +237,111 @@ def test_zero_count_guard_scope(tmp_path, eng):
             snp[at] = ord("A") if genome[at] != ord("A") else ord("C")
             with pytest.raises(RuntimeError, match="not found in the index"):
                 ix.min_unique_segment(bytes(snp), len(snp), 20, 200)
+            for ks in ([36], [100], [24, 36]):
+                with pytest.raises(RuntimeError, match="not found in the index"):
+                    ix.fixed_k_segment(bytes(snp), len(snp), ks)
+        chimera = genome[1000:90_000] + genome[200_000:260_000]
+        with pytest.raises(RuntimeError, match="not found in the index"):
+            ix.min_unique_segment(chimera, len(chimera), 20, 200)
+        before = ix.guard_segments()
+        piece = genome[50_000:250_000]
+        oracle = rd.OracleIndex([genome])
+        got, _ = ix.min_unique_segment(piece, len(piece), 20, 200)
+        assert ix.guard_segments() == before + 1
+        assert np.array_equal(got, rd.closed_form_min_unique(piece, oracle, 20, 200))
+        got, _ = ix.fixed_k_segment(piece, len(piece), [36])
+        want, _ = rd.linear_search_segment(oracle, rd.Segment(b"p", piece, True, 0), [36], 36, np.uint8)
+        assert np.array_equal(got, want)
+        # --initial-search-length shapes the schedule the guard replays, never a result
+        got2, _ = ix.min_unique_segment(piece, len(piece), 20, 200, initial_search_length=30)
+        assert np.array_equal(got2, got if False else rd.closed_form_min_unique(piece, oracle, 20, 200))
+
+
+def test_record_fingerprints_and_native_driver_guard(tmp_path, eng, monkeypatch):
+    """csrc/nm_hash.h end to end: the index lists its records' fingerprints; every path of the device (sites, one lane per
+    position, --norc, list mode) leaves the same fingerprint for the same positions, and segments cut at multiples of 64
+    join to the record's; the native driver -- parallel and streaming front-ends, any batch -- searches a FASTA that IS
+    the indexed genome without a single guard segment, raises for a FASTA with one substituted base (k = 36 list mode on
+    a small genome included), and sends records that merely are not indexed ones (a piece; a renamed, reordered file is
+    fine) through the guard without raising."""
+    from newmap_amd import _lib, engine
+    import torch
+    rng = np.random.default_rng(123)
+    r1 = bytearray(_random_dna(rng, 400_001))
+    r1[1000:1040] = b"N" * 40
+    r1[70_000:70_100] = bytes(r1[70_000:70_100]).lower()
+    r1, r2 = bytes(r1), _random_dna(rng, 12_345)
+    text = b">one\n" + b"\n".join(r1[i:i + 70] for i in range(0, len(r1), 70)) + b"\n>two\n" + r2 + b"\n"
+    fa, idx = _build_index(tmp_path, text, "fp")
+    SW = _lib.NM_STATUS_WORDS
+    with eng.Index(idx, 0) as ix:
+        lens, fps = ix.records()
+        want = sorted([(len(r), engine.fingerprint(r)) for r in (r1, r2)])
+        assert sorted(zip(lens.tolist(), fps.tolist())) == want
+        fp1 = engine.fingerprint(r1)
+        dev = torch.device("cuda", 0)
+        seq = torch.frombuffer(bytearray(r1), dtype=torch.uint8).to(dev)
+        out = torch.zeros(len(r1), dtype=torch.uint8, device=dev)
+        for mode in ("sites", "lanes", "norc", "list", "list3"):
+            for batch in (len(r1), 64 * 1000, 64 * 1563):
+                st = torch.zeros((len(r1) // batch + 2, SW), dtype=torch.int64, device=dev)
+                ix.set_kernel(1 if mode == "lanes" else 0)
+                joined = 0
+                for j, a in enumerate(range(0, len(r1), batch)):
+                    cnt = min(batch, len(r1) - a)
+                    kmax = {"list": 36, "list3": 50}.get(mode, 200)
+                    seg_len = min(len(r1), a + cnt + kmax - 1) - a
+                    if mode.startswith("list"):
+                        ix.fixed_k_segment_dev(seq.data_ptr() + a, seg_len, cnt, [36] if mode == "list" else [24, 36, 50], True, 1, out.data_ptr() + a, st.data_ptr() + 8 * SW * j)
+                    else:
+                        ix.min_unique_segment_dev(seq.data_ptr() + a, seg_len, cnt, 20, 200, mode != "norc", 1, out.data_ptr() + a, st.data_ptr() + 8 * SW * j)
+                    torch.cuda.synchronize()
+                    joined = (joined + engine.fingerprint_join(0, a, int(st[j, _lib.NM_STATUS_HASH].item()) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+                assert joined == fp1, (mode, batch)
+        ix.set_kernel(0)
+
+        def run(fasta, out_name, ks, is_range, batch, **env):
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            out_dir = tmp_path / out_name
+            out_dir.mkdir(exist_ok=True)
+            try:
+                return ix.search_fasta(fasta, out_dir, ks, is_range, True, batch), out_dir
+            finally:
+                for k_ in env:
+                    monkeypatch.delenv(k_)
+
+        for env in ({}, {"NEWMAP_AMD_STREAMING_DRIVER": "1"}):
+            for batch in (10_000_000, 64 * 777, 1000):                   # (1000: segments not at words of the record -> guard, no raise)
+                before = ix.guard_segments()
+                total, out_dir = run(fa, "same", [20, 200], True, batch, **env)
+                assert total["positions"] == len(r1) + len(r2)
+                assert (ix.guard_segments() == before) == (batch != 1000), (env, batch)
+        same_one = np.fromfile(tmp_path / "same" / "one.unique.uint8", dtype=np.uint8)
+        # a FASTA with the records renamed and reordered is still the indexed genome
+        fa2 = tmp_path / "renamed.fa"
+        fa2.write_bytes(b">b\n" + r2 + b"\n>a\n" + r1 + b"\n")
+        before = ix.guard_segments()
+        run(fa2, "renamed", [20, 200], True, 10_000_000)
+        assert ix.guard_segments() == before
+        assert np.array_equal(np.fromfile(tmp_path / "renamed" / "a.unique.uint8", dtype=np.uint8), same_one)
+        # one substituted base: the reference raises, so does the driver -- range mode and k = 36
+        snp = bytearray(r1)
+        snp[222_222] = ord("A") if r1[222_222] != ord("A") else ord("C")
+        fa3 = tmp_path / "snp.fa"
+        fa3.write_bytes(b">one\n" + bytes(snp) + b"\n>two\n" + r2 + b"\n")
+        for env in ({}, {"NEWMAP_AMD_STREAMING_DRIVER": "1"}):
+            for ks, is_range in (([20, 200], True), ([36], False), ([100], False)):
+                with pytest.raises(RuntimeError, match="not found in the index"):
+                    run(fa3, "snp", ks, is_range, 10_000_000, **env)
+        # a piece of a record: guarded, nothing absent, output = the corresponding stretch (away from the piece's end)
+        fa4 = tmp_path / "piece.fa"
+        fa4.write_bytes(b">piece\n" + r1[100_000:300_000] + b"\n")
+        before = ix.guard_segments()
+        run(fa4, "piece", [20, 200], True, 10_000_000)
+        assert ix.guard_segments() > before
+        got = np.fromfile(tmp_path / "piece" / "piece.unique.uint8", dtype=np.uint8)
+        assert np.array_equal(got[:150_000], same_one[100_000:250_000])
 
 
 def test_open_errors(tmp_path, eng):
@@ -333,6 +441,7 @@ def test_segments_on_several_streams_overlap_safely(tmp_path):
     A tandem-rich genome (side-stream probes, resolve walks) and a uniform one, cut into segments of uneven sizes and
     dealt over 1, 2, 3 and 6 streams (6 > lanes: the least recently used lane changes hands): every position equals the
     one-stream result, which equals the oracle; list mode likewise; per-segment status rows keep their own counts."""
+    from newmap_amd._lib import NM_STATUS_WORDS as SW      # one status row per segment
     import torch
     from newmap_amd import engine, synth
     tandem = synth.tandem_dna(1_500_000, 77).tobytes()
@@ -354,7 +463,7 @@ def test_segments_on_several_streams_overlap_safely(tmp_path):
             for n_streams in (1, 2, 3, 6):
                 streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
                 out = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
-                st = torch.zeros((len(cuts) - 1, 8), dtype=torch.int64, device=dev)
+                st = torch.zeros((len(cuts) - 1, SW), dtype=torch.int64, device=dev)
                 torch.cuda.synchronize()
                 for rounds in range(2):                                   # second round: every lane is reused while warm
                     for j, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
@@ -362,7 +471,7 @@ def test_segments_on_several_streams_overlap_safely(tmp_path):
                         seg_len = min(n, b + kmax - 1) - a
                         cnt = b - a if b < n else seg_len
                         ix.min_unique_segment_dev(seq.data_ptr() + a, seg_len, cnt, kmin, kmax, True, 1, out.data_ptr() + a,
-                                                  st.data_ptr() + 64 * j, streams[(j + rounds) % n_streams].cuda_stream)
+                                                  st.data_ptr() + 8 * SW * j, streams[(j + rounds) % n_streams].cuda_stream)
                 torch.cuda.synchronize()
                 results.append((out.cpu().numpy(), st.cpu().numpy()))
             assert np.array_equal(results[0][0], want), (kmin, kmax)
@@ -375,13 +484,13 @@ def test_segments_on_several_streams_overlap_safely(tmp_path):
             for n_streams in (1, 3):
                 streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
                 out = torch.zeros(n, dtype=torch.uint8, device=dev)
-                st = torch.zeros((len(cuts) - 1, 8), dtype=torch.int64, device=dev)
+                st = torch.zeros((len(cuts) - 1, SW), dtype=torch.int64, device=dev)
                 torch.cuda.synchronize()
                 for j, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
                     a, b = int(a), int(b)
                     seg_len = min(n, b + ks[0] - 1) - a
                     cnt = b - a if b < n else seg_len
-                    ix.fixed_k_segment_dev(seq.data_ptr() + a, seg_len, cnt, ks, True, 1, out.data_ptr() + a, st.data_ptr() + 64 * j,
+                    ix.fixed_k_segment_dev(seq.data_ptr() + a, seg_len, cnt, ks, True, 1, out.data_ptr() + a, st.data_ptr() + 8 * SW * j,
                                            streams[j % n_streams].cuda_stream)
                 torch.cuda.synchronize()
                 if want_l is None:
@@ -469,10 +578,35 @@ def _seam_minimality(ix, rec: bytes, out: np.ndarray, kmin: int, kmax: int, rng,
     return int(found.sum()), int(p0.size)
 
 
+def _oracle_windows(records, windows, kmin: int, kmax: int):
+    """ORACLE contact at full size.  `windows` = [(segment bytes incl. lookahead, engine output of its first positions)].
+    The claims an output makes about totals (oracle/ref_driver.py closed_form_claims: total == 1 at the reported length,
+    >= 2 one base shorter, >= 2 at U_p where 0 is reported -- together they pin the closed form of SURVEY.md Appendix
+    A.2 exactly) are checked against totals counted by the oracle's scan counter (or_scan_counts: ONE pass over all the
+    records of the genome with a hash of the queries' first kmin bases, forward + reverse complement; no index, no
+    suffix array -- nothing of the engine, nothing that a 6 G-symbol text rules out)."""
+    blob, starts, lens, rels = [], [], [], []
+    base = 0
+    for seg, out in windows:
+        st, ln, rel = rd.closed_form_claims(seg, out, kmin, kmax)
+        blob.append(seg)
+        starts.append(st + base)
+        lens.append(ln)
+        rels.append(rel)
+        base += len(seg)
+    starts, lens, rels = np.concatenate(starts), np.concatenate(lens), np.concatenate(rels)
+    tot = rd.scan_total_counts(records, b"".join(blob), starts, lens, kmin)
+    assert ((tot == 1) == (rels == 0)).all(), "a reported length is not the least unique one"
+    assert (tot[rels == 1] >= 2).all()
+    return int(starts.size)
+
+
 def test_config3_full_size_properties(tmp_path, eng, monkeypatch):
     """BASELINE configs[2] at FULL size -- 3.09 Gbp, 24 human-shaped records, 24:150, index built on the device (6.18 G BWT
     rows: every kernel runs in its > 2^31-row instantiation) -- and the north-star range 20:200 on the same index.
-    No CPU oracle holds a suffix array of 6 G symbols within this suite's time, so the checks are the properties the
+    No CPU oracle holds a suffix array of the 6 G-symbol both-strand text within this suite's time; the ORACLE is brought in
+    by its scan counter instead (_oracle_windows: three windows of 300 k positions per range, every claim of the output
+    checked against totals counted over all 24 records).  Beside it, the properties the
     domain offers: (1) minimality of sampled elements re-derived through the count seam, (2) batch independence
     (10 M launches == 100 M launches), (3) the sites == the one-lane-per-position kernel on a 20 M stretch (independent
     schedules of the arithmetic), with either quad table and with the coarse probes forced, (4) structural facts (the
@@ -486,7 +620,7 @@ def test_config3_full_size_properties(tmp_path, eng, monkeypatch):
     generate_fm_index(str(fa), str(idx), 8, 12, device=0)
     rng = np.random.default_rng(31)
     chr1, chr21 = recs[0][1].tobytes(), recs[20][1].tobytes()
-    del recs
+    all_records = [r[1] for r in recs]                     # (the oracle's scan counter reads them all)
     monkeypatch.setenv("NEWMAP_AMD_COARSE_MIN", "0")
     with eng.Index(idx, 0) as ix:
         info = ix.info()
@@ -502,6 +636,12 @@ def test_config3_full_size_properties(tmp_path, eng, monkeypatch):
             small, _ = ix.min_unique_segment(chr21, len(chr21), kmin, kmax)          # a whole record: the tail rule
             assert not small[-(kmin - 1):].any() and small[:-(kmin - 1)].min() >= kmin
             _seam_minimality(ix, chr21, small, kmin, kmax, rng, 20_000)
+            # the oracle on windows of this index's own genome: start and inside of chr1, the end of chr21 (tail rule included)
+            W = 300_000
+            n_claims = _oracle_windows(all_records, [(chr1[:W + kmax - 1], whole[:W]),
+                                                     (chr1[77_000_000:77_000_000 + W + kmax - 1], whole[77_000_000:77_000_000 + W]),
+                                                     (chr21[-W:], small[-W:])], kmin, kmax)
+            assert n_claims >= 3 * W - 3 * kmax
             # independent schedules on a 20 M stretch
             sub = chr1[40_000_000:60_000_000 + kmax - 1]
             ix.set_kernel(1)
@@ -561,6 +701,10 @@ def test_config5_full_size_properties(tmp_path, eng, monkeypatch):
         assert np.array_equal(np.concatenate(parts), whole)
         found, none = _seam_minimality(ix, rec[:n + kmax], whole, kmin, kmax, rng, 40_000)
         assert found > 10_000 and none > 10_000
+        # the oracle on three windows (tandem arrays, their ends, spacers): totals from one scan of the whole 1 Gbp record
+        W = 150_000
+        wins = [(rec[o:o + W + kmax - 1], whole[o:o + W]) for o in (0, 30_000_000, 77_700_000)]
+        _oracle_windows([rec], wins, kmin, kmax)
         sub = rec[30_000_000:34_000_000 + kmax - 1]
         ix.set_kernel(1)
         ix.set_repeat_probes(False)

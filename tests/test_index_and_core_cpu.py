@@ -11,6 +11,8 @@ import pytest
 from newmap_amd._c_newmap_generate_index import generate_fm_index
 from oracle import ref_driver as rd
 from tests.hostsim import HostSim
+from tests import hostsim as hs
+from pathlib import Path
 
 from pathlib import Path as _P
 ROOT_DIR = _P(__file__).resolve().parent.parent
@@ -303,6 +305,126 @@ def test_repeat_probes_decide_only_what_the_oracle_confirms(tmp_path):
         assert np.array_equal(with_coarse[closed].astype(np.int64), want[closed])
         assert int((closed[3000:9000] & (want[3000:9000] == 0)).sum()) >= int(((fine_only != 0xFFFFFFFF)[3000:9000] & (want[3000:9000] == 0)).sum())
         assert steps_coarse < steps_fine
+
+
+def _np_fingerprint(rec: bytes) -> int:
+    """csrc/nm_hash.h restated: per 64-base word t = mix(mix(mix(lo + K) ^ hi) ^ amb), H = sum of t(W) * R^W mod 2^64"""
+    M = (1 << 64) - 1
+    R, K = 0x9E3779B97F4A7C15, 0xD6E8FEB86659FD93
+
+    def mix(z):
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    code = {ord(c): i for i, c in enumerate("ACGT")}
+    code.update({ord(c.lower()): i for i, c in enumerate("ACGT")})
+    h, pw = 0, 1
+    for w in range(0, len(rec), 64):
+        lo = hi = amb = 0
+        for j, ch in enumerate(rec[w:w + 64]):
+            c = code.get(ch)
+            if c is None:
+                amb |= 1 << j
+            else:
+                lo |= (c & 1) << j
+                hi |= (c >> 1) << j
+        h = (h + mix(mix(mix((lo + K) & M) ^ hi) ^ amb) * pw) & M
+        pw = (pw * R) & M
+    return h
+
+
+def _record_table(idx) -> list[tuple[int, int]]:
+    raw = Path(idx).read_bytes()
+    n_records = int.from_bytes(raw[88:96], "little")
+    off = int.from_bytes(raw[672:680], "little")
+    return [(int.from_bytes(raw[off + 16 * i:off + 16 * i + 8], "little"), int.from_bytes(raw[off + 16 * i + 8:off + 16 * i + 16], "little"))
+            for i in range(n_records)]
+
+
+def test_record_fingerprints_in_the_index_file_and_from_segments(tmp_path):
+    """index format 2 (csrc/nm_hash.h): the record list of the file == the fingerprint computed in numpy == the C-ABI's host
+    loop == the per-word form the kernels use (tests/hostsim: nm_hash_segment_word over the encoded words), whole and joined
+    from arbitrary segments; case and the kind of ambiguity letter do not matter, a single substituted base always does."""
+    from newmap_amd import engine
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    r1 = bytearray(bytes(alpha[rng.integers(0, 4, 70001)]))
+    r1[100:140] = b"N" * 40
+    r1[5000:5003] = b"RYK"
+    r1[9000:9100] = bytes(r1[9000:9100]).lower()
+    r2 = bytes(alpha[rng.integers(0, 4, 129)])
+    r3 = b"ACGTN" * 13
+    text = b">a x\n" + b"\n".join(bytes(r1)[i:i + 61] for i in range(0, len(r1), 61)) + b"\n>empty\n>b\n" + r2 + b"\n>c\n" + r3 + b"\n"
+    fa = _write(tmp_path, text)
+    idx = tmp_path / "f.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    table = _record_table(idx)
+    recs = [bytes(r1), r2, r3]
+    assert table == [(len(r), _np_fingerprint(r)) for r in recs]
+    for r in recs:
+        fp = _np_fingerprint(r)
+        assert engine.fingerprint(r) == fp
+        assert hs.segment_hash(r, len(r)) == fp
+        cuts = sorted({0, len(r), *(64 * int(x) for x in rng.integers(0, len(r) // 64 + 1, 6))})
+        joined = 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            # a segment = the bytes from a on (lookahead and all), its positions = [0, b - a) -- as the drivers cut them, at
+            # multiples of 64 of the record
+            joined = (joined + engine.fingerprint_join(0, a, hs.segment_hash(r[a:min(len(r), b + 199)], b - a))) & 0xFFFFFFFFFFFFFFFF
+        assert joined == fp
+    assert _np_fingerprint(bytes(r1).upper().replace(b"R", b"N").replace(b"Y", b"X")) == table[0][1]
+    snp = bytearray(r1)
+    snp[33333] = ord("A") if snp[33333] != ord("A") else ord("C")
+    assert _np_fingerprint(bytes(snp)) != table[0][1]
+
+
+def test_exact_guard_raises_exactly_when_the_reference_driver_does(tmp_path):
+    """nm_ref_longest_probe / nm_guard_range_one / nm_guard_list_one (the search of a record that is not one of the indexed
+    ones): for sequences that differ from the indexed genome in several ways -- a substituted base, a chimeric join of
+    two indexed pieces, a piece of an indexed record, a foreign sequence -- the guard reports a position exactly when the
+    reference's driver (oracle/ref_driver.py: newmap/search.py:383-548, :551-644, zero check :699-722) raises."""
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    g = bytearray(bytes(alpha[rng.integers(0, 4, 6000)]))
+    g[1000:1600] = (bytes(alpha[rng.integers(0, 4, 9)]) * 70)[:600]     # a tandem array: long probes
+    g[3000:3400] = g[200:600]                                           # a repeat: lengths above kmin
+    g[4000:4004] = b"NNNN"
+    g = bytes(g)
+    fa = _write(tmp_path, b">g\n" + g + b"\n")
+    idx = tmp_path / "g.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    oracle = rd.OracleIndex([g])
+    sim = HostSim(idx, 0)
+    snp = bytearray(g)
+    snp[2500] = ord("A") if snp[2500] != ord("A") else ord("C")
+    snp2 = bytearray(g)
+    snp2[1300] = ord("A") if snp2[1300] != ord("A") else ord("C")       # inside the array
+    queries = {"same": g, "snp": bytes(snp), "snp in array": bytes(snp2), "chimera": g[100:900] + g[5000:5700],
+               "piece": g[2000:3900], "foreign": bytes(alpha[rng.integers(0, 4, 900)]), "piece with N": g[3800:4300]}
+
+    def reference_raises(q, fn):
+        try:
+            fn(q)
+            return False
+        except RuntimeError:
+            return True
+
+    for name, q in queries.items():
+        seg = rd.Segment(b"q", q, True, 0)
+        for kmin, kmax, init in ((20, 200, 0), (8, 30, 0), (24, 150, 0), (20, 255, 40), (20, 200, 25), (4, 10, 0)):
+            dt, _ = rd.output_dtype(kmax)
+            want = reference_raises(q, lambda qq: rd.binary_search_segment(oracle, seg, kmin, kmax, dt, True, init))
+            got = sim.guard(q, len(q), [kmin, kmax], True, init)
+            assert (got is not None) == want, (name, kmin, kmax, init, got)
+        for ks in ([36], [100], [12, 20, 30], [30, 12], [100, 36]):
+            dt, _ = rd.output_dtype(max(ks))
+            want = reference_raises(q, lambda qq: rd.linear_search_segment(oracle, seg, ks, max(ks), dt, True))
+            got = sim.guard(q, len(q), ks, False)
+            assert (got is not None) == want, (name, ks, got)
+        want = reference_raises(q, lambda qq: rd.binary_search_segment(oracle, seg, 20, 200, np.uint8, False, 0))   # --norc
+        assert (sim.guard(q, len(q), [20, 200], True, 0, use_rc=False) is not None) == want, name
+    assert sim.guard(g, len(g), [20, 200], True) is None and sim.guard(bytes(snp), len(snp), [20, 200], True) is not None
 
 
 def _brute_period(rec: bytes, P: int, length: int, umax: int = 256) -> int:

@@ -14,6 +14,9 @@ from pathlib import Path
 
 import numpy as np
 
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from newmap_amd import _lib  # noqa: E402
+
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
@@ -109,13 +112,13 @@ def main():
                             seq_t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
                             out_t = torch.full((n * eb,), 0xEE, dtype=torch.uint8, device="cuda")
                             starts = list(range(0, n, batch))
-                            st_t = torch.zeros((len(starts), 8), dtype=torch.int64, device="cuda")
+                            st_t = torch.zeros((len(starts), _lib.NM_STATUS_WORDS), dtype=torch.int64, device="cuda")
                             torch.cuda.synchronize()
                             for j, p in enumerate(starts):
                                 cnt = min(batch, n - p)
                                 seg_len = min(p + cnt + kmax - 1, n) - p
                                 fast.min_unique_segment_dev(seq_t.data_ptr() + p, seg_len, cnt, kmin, kmax, True, eb, out_t.data_ptr() + p * eb,
-                                                            st_t.data_ptr() + 64 * j, streams[int(rng.integers(0, len(streams)))].cuda_stream)
+                                                            st_t.data_ptr() + 8 * _lib.NM_STATUS_WORDS * j, streams[int(rng.integers(0, len(streams)))].cuda_stream)
                             torch.cuda.synchronize()
                             got = out_t.cpu().numpy().view(whole.dtype)
                             assert np.array_equal(got, whole), ("lanes", rnd, rid, kmin, kmax, batch, len(streams), mode)

@@ -13,6 +13,9 @@ from pathlib import Path
 
 import numpy as np
 
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from newmap_amd import _lib  # noqa: E402
+
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
@@ -41,7 +44,7 @@ def main():
     out_off = np.concatenate(([0], np.cumsum([(u.count + 15) // 16 * 16 for u in units]))).astype(np.int64)
     d_seq = torch.empty(int(seg_off[-1]), dtype=torch.uint8, device=dev)
     d_out = [torch.zeros(int(out_off[-1]), dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_status = torch.zeros((len(units), 8), dtype=torch.int64, device=dev)
+    d_status = torch.zeros((len(units), _lib.NM_STATUS_WORDS), dtype=torch.int64, device=dev)
     for u, o in zip(units, seg_off[:-1]):
         d_seq[int(o):int(o) + u.seg_len].copy_(torch.from_numpy(wl.record(u.record)[u.start:u.start + u.seg_len]))
     torch.cuda.synchronize()
@@ -51,7 +54,7 @@ def main():
         for i, u in enumerate(units):
             lane = i % lanes
             handles[lane].min_unique_segment_dev(sp + int(seg_off[i]), u.seg_len, u.count, KMIN, KMAX, True, 1,
-                                                 op + int(out_off[i]), st + 64 * i, streams[lane].cuda_stream)
+                                                 op + int(out_off[i]), st + 8 * _lib.NM_STATUS_WORDS * i, streams[lane].cuda_stream)
 
     res = {"config": a.config, "batch": a.batch, "segments": len(units), "tables": a.tables}
     for lanes in (1, 2, 1, 2):
@@ -83,7 +86,7 @@ def main():
             sp, op, st = d_seq.data_ptr(), out.data_ptr(), d_status.data_ptr()
             for i, u in enumerate(units):
                 ix.min_unique_segment_dev(sp + int(seg_off[i]), u.seg_len, u.count, KMIN, KMAX, True, 1,
-                                          op + int(out_off[i]), st + 64 * i, (s0 if i % 2 == 0 else s1).cuda_stream)
+                                          op + int(out_off[i]), st + 8 * _lib.NM_STATUS_WORDS * i, (s0 if i % 2 == 0 else s1).cuda_stream)
         for _ in range(3):                      # buffers of both lanes grown, latches settled
             one_pass(out_g, main_s, side_s)
         torch.cuda.synchronize()

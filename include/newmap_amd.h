@@ -136,6 +136,9 @@ int nm_upper_bound_segment(nm_index *ix, const uint8_t *seq, uint64_t seq_len, u
  * caller stream (up to 5; further streams take over the least recently used set behind an event), so calls given
  * different streams -- independent segments with their own d_out / d_status -- may overlap on the device.  Host-side the
  * calls on one handle are still made one at a time (nm_set_option / info likewise). */
+/* A caller that destroys a stream it has passed to the calls below first hands the stream's launch scratch back
+ * (waits for the stream, frees the lane for the next stream). */
+int nm_stream_release(nm_index *ix, void *stream);
 #define NM_STATUS_WORDS 16
 #define NM_STATUS_HASH 8           /* [8]: fingerprint of the segment's num_kmers positions (csrc/nm_hash.h); the
                                       driver joins the segments of a record (nm_hash_join) and asks nm_index_has_record */

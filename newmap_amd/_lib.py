@@ -14,6 +14,7 @@ NM_OK = 0
 NM_E_FILE_OPEN, NM_E_ALLOC, NM_E_FILE_EXISTS, NM_E_FILE_WRITE, NM_E_FILE_FORMAT = 1, 2, 3, 4, 5
 NM_E_ARGUMENT, NM_E_DEVICE, NM_E_KMER_NOT_FOUND, NM_E_TOO_LARGE = 6, 7, 8, 9
 NM_STATUS_WORDS = 16
+NM_STATUS_HASH = 8
 NM_OPT_COUNT_STEPS = 1
 NM_OPT_TIMING = 3
 NM_OPT_KERNEL = 4
@@ -34,7 +35,7 @@ EXPORTS = [
     "nm_fixed_k_segment_dev", "nm_set_option", "nm_dev_alloc", "nm_dev_free", "nm_dev_upload",
     "nm_dev_download", "nm_dev_sync", "nm_device_count", "nm_timing_read", "nm_timing_read_kind", "nm_search_fasta", "nm_search_fasta_shard", "nm_track_file", "nm_search_segment_multi", "nm_index_build_device",
     "nm_index_has_record", "nm_index_records", "nm_fingerprint_join", "nm_fingerprint_sequence", "nm_guard_segment_dev", "nm_guard_segment",
-    "nm_search_fasta_shard_ex", "nm_guard_fasta",
+    "nm_search_fasta_shard_ex", "nm_guard_fasta", "nm_stream_release",
 ]
 
 _lib = None
@@ -146,6 +147,8 @@ def lib():
     L.nm_search_fasta_shard_ex.argtypes = L.nm_search_fasta_shard.argtypes + [vp, u64, c.POINTER(u64)]
     L.nm_guard_fasta.restype = i32
     L.nm_guard_fasta.argtypes = [vp, c.c_char_p, vp, u32, i32, i32, u64, c.POINTER(c.c_char_p), u32, c.POINTER(c.c_char_p), u32, vp, u64]
+    L.nm_stream_release.restype = i32
+    L.nm_stream_release.argtypes = [vp, vp]
     L.nm_search_segment_multi.restype = i32
     L.nm_search_segment_multi.argtypes = [vp, u32, vp, u32, u64, u64, vp, u32, i32, i32, i32, vp, vp, vp]
     L.nm_track_file.restype = i32

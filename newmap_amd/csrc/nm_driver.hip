@@ -437,11 +437,6 @@ struct FastDriver {
     std::vector<FastRecord> recs;
     std::deque<FastFile> files;
     std::vector<FastSlot> slots;
-    // slot hand-over: main -> writers (jobs), writers -> main (free)
-    std::mutex mu;
-    std::condition_variable cv_job, cv_free;
-    std::deque<int> jobs, free_slots;
-    bool closing = false;
     std::atomic<int> error{NM_OK};
     std::string error_text;
     std::mutex sum_mu;
@@ -453,62 +448,6 @@ struct FastDriver {
         if (error.compare_exchange_strong(expect, code)) { std::lock_guard<std::mutex> g(sum_mu); error_text = text; }
     }
 };
-
-void fast_writer(FastDriver *d) {
-    (void)hipSetDevice(d->device);
-    for (;;) {
-        int si;
-        {
-            std::unique_lock<std::mutex> lk(d->mu);
-            d->cv_job.wait(lk, [&] { return !d->jobs.empty() || d->closing; });
-            if (d->jobs.empty()) return;
-            si = d->jobs.front();
-            d->jobs.pop_front();
-        }
-        FastSlot &s = d->slots[si];
-        const FastRecord &r = d->recs[s.rec];
-        FastFile &f = d->files[r.file];
-        if (hipEventSynchronize(s.done) != hipSuccess) d->fail(NM_E_DEVICE, "waiting for a segment failed");
-        else if (d->error.load() == NM_OK) {
-            if (s.h_status[1]) {
-                const uint64_t at = s.h_status[2] < s.seg_len ? s.h_status[2] : 0;
-                const uint64_t len = s.seg_len - at < d->kmin ? s.seg_len - at : d->kmin;
-                char buf[1024];
-                snprintf(buf, sizeof buf, "The following generated k-mer was not found in the index:\n%.*s\nPossibly a mismatch between the "
-                         "sequence and the index. (record '%s', position %llu)", (int)len, (const char *)s.h_in + at,   // newmap/search.py:719-722
-                         r.id.c_str(), (unsigned long long)(s.rec_start + at));
-                d->fail(NM_E_KMER_NOT_FOUND, buf);
-            } else {
-                const uint64_t bytes = s.count * (uint64_t)d->elem_bytes;
-                uint64_t off = (r.file_offset + s.rec_start) * (uint64_t)d->elem_bytes, done = 0;
-                while (done < bytes) {
-                    const ssize_t w = pwrite(f.fd, s.h_out + done, bytes - done, (off_t)(off + done));
-                    if (w < 0) { if (errno == EINTR) continue; d->fail(NM_E_FILE_WRITE, "could not write " + f.path + ": " + strerror(errno)); break; }
-                    done += (uint64_t)w;
-                }
-                std::lock_guard<std::mutex> g(d->sum_mu);
-                d->rec_hash[(size_t)s.rec] += nm_hash_pow(s.rec_start >> 6) * s.h_status[NM_STATUS_HASH];
-                if (s.rec_start & 63u) d->rec_unaligned[(size_t)s.rec] = 1;   // (cannot be joined: the record goes to the guard)
-                nm_search_summary &rs = f.sum;                 // newmap/search.py:331-347
-                const uint64_t uniq = s.h_sum[0];
-                rs.positions += s.count;
-                rs.ambiguous += s.h_status[0];
-                rs.unique += uniq;
-                rs.no_unique += s.count - uniq - s.h_status[0];
-                if (uniq) {
-                    if ((uint32_t)s.h_sum[1] > rs.max_len) rs.max_len = (uint32_t)s.h_sum[1];
-                    if ((uint32_t)s.h_sum[2] < rs.min_len) rs.min_len = (uint32_t)s.h_sum[2];
-                }
-            }
-        }
-        --f.outstanding;
-        {
-            std::lock_guard<std::mutex> g(d->mu);
-            d->free_slots.push_back(si);
-        }
-        d->cv_free.notify_one();
-    }
-}
 
 // returns NM_OK, an error, or -1 when this front-end does not apply (gzip input, a file that cannot be mapped)
 // rec_info (may be null): per record WITH data, in file order, {length, fingerprint summed over THIS rank's units, 1 if the
@@ -624,33 +563,54 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
             if (hi > lo) ranges.push_back({lo, hi});
         }
     }
-    // ---- device side
-    // slots in flight = writer threads: a writer spends ~4 ms in pwrite per 10 MB segment, the GPU ~1 ms on it
-    int n_slots = d.batch <= (32u << 20) ? 8 : 4;
-    if (const char *e = getenv("NEWMAP_AMD_DRIVER_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= 32) n_slots = v; }
-    const int n_writers = n_slots;
-    int n_ready = 0;                                          // slots that were fully allocated
+    // ---- the units of my ranges, in file order
+    struct Unit { int rec; uint64_t start, count, seg_len; };
+    std::vector<Unit> units;
+    std::vector<long> file_units(d.files.size(), 0);
+    for (size_t ri = 0; ri < d.recs.size() && rc == NM_OK; ri++) {
+        FastRecord &rec = d.recs[ri];
+        if (rec.file < 0) continue;
+        for (auto &rg : ranges) {
+            const uint64_t lo = rg.first > rec.global ? rg.first : rec.global;
+            const uint64_t hi = rg.second < rec.global + rec.n_bases ? rg.second : rec.global + rec.n_bases;
+            // (a part starts and ends at a multiple of 64 bases of its record -- or at the record's end --, so that the segments'
+            // fingerprints can be joined (nm_hash.h); every rank rounds a shared boundary the same way)
+            auto word_edge = [&](uint64_t x) { return x == rec.n_bases ? x : x & ~63ull; };
+            if (hi <= lo) continue;
+            const uint64_t first = word_edge(lo - rec.global), last = word_edge(hi - rec.global);
+            for (uint64_t p = first; p < last; p += d.batch) {
+                const uint64_t count = last - p < d.batch ? last - p : d.batch;
+                units.push_back({(int)ri, p, count, (p + count + d.lookahead < rec.n_bases ? p + count + d.lookahead : rec.n_bases) - p});
+                file_units[rec.file]++;
+            }
+        }
+    }
+    // ---- workers.  Every worker owns one slot (pinned input / output, device buffers, an event) and takes the units in
+    // turn: it strips the unit's lines straight into its pinned buffer, submits copy-in, kernels and copy-out (one
+    // worker at a time: the handle's calls are made one by one), waits for its event and pwrite()s the result into the
+    // record's file.  Strip, transfers, kernels and file writes of different units overlap; nothing is staged twice.
+    int n_workers = d.batch <= (32u << 20) ? 12 : 4;
+    if (const char *e = getenv("NEWMAP_AMD_DRIVER_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_workers = v; }
+    if ((size_t)n_workers > units.size()) n_workers = units.empty() ? 1 : (int)units.size();
+    const size_t piece_slack = 2 * nm_fasta::kPieceBytes + 4096;    // a unit is stripped piece-wise: whole pieces around it
     const uint64_t in_bytes = d.batch + d.lookahead + 64, out_bytes = d.batch * (uint64_t)d.elem_bytes + 64;
-    std::vector<std::thread> writers;
-    std::vector<uint8_t> rec_buf;
     auto hip_ok = [&](hipError_t e, const char *what) {
         if (e == hipSuccess) return true;
-        nm_set_error("HIP error %d (%s): %s", (int)e, hipGetErrorString(e), what);
-        rc = NM_E_DEVICE;
+        d.fail(NM_E_DEVICE, std::string("HIP error (") + hipGetErrorString(e) + "): " + what);
         return false;
     };
     const char *one_stream = getenv("NEWMAP_AMD_DRIVER_STREAMS");
     const bool two_streams = !(one_stream && one_stream[0] == '1');
     const bool phase_times = getenv("NEWMAP_AMD_DRIVER_TIMING") != nullptr;
-    double t_strip = 0, t_copy = 0, t_slot = 0, t_submit = 0;
+    std::atomic<uint64_t> t_strip_us{0}, t_submit_us{0}, t_wait_us{0}, t_write_us{0};
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     if (rc == NM_OK && hip_ok(hipSetDevice(d.device), "hipSetDevice") && hip_ok(hipStreamCreate(&d.stream), "hipStreamCreate") &&
         (!two_streams || hip_ok(hipStreamCreate(&d.stream2), "hipStreamCreate"))) {
-        d.slots.resize(n_slots);
-        for (int i = 0; i < n_slots && rc == NM_OK; i++) {
+        d.slots.resize(n_workers);
+        for (int i = 0; i < n_workers; i++) {
             FastSlot &s = d.slots[i];
-            if (!hip_ok(hipHostMalloc((void **)&s.h_in, in_bytes, hipHostMallocDefault), "pinned input") ||
+            if (!hip_ok(hipHostMalloc((void **)&s.h_in, in_bytes + piece_slack, hipHostMallocDefault), "pinned input") ||
                 !hip_ok(hipHostMalloc((void **)&s.h_out, out_bytes, hipHostMallocDefault), "pinned output") ||
                 !hip_ok(hipHostMalloc((void **)&s.h_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t), hipHostMallocDefault), "pinned status") ||
                 !hip_ok(hipMalloc(&s.d_in, in_bytes), "device input") || !hip_ok(hipMalloc(&s.d_out, out_bytes), "device output") ||
@@ -658,20 +618,108 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
                 !hip_ok(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "event")) break;
             s.h_sum = s.h_status + NM_STATUS_WORDS;
             s.d_sum = s.d_status + NM_STATUS_WORDS;
-            d.free_slots.push_back(i);
-            n_ready++;
         }
     }
-    if (rc == NM_OK) for (int i = 0; i < n_writers; i++) writers.emplace_back(fast_writer, &d);
-
-    // ---- the units of my ranges, record by record
-    std::vector<long> file_units(d.files.size(), 0);
+    if (rc == NM_OK && d.error.load() != NM_OK) rc = d.error.load();
+    std::atomic<size_t> next_unit{0};
+    std::vector<std::atomic<long>> file_done(d.files.size());
+    for (auto &x : file_done) x = 0;
+    std::mutex submit_mu, done_mu;
+    std::condition_variable done_cv;
+    size_t units_done = 0;
+    auto worker = [&](int si) {
+        (void)hipSetDevice(d.device);
+        FastSlot &s = d.slots[si];
+        hipStream_t st = (si & 1) && d.stream2 ? d.stream2 : d.stream;
+        for (size_t ui; (ui = next_unit.fetch_add(1)) < units.size();) {
+            const Unit &u = units[ui];
+            const FastRecord &r = d.recs[u.rec];
+            FastFile &f = d.files[r.file];
+            if (d.error.load() == NM_OK) {
+                double t0 = now();
+                uint64_t buf_base = nm_fasta::materialize_into(r, u.start, u.start + u.seg_len, s.h_in, in_bytes + piece_slack);
+                if (buf_base == ~0ULL) {                              // (lines far longer than a piece: strip aside, keep what is needed)
+                    std::vector<uint8_t> tmp;
+                    const uint64_t tb = nm_fasta::materialize(r, u.start, u.start + u.seg_len, 1, tmp);
+                    memcpy(s.h_in, tmp.data() + (u.start - tb), u.seg_len);
+                    buf_base = u.start;
+                }
+                const uint8_t *src = s.h_in + (u.start - buf_base);
+                t_strip_us += (uint64_t)((now() - t0) * 1e6);
+                s.rec = u.rec; s.rec_start = u.start; s.count = u.count; s.seg_len = u.seg_len;
+                t0 = now();
+                bool ok;
+                {
+                    std::lock_guard<std::mutex> g(submit_mu);
+                    ok = hip_ok(hipMemcpyAsync(s.d_in, src, u.seg_len, hipMemcpyHostToDevice, st), "copy to device");
+                    if (ok) {
+                        const int e = d.range_mode
+                            ? nm_min_unique_segment_dev(d.ix, s.d_in, u.seg_len, u.count, d.kmin, d.kmax, d.use_rc, d.elem_bytes, s.d_out, s.d_status, st)
+                            : nm_fixed_k_segment_dev(d.ix, s.d_in, u.seg_len, u.count, d.ks.data(), (uint32_t)d.ks.size(), d.use_rc, d.elem_bytes, s.d_out, s.d_status, st);
+                        if (e != NM_OK) { d.fail(e, nm_last_error()); ok = false; }
+                    }
+                    if (ok) {
+                        ok = hip_ok(hipMemsetAsync(s.d_sum, 0, 16, st), "summary reset") &&             // count, largest
+                             hip_ok(hipMemsetAsync(s.d_sum + 2, 0xFF, 8, st), "summary reset");        // smallest non-zero
+                        const unsigned grid = (unsigned)((u.count + 256 * 16 - 1) / (256 * 16) < 2048 ? (u.count + 256 * 16 - 1) / (256 * 16) : 2048);
+                        if (d.elem_bytes == 1) hipLaunchKernelGGL(k_out_summary<uint8_t>, dim3(grid ? grid : 1), dim3(256), 0, st, (const uint8_t *)s.d_out, u.count, (unsigned long long *)s.d_sum);
+                        else if (d.elem_bytes == 2) hipLaunchKernelGGL(k_out_summary<uint16_t>, dim3(grid ? grid : 1), dim3(256), 0, st, (const uint16_t *)s.d_out, u.count, (unsigned long long *)s.d_sum);
+                        else hipLaunchKernelGGL(k_out_summary<uint32_t>, dim3(grid ? grid : 1), dim3(256), 0, st, (const uint32_t *)s.d_out, u.count, (unsigned long long *)s.d_sum);
+                        ok = ok && hip_ok(hipMemcpyAsync(s.h_out, s.d_out, u.count * (uint64_t)d.elem_bytes, hipMemcpyDeviceToHost, st), "copy from device") &&
+                             hip_ok(hipMemcpyAsync(s.h_status, s.d_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t), hipMemcpyDeviceToHost, st), "status copy") &&
+                             hip_ok(hipEventRecord(s.done, st), "event record");
+                    }
+                }
+                t_submit_us += (uint64_t)((now() - t0) * 1e6);
+                t0 = now();
+                if (ok && hipEventSynchronize(s.done) != hipSuccess) { d.fail(NM_E_DEVICE, "waiting for a segment failed"); ok = false; }
+                t_wait_us += (uint64_t)((now() - t0) * 1e6);
+                t0 = now();
+                if (ok && d.error.load() == NM_OK) {
+                    if (s.h_status[1]) {
+                        const uint64_t at = s.h_status[2] < s.seg_len ? s.h_status[2] : 0;
+                        const uint64_t len = s.seg_len - at < d.kmin ? s.seg_len - at : d.kmin;
+                        char buf[1024];
+                        snprintf(buf, sizeof buf, "The following generated k-mer was not found in the index:\n%.*s\nPossibly a mismatch between the "
+                                 "sequence and the index. (record '%s', position %llu)", (int)len, (const char *)src + at,   // newmap/search.py:719-722
+                                 r.id.c_str(), (unsigned long long)(s.rec_start + at));
+                        d.fail(NM_E_KMER_NOT_FOUND, buf);
+                    } else {
+                        const uint64_t bytes = s.count * (uint64_t)d.elem_bytes;
+                        uint64_t off = (r.file_offset + s.rec_start) * (uint64_t)d.elem_bytes, done = 0;
+                        while (done < bytes) {
+                            const ssize_t w = pwrite(f.fd, s.h_out + done, bytes - done, (off_t)(off + done));
+                            if (w < 0) { if (errno == EINTR) continue; d.fail(NM_E_FILE_WRITE, "could not write " + f.path + ": " + strerror(errno)); break; }
+                            done += (uint64_t)w;
+                        }
+                        std::lock_guard<std::mutex> g(d.sum_mu);
+                        d.rec_hash[(size_t)s.rec] += nm_hash_pow(s.rec_start >> 6) * s.h_status[NM_STATUS_HASH];
+                        if (s.rec_start & 63u) d.rec_unaligned[(size_t)s.rec] = 1;   // (cannot be joined: the record goes to the guard)
+                        nm_search_summary &rs = f.sum;                 // newmap/search.py:331-347
+                        const uint64_t uniq = s.h_sum[0];
+                        rs.positions += s.count;
+                        rs.ambiguous += s.h_status[0];
+                        rs.unique += uniq;
+                        rs.no_unique += s.count - uniq - s.h_status[0];
+                        if (uniq) {
+                            if ((uint32_t)s.h_sum[1] > rs.max_len) rs.max_len = (uint32_t)s.h_sum[1];
+                            if ((uint32_t)s.h_sum[2] < rs.min_len) rs.min_len = (uint32_t)s.h_sum[2];
+                        }
+                    }
+                }
+                t_write_us += (uint64_t)((now() - t0) * 1e6);
+            }
+            file_done[r.file]++;
+            { std::lock_guard<std::mutex> g(done_mu); units_done++; }
+            done_cv.notify_one();
+        }
+    };
     size_t next_report = 0;
     auto report_ready = [&]() {                                 // per-file summaries, in file order, as soon as a file has drained
         while (next_report < d.files.size()) {
             FastFile &f = d.files[next_report];
             if (f.n_elems) {
-                if (!f.submitted_all.load() || f.outstanding.load() != 0) break;
+                if (file_done[next_report].load() != file_units[next_report]) break;
                 f.sum.records = 1;
                 if (cb && d.error.load() == NM_OK && (world <= 1 || file_units[next_report])) cb(f.id.c_str(), &f.sum, user);
                 f.reported = true;
@@ -679,94 +727,18 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
             next_report++;
         }
     };
-    for (size_t ri = 0; ri < d.recs.size() && rc == NM_OK && d.error.load() == NM_OK; ri++) {
-        FastRecord &rec = d.recs[ri];
-        if (rec.file < 0) continue;
-        // the parts of my ranges inside this record
-        std::vector<std::pair<uint64_t, uint64_t>> mine;
-        for (auto &rg : ranges) {
-            const uint64_t lo = rg.first > rec.global ? rg.first : rec.global;
-            const uint64_t hi = rg.second < rec.global + rec.n_bases ? rg.second : rec.global + rec.n_bases;
-            // (a part starts and ends at a multiple of 64 bases of its record -- or at the record's end --, so that the segments'
-            // fingerprints can be joined (nm_hash.h); every rank rounds a shared boundary the same way)
-            auto word_edge = [&](uint64_t x) { return x == rec.n_bases ? x : x & ~63ull; };
-            if (hi > lo && word_edge(hi - rec.global) > word_edge(lo - rec.global)) mine.push_back({word_edge(lo - rec.global), word_edge(hi - rec.global)});
+    std::vector<std::thread> workers;
+    if (rc == NM_OK) {
+        for (int i = 0; i < n_workers; i++) workers.emplace_back(worker, i);
+        std::unique_lock<std::mutex> lk(done_mu);
+        while (units_done < units.size()) {
+            done_cv.wait(lk);
+            lk.unlock();
+            report_ready();
+            lk.lock();
         }
-        for (auto &part : mine) {
-            // strip the pieces that hold [part.first, part.second + lookahead) into rec_buf
-            const uint64_t need_hi = part.second + d.lookahead < rec.n_bases ? part.second + d.lookahead : rec.n_bases;
-            double t0 = now();
-            const uint64_t buf_base = nm_fasta::materialize(rec, part.first, need_hi, threads, rec_buf);
-            t_strip += now() - t0;
-            for (uint64_t p = part.first; p < part.second && rc == NM_OK && d.error.load() == NM_OK; p += d.batch) {
-                const uint64_t count = part.second - p < d.batch ? part.second - p : d.batch;
-                const uint64_t seg_len = (p + count + d.lookahead < rec.n_bases ? p + count + d.lookahead : rec.n_bases) - p;
-                int si;
-                t0 = now();
-                {
-                    std::unique_lock<std::mutex> lk(d.mu);
-                    d.cv_free.wait(lk, [&] { return !d.free_slots.empty(); });
-                    si = d.free_slots.front();
-                    d.free_slots.pop_front();
-                }
-                t_slot += now() - t0;
-                FastSlot &s = d.slots[si];
-                s.rec = (int)ri; s.rec_start = p; s.count = count; s.seg_len = seg_len;
-                const uint8_t *src = rec_buf.data() + (p - buf_base);
-                const size_t cp = 2u << 20;
-                t0 = now();
-                parallel_for((seg_len + cp - 1) / cp, seg_len > (4u << 20) ? 8 : 1, [&](size_t k) {
-                    const size_t o = k * cp, m = seg_len - o < cp ? seg_len - o : cp;
-                    memcpy(s.h_in + o, src + o, m);
-                });
-                t_copy += now() - t0;
-                t0 = now();
-                hipStream_t st = (si & 1) && d.stream2 ? d.stream2 : d.stream;
-                bool ok = hip_ok(hipMemcpyAsync(s.d_in, s.h_in, seg_len, hipMemcpyHostToDevice, st), "copy to device");
-                if (ok) {
-                    const int e = d.range_mode
-                        ? nm_min_unique_segment_dev(d.ix, s.d_in, seg_len, count, d.kmin, d.kmax, d.use_rc, d.elem_bytes, s.d_out, s.d_status, st)
-                        : nm_fixed_k_segment_dev(d.ix, s.d_in, seg_len, count, d.ks.data(), (uint32_t)d.ks.size(), d.use_rc, d.elem_bytes, s.d_out, s.d_status, st);
-                    if (e != NM_OK) { rc = e; ok = false; }
-                }
-                if (ok) {
-                    ok = hip_ok(hipMemsetAsync(s.d_sum, 0, 16, st), "summary reset") &&             // count, largest
-                         hip_ok(hipMemsetAsync(s.d_sum + 2, 0xFF, 8, st), "summary reset");        // smallest non-zero
-                    const unsigned grid = (unsigned)((count + 256 * 16 - 1) / (256 * 16) < 2048 ? (count + 256 * 16 - 1) / (256 * 16) : 2048);
-                    if (d.elem_bytes == 1) hipLaunchKernelGGL(k_out_summary<uint8_t>, dim3(grid ? grid : 1), dim3(256), 0, st, (const uint8_t *)s.d_out, count, (unsigned long long *)s.d_sum);
-                    else if (d.elem_bytes == 2) hipLaunchKernelGGL(k_out_summary<uint16_t>, dim3(grid ? grid : 1), dim3(256), 0, st, (const uint16_t *)s.d_out, count, (unsigned long long *)s.d_sum);
-                    else hipLaunchKernelGGL(k_out_summary<uint32_t>, dim3(grid ? grid : 1), dim3(256), 0, st, (const uint32_t *)s.d_out, count, (unsigned long long *)s.d_sum);
-                    ok = ok && hip_ok(hipMemcpyAsync(s.h_out, s.d_out, count * (uint64_t)d.elem_bytes, hipMemcpyDeviceToHost, st), "copy from device") &&
-                         hip_ok(hipMemcpyAsync(s.h_status, s.d_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t), hipMemcpyDeviceToHost, st), "status copy") &&
-                         hip_ok(hipEventRecord(s.done, st), "event record");
-                }
-                t_submit += now() - t0;
-                if (!ok) {                                         // give the slot back, stop
-                    std::lock_guard<std::mutex> g(d.mu);
-                    d.free_slots.push_back(si);
-                    break;
-                }
-                d.files[rec.file].outstanding++;
-                file_units[rec.file]++;
-                {
-                    std::lock_guard<std::mutex> g(d.mu);
-                    d.jobs.push_back(si);
-                }
-                d.cv_job.notify_one();
-                report_ready();
-            }
-        }
-        if (d.files[rec.file].last_record == (int)ri) d.files[rec.file].submitted_all = true;
     }
-    for (FastFile &f : d.files) f.submitted_all = true;         // (records this rank has no share of, early exits)
-    // ---- drain
-    {
-        std::unique_lock<std::mutex> lk(d.mu);
-        d.cv_free.wait(lk, [&] { return (int)d.free_slots.size() == n_ready; });
-        d.closing = true;
-    }
-    d.cv_job.notify_all();
-    for (auto &w : writers) w.join();
+    for (auto &w : workers) w.join();
     if (rc == NM_OK && d.error.load() != NM_OK) { rc = d.error.load(); nm_set_error("%s", d.error_text.c_str()); }
     for (FastFile &f : d.files) if (f.fd >= 0) { if (close(f.fd) != 0 && rc == NM_OK) { nm_set_error("could not close %s: %s", f.path.c_str(), strerror(errno)); rc = NM_E_FILE_WRITE; } f.fd = -1; }
     for (FastSlot &s : d.slots) {
@@ -778,12 +750,12 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         if (s.d_status) (void)hipFree(s.d_status);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    if (d.stream) (void)hipStreamDestroy(d.stream);
-    if (d.stream2) (void)hipStreamDestroy(d.stream2);
+    if (d.stream) { (void)nm_stream_release(ix, d.stream); (void)hipStreamDestroy(d.stream); }
+    if (d.stream2) { (void)nm_stream_release(ix, d.stream2); (void)hipStreamDestroy(d.stream2); }
     unmap();
     if (phase_times)
-        fprintf(stderr, "[driver] total %.3fs: strip %.3f, copy to pinned %.3f, wait for a slot %.3f, submit %.3f (main thread)\n",
-                now() - t_begin, t_strip, t_copy, t_slot, t_submit);
+        fprintf(stderr, "[driver] total %.3fs, %d workers, %zu units; summed over the workers: strip %.3f, submit %.3f, wait for the device %.3f, write %.3f s\n",
+                now() - t_begin, n_workers, units.size(), t_strip_us.load() * 1e-6, t_submit_us.load() * 1e-6, t_wait_us.load() * 1e-6, t_write_us.load() * 1e-6);
     if (rc != NM_OK) return rc;
     if (rec_info) {
         rec_info->clear();
@@ -858,6 +830,7 @@ static int guard_pass(nm_index *ix, const char *fasta_path, const uint32_t *ks, 
         else if (s.busy) (void)hipEventSynchronize(s.done);
     }
     for (auto &s : d.slots) free_slot(s);
+    (void)nm_stream_release(ix, d.stream);
     (void)hipStreamDestroy(d.stream);
     return rc;
 }
@@ -965,6 +938,7 @@ static int search_fasta_impl(nm_index *ix, const char *fasta_path, const char *o
         }
     }
     for (auto &s : d.slots) free_slot(s);
+    (void)nm_stream_release(ix, d.stream);
     (void)hipStreamDestroy(d.stream);
     return rc;
 }

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
                                                          uint64_t num_kmers, uint32_t kmin, uint32_t kmax, uint32_t d, void *__restrict__ out,
                                                          int elem_bytes, uint64_t *__restrict__ status, uint64_t *__restrict__ need,
                                                          unsigned long long *__restrict__ work,
-                                                         const uint32_t *__restrict__ list, uint32_t n_list, int hash_on) {
+                                                         const uint32_t *__restrict__ list, uint32_t n_list, uint64_t *__restrict__ hash_part) {
     extern __shared__ uint64_t s_mem[];
     __shared__ uint32_t s_open_total, s_qn;
     __shared__ uint32_t s_q[NM_SITE_CHANCE_MAX];
@@ -436,12 +436,21 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
     for (uint32_t i = tid; i < BP / 16; i += NM_SITE_BLOCK) s_set[i] = 0;          // both bitmaps
     if (tid == 0) { s_open_total = 0; s_qn = 0; }
     __syncthreads();
-    // the fingerprint of the block's own positions (nm_hash.h; status[NM_STATUS_HASH] of the segment sums all blocks)
-    if (hash_on) {
+    // the fingerprint of the block's own positions (nm_hash.h): one partial sum per block, no atomics -- tens of thousands of
+    // blocks adding to ONE status word took as long as the lookups; k_resolve's first block adds the partials up
+    if (hash_part) {
+        __shared__ uint64_t s_hash[NM_SITE_BLOCK / NM_WAVE];
         uint64_t term = 0;
         for (uint32_t i = tid; i < BP / 64; i += NM_SITE_BLOCK) term += nm_hash_segment_word(ix.hash_tab, s_enc[i], w0 + i, num_kmers);
-        for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, NM_WAVE);
-        if ((tid & 63) == 0 && term) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)term);
+        if (BP / 64 > NM_WAVE) {                                       // (more words than one wave: the waves meet in LDS)
+            for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, NM_WAVE);
+            if ((tid & 63) == 0) s_hash[tid >> 6] = term;
+            __syncthreads();
+            if (tid == 0) hash_part[blockIdx.x] = s_hash[0] + s_hash[1] + s_hash[2] + s_hash[3];
+        } else if (tid < NM_WAVE) {
+            for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, NM_WAVE);
+            if (tid == 0) hash_part[blockIdx.x] = term;
+        }
     }
     // the block's own words go to the segment's encoded array; the last block also writes what follows its stretch
     // (lookahead and padding words of the segment)
@@ -621,7 +630,14 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
                                                           uint64_t *__restrict__ status, const uint64_t *__restrict__ need,
                                                           uint64_t n_need, const uint32_t *__restrict__ probe,
                                                           const unsigned long long *__restrict__ work,
-                                                          uint64_t seq_len, const uint32_t *__restrict__ list, uint32_t n_list) {
+                                                          uint64_t seq_len, const uint32_t *__restrict__ list, uint32_t n_list,
+                                                          const uint64_t *__restrict__ hash_part, uint32_t n_hash_part) {
+    if (hash_part && blockIdx.x == 0) {                    // the segment's fingerprint: the partial sums of k_sites' blocks (nm_hash.h)
+        uint64_t term = 0;
+        for (uint32_t i = threadIdx.x; i < n_hash_part; i += NM_RES_BLOCK) term += hash_part[i];
+        for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, NM_WAVE);
+        if ((threadIdx.x & 63) == 0 && term) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)term);
+    }
     if (work[NM_WORK_OPEN] == 0) return;                   // every block of k_sites finished its own positions
     __shared__ uint32_t q_p[NM_RES_QCAP];
     __shared__ uint32_t q_n;
@@ -796,10 +812,18 @@ __global__ __launch_bounds__(NM_BLOCK) void k_multi(nm_multi_args a, uint64_t se
 // over a part of the positions only: list mode); status[NM_STATUS_HASH] += the sum of the words' terms
 __global__ __launch_bounds__(NM_BLOCK) void k_segment_hash(const uint64_t *__restrict__ tab, const nm_enc_word *__restrict__ enc, uint64_t end,
                                                            uint64_t *__restrict__ status) {
-    const uint64_t w = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
-    uint64_t term = w * 64 < end ? nm_hash_segment_word(tab, enc[w], w, end) : 0ULL;
+    __shared__ uint64_t s_hash[NM_BLOCK / NM_WAVE];
+    const uint64_t n_words = (end + 63) >> 6;
+    uint64_t term = 0;                                     // (a fixed, small grid: a few hundred atomics on the one status word)
+    for (uint64_t w = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * NM_BLOCK)
+        term += nm_hash_segment_word(tab, enc[w], w, end);
     for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, NM_WAVE);
-    if ((threadIdx.x & 63) == 0 && term) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)term);
+    if ((threadIdx.x & 63) == 0) s_hash[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t sum = s_hash[0] + s_hash[1] + s_hash[2] + s_hash[3];
+        if (sum) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)sum);
+    }
 }
 
 __global__ void k_reset_status(uint64_t *__restrict__ status, unsigned long long *__restrict__ work) {
@@ -833,7 +857,7 @@ struct nm_lane {
     hipStream_t side = nullptr;           // repeat probes of repeat-rich input run here, beside k_sites (launch_sites)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_last = nullptr;         // end of the lane's last call on its owner's stream
-    nm_buffer enc, ks, work, settled, coarse, need;      // grown on demand
+    nm_buffer enc, ks, work, settled, coarse, need, hashp;   // grown on demand
     uint64_t enc_words = 0;               // words written by the last nm_encode
 };
 
@@ -874,6 +898,7 @@ struct nm_index {
     int kernel_version = 0;               // 0 = automatic (sites when the quad table applies, else 1); 1 / 5 force a kernel
     uint32_t last_site_m = 0;             // core length of the table the sites of the last launch read (nm_index_info 20)
     bool probes_beside = true;            // NEWMAP_AMD_PROBES_BESIDE=0: the probes always follow k_sites on its stream (A/B)
+    int sites_blocks_per_cu = 0;          // NEWMAP_AMD_SITES_BLOCKS_PER_CU (0 = as many as fit)
     bool periodic_runs = true;            // NEWMAP_AMD_PERIODIC=0: the coarse probes walk every stride (A/B) instead of one walk per tandem run
     int site_table = 0;                   // measurement knob (NM_OPT_SITE_TABLE): 0 = pick per launch, 1 = long cores, 2 = short cores
     uint32_t site_d_cap = NM_SITE_MAX_D;  // measurement knob (NEWMAP_AMD_SITE_D): cap on d = kmin - window of the sites
@@ -955,6 +980,22 @@ static int nm_lane_for(nm_index *ix, hipStream_t st) {
     if (rc != NM_OK) return rc;
     pick->tick = ++ix->lane_tick;
     ix->cur = pick;
+    return NM_OK;
+}
+
+// a caller that is about to destroy a stream gives its lane back: the scratch stays for the next stream that needs one
+extern "C" int nm_stream_release(nm_index *ix, void *stream) {
+    if (!ix || !stream) return NM_OK;
+    for (int i = 1; i < NM_LANES; i++) {
+        nm_lane &L = ix->lanes[i];
+        if (L.owner != (hipStream_t)stream) continue;
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        if (L.side) HIP_TRY(hipStreamSynchronize(L.side));
+        L.owner = nullptr;
+        L.tick = 0;
+        if (ix->cur == &L) ix->cur = &ix->lanes[0];
+    }
     return NM_OK;
 }
 
@@ -1308,6 +1349,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (const char *cs = getenv("NEWMAP_AMD_COARSE_STRIDE")) { const int v = atoi(cs); if (v == 128 || v == 256 || v == 512) ix->coarse_stride = (uint32_t)v; }
     if (const char *pb = getenv("NEWMAP_AMD_PROBES_BESIDE")) ix->probes_beside = pb[0] != '0';
     if (const char *pr = getenv("NEWMAP_AMD_PERIODIC")) ix->periodic_runs = pr[0] != '0';
+    if (const char *sb = getenv("NEWMAP_AMD_SITES_BLOCKS_PER_CU")) ix->sites_blocks_per_cu = atoi(sb);
     if (const char *sd = getenv("NEWMAP_AMD_SITE_D")) { ix->site_d_cap = (uint32_t)atoi(sd); if (ix->site_d_cap > NM_SITE_MAX_D) ix->site_d_cap = NM_SITE_MAX_D; }
     if (hipHostMalloc((void **)&ix->h_repeats_seen, 64, hipHostMallocMapped) == hipSuccess) {
         *ix->h_repeats_seen = 0;
@@ -1337,7 +1379,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (nm_lane &L : ix->lanes) {
-        for (void *p : {L.enc.p, L.ks.p, L.work.p, L.settled.p, L.coarse.p, L.need.p})
+        for (void *p : {L.enc.p, L.ks.p, L.work.p, L.settled.p, L.coarse.p, L.need.p, L.hashp.p})
             if (p) (void)hipFree(p);
         if (L.side) (void)hipStreamDestroy(L.side);
         for (hipEvent_t e : {L.ev_fork, L.ev_join, L.ev_last})
@@ -1487,7 +1529,8 @@ static int nm_encode(nm_index *ix, const void *d_seq, uint64_t seq_len, hipStrea
 // status[NM_STATUS_HASH] += fingerprint of positions [0, end) of the segment whose encoded words the lane holds
 static int nm_hash_positions(nm_index *ix, uint64_t end, uint64_t *d_status, hipStream_t st) {
     if (end == 0) return NM_OK;
-    hipLaunchKernelGGL(k_segment_hash, dim3(nm_grid((end + 63) >> 6)), dim3(NM_BLOCK), 0, st, (const uint64_t *)ix->d_hash_tab,
+    const uint64_t want = nm_grid((end + 63) >> 6);
+    hipLaunchKernelGGL(k_segment_hash, dim3((unsigned)(want < 512 ? want : 512)), dim3(NM_BLOCK), 0, st, (const uint64_t *)ix->d_hash_tab,
                        (const nm_enc_word *)ix->cur->enc.p, end, d_status);
     HIP_TRY(hipGetLastError());
     return NM_OK;
@@ -1607,8 +1650,18 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
     if (d > ix->site_d_cap) d = ix->site_d_cap;
     const uint32_t bp = nm_site_block_positions(d);
     const dim3 sgrid((unsigned)((n + bp - 1) / bp)), sblock(NM_SITE_BLOCK);
-    const size_t lds = nm_site_lds_bytes(d, kmax);
+    size_t lds = nm_site_lds_bytes(d, kmax);
+    // NEWMAP_AMD_SITES_BLOCKS_PER_CU (measurement knob): cap the blocks of k_sites a CU holds by asking for more LDS than it
+    // needs -- the lookups reach their line rate with 16 waves per CU (tools/gather_ceiling), and wave slots left free let the
+    // latency-bound kernels of the neighbouring streams (probes, k_resolve) start at once on repeat-rich input
+    if (ix->sites_blocks_per_cu > 0) {
+        const size_t per_block = (size_t)(160u << 10) / (size_t)ix->sites_blocks_per_cu;
+        const size_t want = per_block > 1024 ? (per_block - 512) & ~(size_t)255 : lds;
+        if (want > lds && want <= (64u << 10)) lds = want;
+    }
     ix->last_kernel = 5;
+    if ((rc = nm_grow(ix->cur->hashp, (uint64_t)sgrid.x * sizeof(uint64_t))) != NM_OK) return rc;
+    uint64_t *hash_part = nullptr;                             // set below when k_sites fingerprints the segment itself
     // Input that has shown long repeats before (the latch the fine probes set): the probes are walks of up to kmax + 511
     // dependent steps -- bound by latency, not by lines -- so they run on a second stream BESIDE k_sites (every stride:
     // the bitmap that would gate them is not there yet) and k_resolve waits for both.  Otherwise they follow k_sites
@@ -1622,15 +1675,17 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
         if ((rc = nm_encode(ix, d_seq, seq_len, st, status_ready ? nullptr : d_status)) != NM_OK) return rc;
         if (hash && (rc = nm_hash_positions(ix, n, d_status, st)) != NM_OK) return rc;
         enc_out = nullptr;
+        hash = false;
         HIP_TRY(hipEventRecord(ix->cur->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(ix->cur->side, ix->cur->ev_fork, 0));
         if ((rc = nm_launch_probes<BIG>(ix, view, n, kmax, ix->cur->side, &probe, nullptr)) != NM_OK) return rc;
         HIP_TRY(hipEventRecord(ix->cur->ev_join, ix->cur->side));
     } else if (!status_ready && (rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
+    if (hash) hash_part = (uint64_t *)ix->cur->hashp.p;
     {
         nm_timed timed(ix, st);
 #define NM_LAUNCH_SITES(STATS_, LIST_) hipLaunchKernelGGL((k_sites<BIG, STATS_, LIST_>), sgrid, sblock, lds, st, view, (const uint8_t *)d_seq, seq_len, \
-                                                          enc_out, ix->cur->enc_words, n, kmin, kmax, d, d_out, elem_bytes, d_status, need, work, d_list, n_list, hash && enc_out != nullptr)
+                                                          enc_out, ix->cur->enc_words, n, kmin, kmax, d, d_out, elem_bytes, d_status, need, work, d_list, n_list, hash_part)
         if (d_list) { if (ix->count_steps) NM_LAUNCH_SITES(true, true); else NM_LAUNCH_SITES(false, true); }
         else        { if (ix->count_steps) NM_LAUNCH_SITES(true, false); else NM_LAUNCH_SITES(false, false); }
 #undef NM_LAUNCH_SITES
@@ -1639,7 +1694,7 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
     else if (ix->repeat_probes && (rc = nm_launch_probes<BIG>(ix, view, n, kmax, st, &probe, need)) != NM_OK) return rc;
     const dim3 rgrid((unsigned)((n_need + NM_RES_WORDS - 1) / NM_RES_WORDS)), rblock(NM_RES_BLOCK);
 #define NM_LAUNCH_RES(STATS_, LIST_) hipLaunchKernelGGL((k_resolve<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, \
-                                                        d_status, (const uint64_t *)need, n_need, probe, (const unsigned long long *)work, seq_len, d_list, n_list)
+                                                        d_status, (const uint64_t *)need, n_need, probe, (const unsigned long long *)work, seq_len, d_list, n_list, (const uint64_t *)hash_part, (uint32_t)sgrid.x)
     {
         nm_timed timed(ix, st, 4);
         if (d_list) { if (ix->count_steps) NM_LAUNCH_RES(true, true); else NM_LAUNCH_RES(false, true); }

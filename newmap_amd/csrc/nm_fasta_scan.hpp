@@ -72,7 +72,8 @@ inline uint64_t strip_lines(const unsigned char *p, const unsigned char *e, uint
 }
 
 // the records of a mapped FASTA file, their pieces and base counts (threaded)
-inline std::vector<Record> scan(const unsigned char *base, size_t size, unsigned threads, size_t chunk_bytes = 4u << 20) {
+static const size_t kPieceBytes = 512u << 10;             // a record's data lines are cut into pieces of about this many file bytes
+inline std::vector<Record> scan(const unsigned char *base, size_t size, unsigned threads, size_t chunk_bytes = kPieceBytes) {
     // ---- header lines: '>' or ';' at a line start (newmap/fasta.py:59), found by a threaded scan
     std::vector<size_t> heads;
     {
@@ -159,6 +160,19 @@ inline uint64_t materialize(const Record &rec, uint64_t lo, uint64_t hi, unsigne
         const size_t c = c_lo + k;
         strip_lines(rec.chunk[c], rec.chunk[c + 1], out.data() + (rec.before[c] - buf_base));
     });
+    return buf_base;
+}
+
+// the same into a caller's buffer of `cap` bytes, on the calling thread (the native driver's workers strip one unit each,
+// straight into pinned memory).  Returns the position of out[0] in the record, or ~0 if the pieces do not fit.
+inline uint64_t materialize_into(const Record &rec, uint64_t lo, uint64_t hi, uint8_t *out, size_t cap) {
+    size_t c_lo = (size_t)(std::upper_bound(rec.before.begin(), rec.before.end(), lo) - rec.before.begin()) - 1;
+    size_t c_hi = (size_t)(std::lower_bound(rec.before.begin(), rec.before.end(), hi) - rec.before.begin());
+    if (c_hi > rec.chunk.size() - 1) c_hi = rec.chunk.size() - 1;
+    if (c_hi < c_lo) c_hi = c_lo;
+    const uint64_t buf_base = rec.before[c_lo];
+    if (rec.before[c_hi] - buf_base > cap) return ~0ULL;
+    for (size_t c = c_lo; c < c_hi; c++) strip_lines(rec.chunk[c], rec.chunk[c + 1], out + (rec.before[c] - buf_base));
     return buf_base;
 }
 

@@ -47,6 +47,84 @@ def tandem_dna(n: int, seed: int, frac: float = 0.5) -> np.ndarray:
     return out
 
 
+def _mutate(copy: np.ndarray, divergence: float, rng) -> np.ndarray:
+    """substitutions at `divergence` of the positions (a different base each), a sprinkle of 1-base deletions"""
+    out = copy.copy()
+    n = out.size
+    k = rng.binomial(n, divergence)
+    if k:
+        pos = rng.integers(0, n, k)
+        out[pos] = _ACGT[(np.searchsorted(_ACGT, out[pos]) + rng.integers(1, 4, k)) & 3]
+    d = rng.binomial(n, divergence / 10.0)
+    if d:
+        keep = np.ones(n, dtype=bool)
+        keep[rng.integers(0, n, d)] = False
+        out = out[keep]
+    return out
+
+
+def _revcomp(a: np.ndarray) -> np.ndarray:
+    return _ACGT[3 - np.searchsorted(_ACGT, a[::-1])]
+
+
+def human_like_dna(n: int, seed: int) -> np.ndarray:
+    """A record shaped like a human chromosome rather than like noise (BASELINE configs[3] stand-in: the GRCh38 file is on no
+    box).  On a uniform ACGT background:
+      * interspersed repeats, both strands: a 300-base family at 5-20 % divergence from its consensus (~10 % of the
+        record) and a 6-kb family, copies truncated at the 5' end, at 2-15 % (~15 %); the consensus sequences depend on
+        seed // 100 only, so the records of one genome share them;
+      * segmental duplications: a handful of 10-100 kb stretches copied elsewhere in the record at 0-2 % divergence;
+      * soft-masking: the repeat copies and random stretches in lower case, about half of the record;
+      * upper-case N: 10 kb telomeres, a centromere run of up to 3 Mb (scaled with the record), a few 10-100 kb gaps.
+    Lower-case bases are searched like upper-case ones (newmap/search.py:23); list mode drops a position whose k-mer
+    holds an N (:593-596)."""
+    rng = np.random.default_rng(seed)
+    fam = np.random.default_rng(seed // 100 + 7)
+    alu = _ACGT[fam.integers(0, 4, 300, dtype=np.uint8)]
+    l1 = _ACGT[fam.integers(0, 4, 6000, dtype=np.uint8)]
+    out = uniform_dna(n, seed)
+    lower = np.zeros(n, dtype=bool)
+
+    def plant(consensus, share, div_lo, div_hi, truncate):
+        target, done = int(n * share), 0
+        while done < target:
+            m = consensus.size if not truncate else int(rng.integers(consensus.size // 10, consensus.size + 1))
+            copy = _mutate(consensus[consensus.size - m:], float(rng.uniform(div_lo, div_hi)), rng)
+            if rng.integers(0, 2):
+                copy = _revcomp(copy)
+            at = int(rng.integers(0, max(n - copy.size, 1)))
+            m = min(copy.size, n - at)
+            out[at:at + m] = copy[:m]
+            lower[at:at + m] = True
+            done += m
+
+    plant(alu, 0.10, 0.05, 0.20, False)
+    plant(l1, 0.15, 0.02, 0.15, True)
+    for _ in range(max(1, n // 25_000_000)):                # segmental duplications
+        m = int(min(rng.integers(10_000, 100_001), n // 4))
+        src, dst = int(rng.integers(0, n - m)), int(rng.integers(0, n - m))
+        dup = _mutate(out[src:src + m], float(rng.uniform(0.0, 0.02)), rng)
+        out[dst:dst + dup.size] = dup
+    masked = int(lower.sum())
+    while masked < n // 2:                                  # further soft-masked stretches
+        m = int(rng.integers(200, 20_001))
+        at = int(rng.integers(0, max(n - m, 1)))
+        masked += m - int(lower[at:at + m].sum())
+        lower[at:at + m] = True
+    out = np.where(lower, out | 0x20, out).astype(np.uint8)
+    tel = min(10_000, n // 50)
+    out[:tel] = ord("N")
+    out[n - tel:] = ord("N")
+    cen = min(3_000_000, n // 40)
+    at = n // 3
+    out[at:at + cen] = ord("N")
+    for _ in range(max(1, n // 30_000_000)):
+        m = int(min(rng.integers(10_000, 100_001), n // 100))
+        at = int(rng.integers(0, max(n - m, 1)))
+        out[at:at + m] = ord("N")
+    return out
+
+
 def write_fasta(path, records: list[tuple[str, np.ndarray]], width: int = 60):
     """60-column FASTA without a Python loop per line."""
     path = Path(path)
@@ -67,7 +145,8 @@ def write_fasta(path, records: list[tuple[str, np.ndarray]], width: int = 60):
 
 def config_genome(name: str, scale_mbp: float | None = None) -> list[tuple[str, np.ndarray]]:
     """Records of a BASELINE config: 'c2' (100 Mbp uniform, seed 20260515), 'c3' (24 human-shaped
-    records, seeds 20260516+i), 'c5' (1 Gbp, 50 % tandem repeats, seed 20260517).  `scale_mbp`
+    records, seeds 20260516+i), 'c5' (1 Gbp, 50 % tandem repeats, seed 20260517), 'hs' (24 records of
+    human_like_dna: the stand-in of configs[3]'s GRCh38).  `scale_mbp`
     shrinks the total size proportionally (tests, quick runs)."""
     if name == "c2":
         n = int((scale_mbp or 100) * 1e6)
@@ -81,4 +160,10 @@ def config_genome(name: str, scale_mbp: float | None = None) -> list[tuple[str, 
     if name == "c5":
         n = int((scale_mbp or 1000) * 1e6)
         return [("rep1", tandem_dna(n, 20260517))]
+    if name == "hs":                                        # the human-shaped stand-in of configs[3]: 24 records of human_like_dna
+        total = sum(HUMAN_SHAPED)
+        f = 1.0 if scale_mbp is None else scale_mbp * 1e6 / total
+        names = [f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY"]
+        return [(nm, human_like_dna(max(100_000, int(L * f)), 20260600 + i))
+                for i, (nm, L) in enumerate(zip(names, HUMAN_SHAPED))]
     raise ValueError(f"unknown config {name!r}")

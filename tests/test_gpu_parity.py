@@ -840,6 +840,43 @@ def test_config4_fixed_k(tmp_path, eng, k):
             assert np.array_equal(got, want), (name, k)
 
 
+def test_config4_human_shaped_stand_in(tmp_path, eng):
+    """BASELINE configs[3]'s genome is GRCh38 (on no box); its stand-in at 1/1000 scale: 24 records of synth.human_like_dna --
+    interspersed 300-base and 6-kb repeat families on both strands, segmental duplications, half of the bases soft-masked,
+    telomere / centromere / gap runs of N.  List mode k = 36 and k = 100 (and a list), the native driver's files, and
+    range mode 20:200 against the oracle's restatement of the reference driver: lower-case bases are searched
+    (newmap/search.py:23), a k-mer that holds an N drops its position (:593-596), the tail rule (:590)."""
+    from newmap_amd import synth
+    recs = synth.config_genome("hs", 3.0)
+    assert len(recs) == 24
+    blob = np.concatenate([s for _, s in recs])
+    assert 0.4 < ((blob >= 97) & (blob <= 122)).mean() < 0.6 and 0.01 < (blob == ord("N")).mean() < 0.2
+    fa, idx = _build_index(tmp_path, _records_fasta(recs), "hs")
+    oracle = rd.OracleIndex([s.tobytes() for _, s in recs])
+    with eng.Index(idx, 0) as ix:
+        for name, seq in recs[:8] + recs[-2:]:
+            data = seq.tobytes()
+            seg = rd.Segment(name.encode(), data, True)
+            for ks in ([36], [100], [24, 36, 50, 100]):
+                want, _ = rd.linear_search_segment(oracle, seg, ks, max(ks), np.uint8)
+                got, _ = ix.fixed_k_segment(data, len(data), ks)
+                assert np.array_equal(got, want), (name, ks)
+            got, amb = ix.min_unique_segment(data, len(data), 20, 200)
+            assert amb == int(np.count_nonzero(seq == ord("N")))
+            assert np.array_equal(got, rd.closed_form_min_unique(data, oracle, 20, 200)), name
+        out = tmp_path / "hs_out"
+        out.mkdir()
+        before = ix.guard_segments()
+        ix.search_fasta(fa, out, [36], False, True, 64 * 2000)
+        assert ix.guard_segments() == before                # the FASTA is the indexed genome: no guard
+        for name, seq in recs:
+            data = seq.tobytes()
+            want, _ = rd.linear_search_segment(oracle, rd.Segment(name.encode(), data, True), [36], 36, np.uint8)
+            assert np.array_equal(np.fromfile(out / f"{name}.unique.uint8", dtype=np.uint8), want), name
+        zeros = np.mean([np.mean(np.fromfile(out / f"{n_}.unique.uint8", dtype=np.uint8) == 0) for n_, _ in recs])
+        assert 0.05 < zeros < 0.6                           # repeats and N runs leave a real share of positions without a unique 36-mer
+
+
 def test_both_range_kernels_agree(mixed_genome, eng):
     """the two range paths -- one lane per position (k_min_unique) and the sites (k_sites + gated probes + k_resolve)
     -- are schedules of the same arithmetic: identical elements and ambiguity counts for every window / group size,

@@ -1,7 +1,7 @@
 """Throughput of list mode with one length (BASELINE configs[3]'s shape: fixed-k count mode, k = 36 and 100)
 on a bench genome resident in HBM: the range-kernel route (default) against the list kernel.
 
-    python tools/list_mode_timing.py [--config c2|c3|c5] [--mbp N] [--k 36 100]
+    python tools/list_mode_timing.py [--config c2|c3|c5|hs] [--mbp N] [--k 36 100]      (hs: the human-shaped stand-in, synth.human_like_dna)
 """
 import argparse
 import json
@@ -41,7 +41,7 @@ def main():
     for (_, r), o in zip(recs, off[:-1]):
         d_seq[int(o):int(o) + r.size].copy_(torch.from_numpy(r))
     d_out = torch.zeros(n, dtype=torch.uint8, device=dev)
-    d_st = torch.zeros(8, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(16, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     res = {"config": a.config, "positions": n, "batch": a.batch}
     with Index(wd / "genome.awfmi", 0) as ix:
@@ -69,6 +69,9 @@ def main():
                 res[f"{tag}_{name}_positions_per_s"] = n / dt
             res[f"{tag}_identical"] = bool(np.array_equal(outs["range_kernels"], outs["list_kernel"]))
             res[f"{tag}_nonzero_fraction"] = float((outs["list_kernel"] != 0).mean())
+        host = np.concatenate([r for _, r in recs])
+        res["ambiguous_fraction"] = float(np.isin(host, np.frombuffer(b"ACGTacgt", np.uint8), invert=True).mean())
+        res["lower_case_fraction"] = float(((host >= 97) & (host <= 122)).mean())
     print(json.dumps(res))
 
 

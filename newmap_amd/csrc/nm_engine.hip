@@ -1536,8 +1536,8 @@ static int nm_hash_positions(nm_index *ix, uint64_t end, uint64_t *d_status, hip
     return NM_OK;
 }
 
-static int nm_reset_status(nm_index *ix, uint64_t *d_status, hipStream_t st) {
-    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(NM_WAVE), 0, st, d_status, (unsigned long long *)ix->cur->work.p);
+static int nm_reset_status(nm_index *ix, uint64_t *d_status, hipStream_t st, bool counters = true) {
+    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(NM_WAVE), 0, st, d_status, counters ? (unsigned long long *)ix->cur->work.p : nullptr);
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }
@@ -1916,7 +1916,7 @@ extern "C" int nm_guard_segment_dev(nm_index *ix, const void *d_seq, uint64_t se
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
     if ((rc = nm_lane_for(ix, st)) != NM_OK) return rc;
-    if ((rc = nm_reset_status(ix, d_status, st)) != NM_OK) return rc;
+    if ((rc = nm_reset_status(ix, d_status, st, false)) != NM_OK) return rc;   // (the counters of the search before it stay readable)
     if (num_kmers == 0) return NM_OK;
     ix->guard_segments++;
     if ((rc = nm_encode(ix, d_seq, seq_len, st)) != NM_OK) return rc;

@@ -51,7 +51,7 @@ C2_SEED, C2_BASES = 20260515, 100_000_000
 SW = 16                        # uint64 words of a segment's status row (include/newmap_amd.h NM_STATUS_WORDS)
 PROFILES = ROOT / "profiles" / "round3"
 PMC_SUMMARIES = {"ns": PROFILES / "pmc_ns_sites_kernel_summary.csv", "c2": PROFILES / "pmc_sites_kernel_summary.csv"}
-KERNEL_SOURCES = [ROOT / "newmap_amd" / "csrc" / "nm_engine.hip", ROOT / "newmap_amd" / "csrc" / "nm_core.h"]
+KERNEL_SOURCES = [ROOT / "newmap_amd" / "csrc" / f for f in ("nm_kernels.hip.h", "nm_core.h")]
 
 
 def log(*a):
@@ -198,7 +198,7 @@ def source_hash() -> str:
 def measured_traffic(kernel: str, quad_m: int, positions_per_launch: float, summary: Path):
     """HBM-side read + write bytes per launch of the dominant kernel from the PMC pass committed under profiles/
     (rocprofv3 --pmc cannot run inside this process).  The summary names the kernel sources it was measured on
-    (sha256 of nm_engine.hip + nm_core.h), the core length of the table the sites read and the launch size; a summary
+    (sha256 of nm_kernels.hip.h + nm_core.h), the core length of the table the sites read and the launch size; a summary
     of OTHER sources, another table or another launch size reports null with the reason.  Reads: TCC_EA0_RDREQ x 128 B
     (on gfx950 every read request of this gather is a 128-byte one, TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ -- the guide's
     "FETCH_SIZE reports half" correction stated exactly); writes: TCC_EA0_WRREQ x 64 B."""

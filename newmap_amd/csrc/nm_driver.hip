@@ -134,7 +134,7 @@ int alloc_slot(Driver &d, Slot &s) {
     HIP_TRY(hipMalloc(&s.d_in, in_bytes));
     HIP_TRY(hipMalloc(&s.d_out, out_bytes));
     HIP_TRY(hipMalloc((void **)&s.d_status, NM_STATUS_WORDS * sizeof(uint64_t)));
-    HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync));
     return NM_OK;
 }
 
@@ -563,7 +563,15 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
             if (hi > lo) ranges.push_back({lo, hi});
         }
     }
-    // ---- the units of my ranges, in file order
+    // ---- the units of my ranges, in file order.  A unit = as many whole batches as fit 32 M positions: the batch bounds what
+    // the REFERENCE keeps in host memory per segment (newmap/main.py:172-180); here it only sets where segments may be cut,
+    // the output does not depend on it, and a unit of 10 M positions spends as long in copies and launches as in its kernels.
+    // NEWMAP_AMD_DRIVER_FUSE=0: one batch per unit.
+    {
+        const char *fz = getenv("NEWMAP_AMD_DRIVER_FUSE");
+        const uint64_t launch = 32ull << 20;
+        if (!(fz && fz[0] == '0') && d.batch < launch) d.batch *= launch / d.batch;
+    }
     struct Unit { int rec; uint64_t start, count, seg_len; };
     std::vector<Unit> units;
     std::vector<long> file_units(d.files.size(), 0);
@@ -589,7 +597,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
     // turn: it strips the unit's lines straight into its pinned buffer, submits copy-in, kernels and copy-out (one
     // worker at a time: the handle's calls are made one by one), waits for its event and pwrite()s the result into the
     // record's file.  Strip, transfers, kernels and file writes of different units overlap; nothing is staged twice.
-    int n_workers = d.batch <= (32u << 20) ? 12 : 4;
+    int n_workers = d.batch <= (40u << 20) ? 8 : 4;           // (measured on 3.09 Gbp: 8 workers of 32 M units; more workers only contend)
     if (const char *e = getenv("NEWMAP_AMD_DRIVER_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_workers = v; }
     if ((size_t)n_workers > units.size()) n_workers = units.empty() ? 1 : (int)units.size();
     const size_t piece_slack = 2 * nm_fasta::kPieceBytes + 4096;    // a unit is stripped piece-wise: whole pieces around it
@@ -615,7 +623,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
                 !hip_ok(hipHostMalloc((void **)&s.h_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t), hipHostMallocDefault), "pinned status") ||
                 !hip_ok(hipMalloc(&s.d_in, in_bytes), "device input") || !hip_ok(hipMalloc(&s.d_out, out_bytes), "device output") ||
                 !hip_ok(hipMalloc((void **)&s.d_status, (NM_STATUS_WORDS + 3) * sizeof(uint64_t)), "device status") ||
-                !hip_ok(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "event")) break;
+                !hip_ok(hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync), "event")) break;
             s.h_sum = s.h_status + NM_STATUS_WORDS;
             s.d_sum = s.d_status + NM_STATUS_WORDS;
         }

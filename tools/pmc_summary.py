@@ -5,7 +5,7 @@
 Each PASS_DIR holds the *_counter_collection.csv of one `rocprofv3 --pmc ... --output-format csv` run
 (counters are collected in separate passes, as the MI355X guide prescribes).  Only dispatches of the
 non-counting build of the kernel (template argument STATS = false) are averaged.  The first line of OUT.csv
-ties the numbers to what produced them: the sha256 of the kernel sources (nm_engine.hip + nm_core.h), the git
+ties the numbers to what produced them: the sha256 of the kernel sources (nm_kernels.hip.h + nm_core.h), the git
 commit, the launch size and the quad table the sites read -- bench.py reports `traffic` only when they match
 the run it is in."""
 import collections
@@ -37,7 +37,7 @@ def main():
                 vals = list(by_dispatch.values())
                 sums[c] = (sum(vals) / len(vals), len(vals))
     h = hashlib.sha256()
-    for f in ("newmap_amd/csrc/nm_engine.hip", "newmap_amd/csrc/nm_core.h"):
+    for f in ("newmap_amd/csrc/nm_kernels.hip.h", "newmap_amd/csrc/nm_core.h"):
         h.update((ROOT / f).read_bytes())
     try:
         commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or "n/a (snapshot without .git)"

@@ -405,6 +405,15 @@ struct FastSlot {
 };
 
 // non-zero elements, the largest and the smallest non-zero one (newmap/search.py:331-347), on the device
+#ifdef NM_DRIVER_HOSTSIM      /* tests/hostsim: the driver's host logic under ThreadSanitizer, "device" = host memory */
+template <typename T>
+void k_out_summary(const T *out, uint64_t n, unsigned long long *sum) {
+    unsigned long long cnt = 0, mx = 0, mn = ~0ULL;
+    for (uint64_t i = 0; i < n; i++) { const unsigned long long v = out[i]; if (v) { cnt++; mx = v > mx ? v : mx; mn = v < mn ? v : mn; } }
+    if (cnt) { sum[0] += cnt; sum[1] = mx > sum[1] ? mx : sum[1]; sum[2] = mn < sum[2] ? mn : sum[2]; }
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) kernel(__VA_ARGS__)
+#else
 template <typename T>
 __global__ void k_out_summary(const T *__restrict__ out, uint64_t n, unsigned long long *__restrict__ sum) {
     unsigned long long cnt = 0, mx = 0, mn = ~0ULL;
@@ -423,12 +432,12 @@ __global__ void k_out_summary(const T *__restrict__ out, uint64_t n, unsigned lo
         atomicMin(&sum[2], mn);
     }
 }
+#endif
 
 struct FastDriver {
     nm_index *ix = nullptr;
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;        // odd slots run here: copies and kernels of neighbouring segments overlap (lanes of the handle)
+    std::vector<hipStream_t> streams;     // worker i runs on streams[i % n]: copies and kernels of neighbouring units overlap (lanes of the handle)
     std::vector<uint32_t> ks;
     bool range_mode = true, use_rc = true;
     uint32_t kmin = 0, kmax = 0;
@@ -607,14 +616,19 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         d.fail(NM_E_DEVICE, std::string("HIP error (") + hipGetErrorString(e) + "): " + what);
         return false;
     };
-    const char *one_stream = getenv("NEWMAP_AMD_DRIVER_STREAMS");
-    const bool two_streams = !(one_stream && one_stream[0] == '1');
+    int n_streams = 2;                                          // NEWMAP_AMD_DRIVER_STREAMS = 1 .. 4
+    if (const char *e = getenv("NEWMAP_AMD_DRIVER_STREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 4) n_streams = v; }
     const bool phase_times = getenv("NEWMAP_AMD_DRIVER_TIMING") != nullptr;
     std::atomic<uint64_t> t_strip_us{0}, t_submit_us{0}, t_wait_us{0}, t_write_us{0};
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    if (rc == NM_OK && hip_ok(hipSetDevice(d.device), "hipSetDevice") && hip_ok(hipStreamCreate(&d.stream), "hipStreamCreate") &&
-        (!two_streams || hip_ok(hipStreamCreate(&d.stream2), "hipStreamCreate"))) {
+    bool streams_ok = rc == NM_OK && hip_ok(hipSetDevice(d.device), "hipSetDevice");
+    for (int i = 0; i < n_streams && streams_ok; i++) {
+        hipStream_t st = nullptr;
+        streams_ok = hip_ok(hipStreamCreate(&st), "hipStreamCreate");
+        if (streams_ok) d.streams.push_back(st);
+    }
+    if (streams_ok) {
         d.slots.resize(n_workers);
         for (int i = 0; i < n_workers; i++) {
             FastSlot &s = d.slots[i];
@@ -638,7 +652,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
     auto worker = [&](int si) {
         (void)hipSetDevice(d.device);
         FastSlot &s = d.slots[si];
-        hipStream_t st = (si & 1) && d.stream2 ? d.stream2 : d.stream;
+        hipStream_t st = d.streams[(size_t)si % d.streams.size()];
         for (size_t ui; (ui = next_unit.fetch_add(1)) < units.size();) {
             const Unit &u = units[ui];
             const FastRecord &r = d.recs[u.rec];
@@ -758,8 +772,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         if (s.d_status) (void)hipFree(s.d_status);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    if (d.stream) { (void)nm_stream_release(ix, d.stream); (void)hipStreamDestroy(d.stream); }
-    if (d.stream2) { (void)nm_stream_release(ix, d.stream2); (void)hipStreamDestroy(d.stream2); }
+    for (hipStream_t st : d.streams) { (void)nm_stream_release(ix, st); (void)hipStreamDestroy(st); }
     unmap();
     if (phase_times)
         fprintf(stderr, "[driver] total %.3fs, %d workers, %zu units; summed over the workers: strip %.3f, submit %.3f, wait for the device %.3f, write %.3f s\n",

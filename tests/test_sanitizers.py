@@ -81,3 +81,106 @@ print("ok")
         assert "ok" in _run(code, {"NEWMAP_AMD_SA": algo})
         out[algo] = (tmp_path / "o.awfmi").read_bytes()
     assert out["sais"] == out["pd"]
+
+
+def _libtsan():
+    out = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
+    return out if out and Path(out).exists() else None
+
+
+def test_native_driver_host_logic_under_tsan(tmp_path):
+    """The worker pool of newmap_amd/csrc/nm_driver.hip -- units, pinned slots, hand-over to the device, pwrite at offsets,
+    per-file statistics, record fingerprints, guard pass -- compiled for the host against a stand-in HIP runtime
+    (tests/hostsim/fake_hip) and stubbed engine calls (tests/hostsim/driver_sim.cpp), run under ThreadSanitizer with 8
+    workers: no data race, the engine is never entered by two workers at once, and the files equal a Python model of
+    the stub's function -- for batches fused or not, one rank and three, a skipped record between two records of one
+    id (appends, as newmap/search.py:268-305), a record that is not indexed (guard pass) and one the guard rejects."""
+    tsan = _libtsan()
+    if tsan is None:
+        pytest.skip("libtsan not found")
+    BUILD.mkdir(exist_ok=True)
+    so = BUILD / "libdriver_tsan.so"
+    src = ROOT / "newmap_amd" / "csrc" / "nm_driver.hip"
+    sim = ROOT / "tests" / "hostsim" / "driver_sim.cpp"
+    deps = [src, sim, src.with_name("nm_fasta_scan.hpp"), src.with_name("nm_hash.h"), ROOT / "tests" / "hostsim" / "fake_hip" / "hip" / "hip_runtime.h"]
+    if not so.exists() or so.stat().st_mtime < max(d.stat().st_mtime for d in deps):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-fPIC", "-shared", "-pthread", "-DNM_DRIVER_HOSTSIM",
+                        f"-I{ROOT / 'tests' / 'hostsim' / 'fake_hip'}", "-x", "c++", str(src), str(sim), "-o", str(so), "-lz"], check=True)
+    code = f"""
+import ctypes, os, sys
+import numpy as np
+L = ctypes.CDLL({str(so)!r})
+vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+L.ds_index_new.restype = vp
+L.ds_index_add_record.argtypes = [vp, ctypes.c_char_p, u64]
+L.nm_index_info.restype = u64
+L.nm_index_info.argtypes = [vp, i32]
+L.nm_last_error.restype = ctypes.c_char_p
+L.nm_search_fasta_shard.restype = i32
+L.nm_search_fasta_shard.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, vp, u32, i32, i32, u64, ctypes.POINTER(ctypes.c_char_p), u32,
+                                    ctypes.POINTER(ctypes.c_char_p), u32, vp, vp, vp, i32, i32]
+rng = np.random.default_rng(4)
+alpha = np.frombuffer(b"ACGTN", np.uint8)
+def dna(n): return bytes(alpha[rng.choice(5, n, p=[.24, .24, .24, .24, .04])])
+recs = [(b"", dna(700)), (b"a", dna(200_003)), (b"skip", dna(5000)), (b"a", dna(64 * 300)), (b"b", dna(1)), (b"long", dna(150_000)), (b"c", dna(90_001))]
+def fasta(records, width=61):
+    out = b""
+    for rid, d in records:
+        if rid: out += b">" + rid + b" x y\\n"
+        out += (d + b"\\n") if rid == b"long" else b"".join(d[i:i + width] + b"\\r\\n" for i in range(0, len(d), width))
+        if rid == b"b": out += b">nodata\\n"
+    return out
+tmp = {str(tmp_path)!r}
+fa = os.path.join(tmp, "g.fa")
+open(fa, "wb").write(fasta(recs))
+ix = L.ds_index_new()
+for rid, d in recs: L.ds_index_add_record(ix, d, len(d))
+def model(d, kmax):
+    a = np.frombuffer(d, np.uint8).astype(np.int64)
+    v = np.zeros(len(d), np.int64)
+    n = len(d) - (kmax - 1)
+    if n > 0: v[:n] = 1 + (a[:n] * 7 + a[kmax - 1:kmax - 1 + n] * 13 + kmax) % 200
+    v[~np.isin(a, np.frombuffer(b"ACGTacgt", np.uint8))] = 0
+    return v.astype(np.uint8)
+def run(name, ks, is_range, batch, world=1, exclude=(b"skip",), fasta_path=fa):
+    out = os.path.join(tmp, name); os.makedirs(out, exist_ok=True)
+    k = np.asarray(ks, np.uint32)
+    exc = (ctypes.c_char_p * max(len(exclude), 1))(*exclude)
+    for rank in range(world):
+        rc = L.nm_search_fasta_shard(ix, fasta_path.encode(), out.encode(), k.ctypes.data, k.size, int(is_range), 1, batch, None, 0, exc, len(exclude), None, None, None, rank, world)
+        if rc: return rc, L.nm_last_error().decode()
+    return 0, out
+os.environ["NEWMAP_AMD_DRIVER_SLOTS"] = "8"
+for fuse in ("0", "1"):
+    os.environ["NEWMAP_AMD_DRIVER_FUSE"] = fuse
+    for ks, is_range, batch, world in (([20, 200], True, 64 * 100, 1), ([36], False, 5000, 1), ([20, 60], True, 64 * 37, 3), ([20, 200], True, 10_000_000, 1)):
+        if world > 1: os.environ["NEWMAP_AMD_SHARD_CHUNK"] = "30000"
+        rc, out = run(f"o_{{fuse}}_{{batch}}_{{world}}", ks, is_range, batch, world)
+        os.environ.pop("NEWMAP_AMD_SHARD_CHUNK", None)
+        assert rc == 0, out
+        kmax = max(ks)
+        want = {{b"": model(recs[0][1], kmax), b"a": np.concatenate([model(recs[1][1], kmax), model(recs[3][1], kmax)]), b"b": model(recs[4][1], kmax),
+                b"long": model(recs[5][1], kmax), b"c": model(recs[6][1], kmax)}}
+        assert sorted(os.listdir(out)) == sorted((k_.decode() + ".unique.uint8") for k_ in want), os.listdir(out)
+        for rid, w in want.items():
+            got = np.fromfile(os.path.join(out, rid.decode() + ".unique.uint8"), np.uint8)
+            assert np.array_equal(got, w), (fuse, ks, batch, world, rid)
+assert L.nm_index_info(ix, 23) > 0       # (batches that are no multiple of 64 cannot be joined: those records went through the guard)
+before = L.nm_index_info(ix, 23)
+os.environ["NEWMAP_AMD_DRIVER_FUSE"] = "1"
+rc, out = run("same", [20, 200], True, 64 * 1000)
+assert rc == 0 and L.nm_index_info(ix, 23) == before      # every record is an indexed one: no guard
+# a record that is not indexed: guarded; with an 'X' the stub's guard rejects it
+other = list(recs); other[5] = (b"long", recs[5][1][:70_000] + b"A" + recs[5][1][70_001:] if recs[5][1][70_000:70_001] != b"A" else recs[5][1][:70_000] + b"C" + recs[5][1][70_001:])
+fb = os.path.join(tmp, "h.fa"); open(fb, "wb").write(fasta(other))
+rc, out = run("other", [20, 200], True, 64 * 1000, fasta_path=fb)
+assert rc == 0 and L.nm_index_info(ix, 23) > before
+bad = list(recs); bad[6] = (b"c", recs[6][1][:500] + b"X" + recs[6][1][501:])
+fc = os.path.join(tmp, "x.fa"); open(fc, "wb").write(fasta(bad))
+rc, msg = run("bad", [20, 200], True, 64 * 1000, fasta_path=fc)
+assert rc == 8 and "not found in the index" in msg and "'c'" in msg, (rc, msg)
+print("ok")
+"""
+    env = dict(os.environ, LD_PRELOAD=tsan, TSAN_OPTIONS="halt_on_error=1:exitcode=66:report_signal_unsafe=0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

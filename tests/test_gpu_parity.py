@@ -625,6 +625,7 @@ def test_config3_full_size_properties(tmp_path, eng, monkeypatch):
     all_records = [r[1] for r in recs]                     # (the oracle's scan counter reads them all)
     monkeypatch.setenv("NEWMAP_AMD_COARSE_MIN", "0")
     with eng.Index(idx, 0) as ix:
+        ix.set_segment_guard(False)        # (pieces of records by the hundred million: the record check has its own tests)
         info = ix.info()
         assert info["bwt_length"] > 2 ** 32 and info["quad_core_length"] == 15
         for kmin, kmax in ((24, 150), (20, 200)):
@@ -692,6 +693,7 @@ def test_config5_full_size_properties(tmp_path, eng, monkeypatch):
     kmin, kmax = 20, 255
     n = 100_000_000
     with eng.Index(idx, 0) as ix:
+        ix.set_segment_guard(False)                          # (pieces of the record: the record check has its own tests)
         ix.set_count_steps(True)                             # (the probes' tally of settled positions is kept by the counter build)
         whole, amb = ix.min_unique_segment(rec[:n + kmax - 1], n, kmin, kmax)
         assert amb == 0 and ix.info()["last_range_kernel"] == 5

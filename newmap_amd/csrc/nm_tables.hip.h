@@ -298,6 +298,14 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     uint32_t quad_m = 0;
     if (seed_len_override < -1 && s >= 8) {
         quad_m = nm_auto_quad_len(ix, s);
+        {   // cost-aware: cores longer than this genome needs buy nothing -- with windows of ceil(log4(200 n)) bases one window
+            // in two hundred is repeated, and what they leave open is a per-mille of the positions.  100 Mbp: cores of 14
+            // (34 GB, open in ~1 s) instead of 15 (137 GB, ~4 s); 3 Gbp: the HBM is the limit as before (15)
+            uint32_t w = 1;
+            while (w < 32 && (double)(1ULL << (2 * w)) < 200.0 * (double)h.n) w++;
+            const uint32_t enough = w > NM_QUAD_EXT + 8 ? w - NM_QUAD_EXT : 8;
+            if (!getenv("NEWMAP_AMD_QUAD_FULL") && quad_m > enough) quad_m = enough;
+        }
         if (small_tables && quad_m > 13) quad_m = 13;
         if (const char *q = getenv("NEWMAP_AMD_QUAD_M")) quad_m = (uint32_t)atoi(q);
         if (quad_m > s) quad_m = s;

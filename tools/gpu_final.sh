@@ -2,8 +2,9 @@
 # final trips of a round (run on the GPU box, one part per gpurun call: each stays below the call limit)
 #   tools/gpu_final.sh b NAME   PMC passes tied to the sources as they are now (headline + configs[1]) -> profiles/round3/, then the
 #                               default bench (reads them) and the --gpus 2 / 3 rehearsals from a bare shell
-#   tools/gpu_final.sh c NAME   kernel traces (headline, configs[4]), PMC of configs[4]'s kernels, the other BASELINE configs,
-#                               list mode on the uniform and on the human-shaped 3 Gbp genome, the CLI process end to end, the A/B soak
+#   tools/gpu_final.sh c NAME   kernel traces (headline, configs[4]), PMC of configs[4]'s kernels, configs[2]
+#   tools/gpu_final.sh d NAME   configs[4], list mode on the uniform and on the human-shaped 3 Gbp genome
+#   tools/gpu_final.sh e NAME   the CLI process end to end, the A/B soak
 #   tools/gpu_final.sh a NAME   the GPU suite
 part=$1
 O=gpurun_out/${2:-final}
@@ -26,9 +27,15 @@ c)
   bash tools/kernel_trace_ns.sh $(basename $O)/traces > $O/traces.txt 2>&1; tail -12 $O/traces.txt
   bash tools/profile_c5.sh $O/prof_c5 > $O/prof_c5.txt 2>&1; tail -3 $O/prof_c5.txt
   python bench.py --config c3 --steps 5 --warmup 2 --no-end-to-end > $O/bench_c3.json 2> $O/bench_c3.err; echo "c3 rc=$?"; python tools/show_value.py $O/bench_c3.json
-  python bench.py --config c5 --batch 100000000 --streams 3 --steps 5 --warmup 2 --no-end-to-end > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?"; python tools/show_value.py $O/bench_c5.json
+  ;;
+d)
+  # (no CPU baseline on the tandem genome: the oracle's comparison sort of whole suffixes is quadratic in a 50 kb array)
+  python bench.py --config c5 --batch 100000000 --streams 3 --steps 5 --warmup 2 --no-end-to-end --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?"; python tools/show_value.py $O/bench_c5.json
+  python bench.py --config c5 --batch 100000000 --streams 5 --steps 5 --warmup 2 --no-end-to-end --no-cpu-baseline > $O/bench_c5_s5.json 2> $O/bench_c5_s5.err; python tools/show_value.py $O/bench_c5_s5.json
   python tools/list_mode_timing.py --config c3 --passes 3 > $O/list_mode_c3.json 2> $O/list_mode_c3.err; echo "list mode c3 rc=$?"
   python tools/list_mode_timing.py --config hs --passes 3 > $O/list_mode_hs.json 2> $O/list_mode_hs.err; echo "list mode hs rc=$?"
+  ;;
+e)
   python tools/e2e_timing.py --config c3 --device-index --out $O/e2e_c3.json > $O/e2e_c3.log 2>&1; echo "e2e rc=$?"
   python tools/fuzz_gpu.py --rounds 150 > $O/fuzz_gpu.log 2>&1; echo "fuzz rc=$?"; tail -1 $O/fuzz_gpu.log
   ;;

@@ -58,6 +58,9 @@ struct nm_view {                // the index as the kernels see it
     const uint64_t *quad2;      // a second quad table with longer cores (nullptr = none): k_resolve's second chance
     uint32_t quad2_m;
     const uint64_t *hash_tab;   // NM_HASH_TAB_WORDS words (nm_hash.h): nibble tables + powers of the record fingerprint
+    const uint64_t *dict;       // repeat dictionary (below): 2^dict_bits buckets of 128 bytes, nullptr = none
+    uint32_t dict_len;          // the length x of the strings it holds
+    uint32_t dict_bits;
 };
 
 struct nm_tally {               // counter build only
@@ -67,6 +70,7 @@ struct nm_tally {               // counter build only
 #define NM_SEED_LO_BITS 40
 #define NM_SEED_LO_MASK ((1ULL << NM_SEED_LO_BITS) - 1)
 #define NM_SEED_CNT_SAT 0xFFFFFFu
+#define NM_SEED_CNT_BITS_SHIFT NM_SEED_LO_BITS
 
 // 0..3 for ACGTacgt, 4 otherwise.  Branch-free (a compare chain compiles to divergent branches per byte):
 // with bit 5 cleared the four letters are 0x41 0x43 0x47 0x54 -- bits 1 and 2 spell A=00 C=01 G=11 T=10,
@@ -1033,6 +1037,73 @@ NM_HD const uint64_t *nm_quad_pair34(const uint64_t *entry, const uint32_t b[4])
 NM_HD uint32_t nm_quad_bits(const uint32_t b[4], const uint64_t e[4]) {
     return (uint32_t)((e[0] >> (b[0] & 63u)) & 1ULL) | ((uint32_t)((e[1] >> (b[1] & 63u)) & 1ULL) << 1) |
            ((uint32_t)((e[2] >> (b[2] & 63u)) & 1ULL) << 3) | ((uint32_t)((e[3] >> (b[3] & 63u)) & 1ULL) << 4);
+}
+
+// ---- repeat dictionary: every x-mer that occurs MORE than once, with its interval ---------------------------------
+// What the sites leave open is, on a genome without long repeats, a few percent of the positions whose windows happen to
+// be repeated; nearly all of them are unique a base or two further on.  The dictionary answers that with ONE 128-byte line:
+// it holds every x-mer of the both-strand text that occurs at least twice (x = ceil(log4 n) + 3: 20 for a 3 Gbp genome --
+// 17 M of the 1.1 T possible 20-mers) with its suffix-array interval, in buckets of 8 entries {key, interval}.  An open
+// position looks its x-mer up (x <= kmin): a MISS means the x-mer occurs once, so the element is kmin; a HIT hands the
+// walk an interval x bases deep.  This replaces the second quad table's line, the seed entry and the first x - 16 LF
+// steps of a walk.  (An x-mer that is ABSENT from the index misses too: that is the guard's business, nm_hash.h.)
+// key = the x-mer's bit-planes (lo | hi << 32, x <= 24); value = interval start (40 bits) | size (24 bits, saturating).
+#define NM_DICT_SLOTS 8u
+#define NM_DICT_EMPTY (~0ULL)
+#define NM_DICT_MAX_LEN 24u
+#define NM_DICT_MAX_PROBES 16u
+
+NM_HD uint64_t nm_dict_key(const nm_window &w, uint32_t x) {
+    const uint64_t m = (1ULL << x) - 1ULL;
+    return (w.lo & m) | ((w.hi & m) << 32);
+}
+NM_HD uint64_t nm_dict_bucket(uint64_t key, uint32_t bits) {
+    uint64_t z = key * 0x9E3779B97F4A7C15ULL;
+    z ^= z >> 29;
+    z *= 0xBF58476D1CE4E5B9ULL;
+    return z >> (64 - bits);
+}
+// one-lane lookup (walk kernels, host mirror): true = found, value in `entry`
+NM_HD bool nm_dict_find(const nm_view &ix, uint64_t key, uint64_t &entry) {
+    uint64_t b = nm_dict_bucket(key, ix.dict_bits);
+    const uint64_t mask = (1ULL << ix.dict_bits) - 1ULL;
+    for (uint32_t probe = 0; probe < NM_DICT_MAX_PROBES; probe++, b = (b + 1) & mask) {
+        const uint64_t *e = ix.dict + b * (2 * NM_DICT_SLOTS);
+        for (uint32_t i = 0; i < NM_DICT_SLOTS; i++) {
+            const uint64_t k = e[2 * i];
+            if (k == key) { entry = e[2 * i + 1]; return true; }
+            if (k == NM_DICT_EMPTY) return false;          // (a bucket fills from its first slot: nothing beyond an empty one)
+        }
+    }
+    return false;
+}
+// children of a node {planes klo / khi of an L-mer, its seed-format entry} that occur at least twice: appended base b, its
+// planes and entry.  Returns the number written (0 .. 4).
+template <bool BIG>
+NM_HD uint32_t nm_dict_children(const nm_view &ix, uint32_t klo, uint32_t khi, uint64_t entry, uint32_t L, uint32_t out_lo[4], uint32_t out_hi[4],
+                                uint64_t out_entry[4]) {
+    uint64_t lo, hi;
+    if (!nm_seed_decode(entry, lo, hi)) {                  // saturated size: walk the L bases
+        lo = 0; hi = ix.n;
+        for (uint32_t j = 0; j < L && lo < hi; j++) {
+            const uint32_t code = ((klo >> j) & 1u) | (((khi >> j) & 1u) << 1);
+            nm_lf_interval<BIG>(ix, 3u - code, lo, hi);
+        }
+    }
+    if (hi - lo < 2) return 0;
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < 4; b++) {
+        uint64_t l = lo, h = hi;
+        nm_lf_interval<BIG>(ix, 3u - b, l, h);
+        if (h <= l || h - l < 2) continue;
+        uint64_t cnt = h - l;
+        if (cnt >= NM_SEED_CNT_SAT) cnt = NM_SEED_CNT_SAT;
+        out_lo[n] = klo | ((b & 1u) << L);
+        out_hi[n] = khi | ((b >> 1) << L);
+        out_entry[n] = (l & NM_SEED_LO_MASK) | (cnt << NM_SEED_CNT_BITS_SHIFT);
+        n++;
+    }
+    return n;
 }
 
 // ---- sites: one quad entry settles 5 + d positions (nm_engine.hip: k_sites, k_resolve) -----------

@@ -42,6 +42,8 @@ struct nm_index {
     void *d_quad_small = nullptr;         // a second one with shorter cores: larger groups per line on small genomes
     uint32_t quad_small_m = 0;
     void *d_lfb = nullptr;                // LF blocks
+    void *d_dict = nullptr;               // repeat dictionary (nm_core.h)
+    uint64_t dict_entries = 0;
     void *d_hash_tab = nullptr;           // tables of the record fingerprint (nm_hash.h)
     std::vector<nm_record_entry> records; // (length, fingerprint) of the indexed records, sorted
     uint64_t device_bytes = 0;

@@ -492,11 +492,87 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
             for (uint32_t bits = s_need[i]; bits; bits &= bits - 1) s_q[atomicAdd(&s_qn, 1u)] = i * 32 + (uint32_t)__builtin_ctz(bits);
         __syncthreads();
     };
+    // ---- phase 3D (range mode with a dictionary, nm_core.h): an open position looks its x-mer up in the repeat dictionary --
+    // ONE 128-byte bucket, read by eight neighbouring lanes (16 bytes each, one line per load instruction and position).
+    // A miss: the x-mer occurs once, the element is kmin.  A hit: the position walks from an interval x bases deep
+    // (phase 4D).  Up to four positions per lane group are in flight.
+    nm_tally t = {0, 0, 0, 0};
+    bool any_err = false;
+    uint64_t err_pos = ~0ULL;
+    const bool use_dict = !LIST && ix.dict != nullptr && kmin >= ix.dict_len && !(ix.seed_policy & 0x1000u);
+    bool dict_done = false;
+    if (use_dict && s_open_total && s_open_total <= NM_SITE_CHANCE_MAX) {
+        __shared__ uint32_t s_wpos[NM_SITE_CHANCE_MAX];
+        __shared__ uint64_t s_went[NM_SITE_CHANCE_MAX];
+        __shared__ uint32_t s_wn;
+        gather_open();
+        const uint32_t n_q = s_qn, x = ix.dict_len;
+        if (tid == 0) s_wn = 0;
+        __syncthreads();
+        const uint32_t sub = tid & 7u, gbase = (tid & 63u) & ~7u;
+        for (uint32_t r0 = 0; r0 < n_q; r0 += 4 * (NM_SITE_BLOCK / 8)) {
+            uint64_t key[4], kk[4], vv[4];
+            uint32_t rel[4];
+            bool have[4];
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) {
+                const uint32_t qi = r0 + r * (NM_SITE_BLOCK / 8) + (tid >> 3);
+                have[r] = qi < n_q;
+                rel[r] = have[r] ? s_q[qi] : 0u;
+                key[r] = nm_dict_key(lds_window(rel[r]), x);
+                kk[r] = NM_DICT_EMPTY; vv[r] = 0;
+                if (have[r]) {
+                    const nm_u64x2 v = nm_quad_load16((uint64_t)(ix.dict + (nm_dict_bucket(key[r], ix.dict_bits) * NM_DICT_SLOTS + sub) * 2));
+                    kk[r] = v.x; vv[r] = v.y;
+                    n_entries += 2;
+                }
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) {
+                const uint32_t m8 = (uint32_t)((__ballot(have[r] && kk[r] == key[r]) >> gbase) & 0xFFu);
+                const uint32_t e8 = (uint32_t)((__ballot(have[r] && kk[r] == NM_DICT_EMPTY) >> gbase) & 0xFFu);
+                const int src = m8 ? (int)(gbase + (uint32_t)__builtin_ctz(m8)) : (int)gbase;
+                uint64_t entry = __shfl(vv[r], src, NM_WAVE);
+                if (have[r] && sub == 0) {
+                    bool hit = m8 != 0;
+                    if (!hit && !e8) hit = nm_dict_find(ix, key[r], entry);       // (a full bucket without the key: it may have spilled over)
+                    if (hit) {
+                        const uint32_t slot = atomicAdd(&s_wn, 1u);
+                        s_wpos[slot] = rel[r];
+                        s_went[slot] = entry;
+                    } else {
+                        nm_store(out, elem_bytes, base + rel[r], kmin);
+                        atomicAnd(&s_need[rel[r] >> 5], ~(1u << (rel[r] & 31)));
+                        atomicSub(&s_open_total, 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 4D: the positions whose x-mer is repeated walk on from its interval (a few: here; many: a long repeat, k_resolve)
+        const uint32_t n_w = s_wn;
+        if (n_w <= NM_SITE_WALK_MAX && kmax <= NM_SITE_LA_MAX && !(ix.seed_policy & 0x900u)) {
+            if (tid < n_w) {
+                const uint32_t relw = s_wpos[tid];
+                uint64_t lo, hi;
+                bool amb0 = false, err = false;
+                uint32_t v;
+                if (nm_seed_decode(s_went[tid], lo, hi)) v = nm_min_unique_walk<BIG, true>(ix, s_enc, relw, lds_window(relw), 0, lo, hi, x, kmin, kmax, err, t);
+                else v = nm_min_unique_one<BIG, true>(ix, s_enc, relw, kmin, kmax, amb0, err, t);
+                if (err) { any_err = true; err_pos = base + relw; }
+                nm_store(out, elem_bytes, base + relw, v);
+                atomicAnd(&s_need[relw >> 5], ~(1u << (relw & 31)));
+            }
+            if (tid == 0) s_open_total = 0;
+            dict_done = true;
+        }
+        if (tid == 0) s_qn = 0;
+        __syncthreads();
+    }
     // ---- phase 3: second chance.  A position no site settled asks the table with the longer cores (nm_second_chance; its
     // window is in LDS).  All lookups of the block are in flight together; a block with many open positions sits in a
     // long repeat and skips this.
-    nm_tally t = {0, 0, 0, 0};
-    if (ix.quad2 != nullptr && kmin >= ix.quad2_m + NM_QUAD_EXT && s_open_total && s_open_total <= NM_SITE_CHANCE_MAX) {
+    if (!use_dict && ix.quad2 != nullptr && kmin >= ix.quad2_m + NM_QUAD_EXT && s_open_total && s_open_total <= NM_SITE_CHANCE_MAX) {
         gather_open();
         const uint32_t n_q = s_qn;
         __syncthreads();
@@ -524,12 +600,10 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
     // ---- phase 4: a few open positions (the rule outside long repeats): the block finishes them itself -- seed table +
     // walk -- and hands an empty bitmap on.  Many: they stay for the repeat probes and k_resolve.
     const uint32_t open_total = s_open_total;
-    bool any_err = false;
-    uint64_t err_pos = ~0ULL;
     // (the walks read the block's staged words -- positions relative to its first base -- so the lookahead of the
     // longest walk must have been staged: kmax <= NM_SITE_LA_MAX)
     // (seed_policy bit 0x800, measurement knob: the blocks never walk themselves, every open position goes to k_resolve)
-    const bool self = open_total && open_total <= NM_SITE_WALK_MAX && kmax <= NM_SITE_LA_MAX && !(ix.seed_policy & 0x900u);
+    const bool self = !dict_done && open_total && open_total <= NM_SITE_WALK_MAX && kmax <= NM_SITE_LA_MAX && !(ix.seed_policy & 0x900u);
     if (self) {
         gather_open();
         if (tid < s_qn) {
@@ -544,7 +618,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         atomicOr(&work[NM_WORK_OPEN], 1ULL);
     }
     for (uint32_t i = tid; i < BP / 64; i += NM_SITE_BLOCK)
-        if (base + 64ull * i < num_kmers) need[w0 + i] = self ? 0ULL : ((uint64_t)s_need[2 * i] | ((uint64_t)s_need[2 * i + 1] << 32));
+        if (base + 64ull * i < num_kmers) need[w0 + i] = (self || dict_done) ? 0ULL : ((uint64_t)s_need[2 * i] | ((uint64_t)s_need[2 * i + 1] << 32));
 
     const uint32_t amb_sum = wave_sum(n_amb);
     if ((tid & 63) == 0 && amb_sum) atomicAdd((unsigned long long *)&status[0], (unsigned long long)amb_sum);
@@ -760,6 +834,57 @@ __global__ __launch_bounds__(NM_BLOCK) void k_multi(nm_multi_args a, uint64_t se
         nm_store(out, elem_bytes, p, r);
     }
     nm_epilogue<false>(inb, amb0, err, p, t, status);
+}
+
+// ---- repeat dictionary (nm_core.h): built at open, level by level from the seed table: a node = an L-mer that occurs at
+// least twice; its children with at least two occurrences are the nodes of level L + 1; the nodes of level x are hashed
+// into buckets of 8.
+struct nm_dict_node { uint32_t klo, khi; uint64_t entry; };
+
+// seed != nullptr: the nodes are the slots of the level-L seed table (first_slot + lane), else in[0 .. n_in)
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_dict_expand(nm_view ix, const uint64_t *__restrict__ seed, uint64_t first_slot, const nm_dict_node *__restrict__ in,
+                                                          uint64_t n_in, uint32_t L, nm_dict_node *__restrict__ out, unsigned long long *__restrict__ counter,
+                                                          uint64_t cap) {
+    const uint64_t i = first_slot + blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    uint32_t clo[4], chi[4], n = 0;
+    uint64_t cent[4];
+    if (i < n_in) {
+        uint32_t klo, khi;
+        uint64_t entry;
+        if (seed) { klo = (uint32_t)(i & ((1ULL << L) - 1ULL)); khi = (uint32_t)(i >> L); entry = seed[i]; }
+        else { klo = in[i].klo; khi = in[i].khi; entry = in[i].entry; }
+        if ((entry >> NM_SEED_LO_BITS) >= 2) n = nm_dict_children<BIG>(ix, klo, khi, entry, L, clo, chi, cent);
+    }
+    // one atomic per wave: exclusive prefix sum of n over the lanes
+    uint32_t incl = n;
+    const uint32_t lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, NM_WAVE); if ((int)lane >= off) incl += v; }
+    const uint32_t total = __shfl(incl, 63, NM_WAVE);
+    unsigned long long base = 0;
+    if (lane == 63 && total) base = atomicAdd(counter, (unsigned long long)total);
+    base = __shfl(base, 63, NM_WAVE);
+    const uint64_t at = base + incl - n;
+    for (uint32_t c = 0; c < n; c++)
+        if (at + c < cap) { nm_dict_node nd; nd.klo = clo[c]; nd.khi = chi[c]; nd.entry = cent[c]; out[at + c] = nd; }
+}
+
+__global__ __launch_bounds__(NM_BLOCK) void k_dict_insert(const nm_dict_node *__restrict__ nodes, uint64_t n, uint64_t *__restrict__ table, uint32_t bits,
+                                                          unsigned int *__restrict__ fail) {
+    const uint64_t i = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = (uint64_t)nodes[i].klo | ((uint64_t)nodes[i].khi << 32);
+    const uint64_t mask = (1ULL << bits) - 1ULL;
+    uint64_t b = nm_dict_bucket(key, bits);
+    for (uint32_t probe = 0; probe < NM_DICT_MAX_PROBES; probe++, b = (b + 1) & mask)
+        for (uint32_t j = 0; j < NM_DICT_SLOTS; j++) {
+            unsigned long long *slot = (unsigned long long *)&table[(b * NM_DICT_SLOTS + j) * 2];
+            if (atomicCAS(slot, (unsigned long long)NM_DICT_EMPTY, (unsigned long long)key) == (unsigned long long)NM_DICT_EMPTY) {
+                table[(b * NM_DICT_SLOTS + j) * 2 + 1] = nodes[i].entry;
+                return;
+            }
+        }
+    atomicOr(fail, 1u);
 }
 
 // fingerprint of the positions [0, end) of a segment from its encoded words (the paths that do not run k_sites, or run it

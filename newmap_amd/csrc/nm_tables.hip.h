@@ -142,6 +142,94 @@ static int nm_build_seed(nm_index *ix, uint32_t s, uint32_t quad_m = 0, uint32_t
     return NM_OK;
 }
 
+// The repeat dictionary (nm_core.h): every x-mer that occurs at least twice, x = ceil(log4 n) + 3 (<= 24), derived from the
+// seed table of length s < x level by level (k_dict_expand), then hashed into buckets of 8 (k_dict_insert).  A genome
+// whose repeated x-mers do not fit the memory at hand simply goes without (the second quad table and the seed walks
+// remain).  NEWMAP_AMD_DICT=0: none; NEWMAP_AMD_DICT_LEN: another x.
+static int nm_build_dict(nm_index *ix) {
+    ix->view.dict = nullptr;
+    ix->view.dict_len = ix->view.dict_bits = 0;
+    const uint32_t s = ix->view.seed_len;
+    if (const char *e = getenv("NEWMAP_AMD_DICT")) if (e[0] == '0') return NM_OK;
+    if (!ix->view.seed || s < 8 || ix->h.n < 2) return NM_OK;
+    uint32_t x = 1;
+    while (x < 32 && (1ULL << (2 * x)) < ix->h.n) x++;
+    x += 3;
+    if (const char *e = getenv("NEWMAP_AMD_DICT_LEN")) x = (uint32_t)atoi(e);
+    if (x > NM_DICT_MAX_LEN) x = NM_DICT_MAX_LEN;
+    if (x <= s) return NM_OK;
+    double td = nm_now();
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return NM_OK;
+    // room for the lists: a repeated L-mer has two occurrences at least (n / 2 strings), and a text without much repetition
+    // has about 4^L (1 - e^-l (1 + l)), l = n / 4^L, of them at the first level -- twice that is allocated, the rest of the
+    // memory stays untouched (a genome with more repeated strings than that goes without a dictionary)
+    uint64_t cap = ix->h.n / 2 + 1024;
+    {
+        const double slots = pow(4.0, (double)(s + 1)), l = (double)ix->h.n / slots;
+        const double est = slots * (1.0 - exp(-l) * (1.0 + l));
+        if ((double)cap > 2.0 * est + 1e6) cap = (uint64_t)(2.0 * est + 1e6);
+    }
+    if (cap * sizeof(nm_dict_node) * 2 > free_b / 2) cap = free_b / 2 / (2 * sizeof(nm_dict_node));
+    nm_dict_node *lists[2] = {nullptr, nullptr};
+    unsigned long long *counter = nullptr;
+    unsigned int *fail = nullptr;
+    auto cleanup = [&]() { for (auto *p : lists) if (p) (void)hipFree(p); if (counter) (void)hipFree(counter); if (fail) (void)hipFree(fail); };
+    if (cap < 1024 || hipMalloc((void **)&lists[0], cap * sizeof(nm_dict_node)) != hipSuccess || hipMalloc((void **)&lists[1], cap * sizeof(nm_dict_node)) != hipSuccess ||
+        hipMalloc((void **)&counter, 8) != hipSuccess || hipMalloc((void **)&fail, 4) != hipSuccess) {
+        (void)hipGetLastError();
+        cleanup();
+        return NM_OK;
+    }
+    nm_view v = ix->view;
+    uint64_t n_nodes = 0;
+    int cur = 0;
+    for (uint32_t L = s; L < x; L++) {
+        HIP_TRY(hipMemsetAsync(counter, 0, 8, ix->stream));
+        const uint64_t n_in = L == s ? (1ULL << (2 * s)) : n_nodes;
+        const uint64_t slice = 1ULL << 30;
+        for (uint64_t first = 0; first < n_in; first += slice) {
+            const uint64_t m = n_in - first < slice ? n_in - first : slice;
+            const dim3 grid(nm_grid(m)), block(NM_BLOCK);
+            const uint64_t *seed = L == s ? v.seed : nullptr;
+            if (ix->big) hipLaunchKernelGGL(k_dict_expand<true>, grid, block, 0, ix->stream, v, seed, first, (const nm_dict_node *)lists[cur ^ 1], n_in, L, lists[cur], counter, cap);
+            else         hipLaunchKernelGGL(k_dict_expand<false>, grid, block, 0, ix->stream, v, seed, first, (const nm_dict_node *)lists[cur ^ 1], n_in, L, lists[cur], counter, cap);
+            HIP_TRY(hipGetLastError());
+        }
+        unsigned long long got = 0;
+        HIP_TRY(hipMemcpyAsync(&got, counter, 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        if (got > cap) {                                            // more repeated strings than the lists hold: no dictionary
+            if (nm_verbose()) fprintf(stderr, "[open] repeat dictionary: %llu nodes at length %u do not fit: none built\n", got, L + 1);
+            cleanup();
+            return NM_OK;
+        }
+        n_nodes = got;
+        cur ^= 1;
+    }
+    const nm_dict_node *nodes = lists[cur ^ 1];
+    uint32_t bits = 4;
+    while ((1ULL << bits) * 4 < n_nodes) bits++;                    // <= 4 of 8 slots per bucket on average
+    void *table = nullptr;
+    if (hipMalloc(&table, (128ULL << bits)) != hipSuccess) { (void)hipGetLastError(); cleanup(); return NM_OK; }
+    HIP_TRY(hipMemsetAsync(table, 0xFF, (128ULL << bits), ix->stream));
+    HIP_TRY(hipMemsetAsync(fail, 0, 4, ix->stream));
+    if (n_nodes) hipLaunchKernelGGL(k_dict_insert, dim3(nm_grid(n_nodes)), dim3(NM_BLOCK), 0, ix->stream, nodes, n_nodes, (uint64_t *)table, bits, fail);
+    unsigned int failed = 0;
+    HIP_TRY(hipMemcpyAsync(&failed, fail, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    cleanup();
+    if (failed) { (void)hipFree(table); return NM_OK; }
+    ix->d_dict = table;
+    ix->dict_entries = n_nodes;
+    ix->device_bytes += 128ULL << bits;
+    ix->view.dict = (const uint64_t *)table;
+    ix->view.dict_len = x;
+    ix->view.dict_bits = bits;
+    if (nm_verbose()) fprintf(stderr, "[open] repeat dictionary: %llu strings of %u bases in 2^%u buckets: %.3fs\n", (unsigned long long)n_nodes, x, bits, nm_now() - td);
+    return NM_OK;
+}
+
 // Range / list searches whose shortest length is below the main table's s cannot use it; they get
 // a second, small table of exactly that length (built on first use, kept in the handle).
 static int nm_view_for(nm_index *ix, uint32_t shortest, nm_view *v) {
@@ -276,6 +364,8 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.quad2 = nullptr;
     v.quad2_m = 0;
     v.hash_tab = (const uint64_t *)ix->d_hash_tab;
+    v.dict = nullptr;
+    v.dict_len = v.dict_bits = 0;
 
     if (seed_len_override < -1 && h.n >= 2) {
         const char *off = getenv("NEWMAP_AMD_LF_BLOCKS");
@@ -339,6 +429,9 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     }
     rc = nm_build_seed(ix, s, quad_m, quad_small_m);
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
+    // (not with the small tables of the one-shot CLI: its run is bound by the host, and the dictionary costs ~0.5 s to build)
+    if (seed_len_override == -2 && (rc = nm_build_dict(ix)) != NM_OK) { nm_index_close(ix); return rc; }
+    NM_PHASE(t_open, "repeat dictionary");
     if (const char *cm = getenv("NEWMAP_AMD_COARSE_MIN")) ix->coarse_min = strtoull(cm, nullptr, 10);
     if (const char *cm = getenv("NEWMAP_AMD_COARSE")) ix->coarse_mode = atoi(cm);
     if (const char *cs = getenv("NEWMAP_AMD_COARSE_STRIDE")) { const int v = atoi(cs); if (v == 128 || v == 256 || v == 512) ix->coarse_stride = (uint32_t)v; }
@@ -369,7 +462,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     (void)hipDeviceSynchronize();                              // launches on caller streams and side streams included
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->d_hash_tab, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->d_hash_tab, ix->d_dict, ix->seq.p,
                     ix->out.p, ix->status.p, ix->starts.p, ix->lens.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -410,6 +503,8 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 21: return ix->last_fingerprint;
         case 22: return ix->initial_len;
         case 23: return ix->guard_segments;
+        case 24: return ix->view.dict_len;
+        case 25: return ix->dict_entries;
         case 14: case 15: case 16: case 17: {              // probe tally of the last range-mode launch
             unsigned long long v = 0;
             if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
@@ -429,7 +524,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_SEED_POLICY) {
-        if (value < 0 || (value & 0xFF) > 2 || value > 0xFFF) { nm_set_error("seed policy must be 0, 1 or 2 (+ 0x100 / 0x200 timing experiments)"); return NM_E_ARGUMENT; }
+        if (value < 0 || (value & 0xFF) > 2 || value > 0x1FFF) { nm_set_error("seed policy must be 0, 1 or 2 (+ 0x100 / 0x200 timing experiments)"); return NM_E_ARGUMENT; }
         ix->view.seed_policy = (uint32_t)value;
         return NM_OK;
     }

@@ -97,6 +97,8 @@ class Index:
         d["quad_core_length"] = int(self._L.nm_index_info(self.handle, 18))
         d["quad_small_core_length"] = int(self._L.nm_index_info(self.handle, 19))
         d["last_site_core_length"] = int(self._L.nm_index_info(self.handle, 20))
+        d["dict_length"] = int(self._L.nm_index_info(self.handle, 24))
+        d["dict_entries"] = int(self._L.nm_index_info(self.handle, 25))
         return d
 
     def probe_tally(self) -> dict:
@@ -132,6 +134,11 @@ class Index:
     def set_site_table(self, which: int):
         """measurement / tests: the quad table the sites read: 0 = picked per launch, 1 = long cores, 2 = short cores"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SITE_TABLE, int(which)))
+
+    def set_dictionary(self, on: bool):
+        """A/B: open positions of the sites ask the repeat dictionary (default, when one was built and kmin allows) or the
+        second quad table / the seed table"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SEED_POLICY, 0 if on else 0x1000))
 
     def set_force_big(self, on: bool):
         """tests: exercise the code path of indexes beyond 2^31 positions on a small index"""

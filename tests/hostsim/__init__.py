@@ -48,6 +48,10 @@ def lib():
     L.hs_segment_hash.argtypes = [vp, u64, u64]
     L.hs_guard.restype = u64
     L.hs_guard.argtypes = [vp, vp, u64, u64, vp, u32, i32, u32, i32]
+    L.hs_build_dict.restype = ctypes.c_int64
+    L.hs_build_dict.argtypes = [vp, u32, u32]
+    L.hs_dict_lookup.restype = ctypes.c_int64
+    L.hs_dict_lookup.argtypes = [vp, ctypes.c_char_p]
     L.hs_fasta_open.restype = vp
     L.hs_fasta_open.argtypes = [ctypes.c_char_p, u32, u64]
     L.hs_fasta_close.argtypes = [vp]
@@ -142,6 +146,13 @@ class HostSim:
         steps = self.L.hs_repeat_probes2(self.h, buf.ctypes.data, buf.size, num_kmers, kmin, kmax, stride, coarse_stride,
                                          words.ctypes.data, decided.ctypes.data, 1, periods.ctypes.data, coarse.ctypes.data)
         return words[:n_probes], decided[:num_kmers], int(steps), periods[:n_coarse], coarse[:n_coarse]
+
+    def build_dict(self, seed_level: int, length: int) -> int:
+        """the repeat dictionary of strings of `length` bases, derived from the seed level `seed_level` (as nm_build_dict)"""
+        return int(self.L.hs_build_dict(self.h, seed_level, length))
+
+    def dict_lookup(self, kmer: bytes) -> int:
+        return int(self.L.hs_dict_lookup(self.h, kmer))
 
     def guard(self, seq: bytes, num_kmers, ks, is_range: bool, initial_len: int = 0, use_rc: bool = True):
         """nm_guard_range_one / nm_guard_list_one: first position of the segment for which the reference would raise, or None"""

@@ -23,7 +23,7 @@ struct hs_index {
     std::vector<nm_strand_block> strand;
     std::vector<uint64_t> sep, seed, superC;
     std::vector<nm_lf_entry> lfb;
-    std::vector<uint64_t> quad, quad2;
+    std::vector<uint64_t> quad, quad2, dict;
     nm_view v;
     bool big;
 };
@@ -178,6 +178,55 @@ int hs_build_quad2(hs_index *ix, uint32_t m2) {
     ix->v.quad2 = ix->quad2.data();
     ix->v.quad2_m = m2;
     return 0;
+}
+// the repeat dictionary (nm_core.h; nm_tables.hip.h: nm_build_dict): level by level from a seed level of length s0 with the
+// same node expansion (nm_dict_children), inserted serially with the kernels' bucket rule.  Returns the number of strings,
+// or -1 if a bucket chain ran over.
+int64_t hs_build_dict(hs_index *ix, uint32_t s0, uint32_t x) {
+    if (x <= s0 || x > NM_DICT_MAX_LEN || s0 < 1 || s0 > 10) return -1;
+    struct Node { uint32_t klo, khi; uint64_t entry; };
+    std::vector<Node> cur, nxt;
+    nm_view v = ix->v;
+    for (uint64_t slot = 0; slot < (1ULL << (2 * s0)); slot++) {
+        const uint64_t e = ix->big ? nm_seed_entry<true>(v, slot, s0) : nm_seed_entry<false>(v, slot, s0);
+        if ((e >> NM_SEED_LO_BITS) >= 2) cur.push_back({(uint32_t)(slot & ((1ULL << s0) - 1)), (uint32_t)(slot >> s0), e});
+    }
+    for (uint32_t L = s0; L < x; L++) {
+        nxt.clear();
+        for (const Node &nd : cur) {
+            uint32_t lo[4], hi[4];
+            uint64_t en[4];
+            const uint32_t n = ix->big ? nm_dict_children<true>(v, nd.klo, nd.khi, nd.entry, L, lo, hi, en) : nm_dict_children<false>(v, nd.klo, nd.khi, nd.entry, L, lo, hi, en);
+            for (uint32_t c = 0; c < n; c++) nxt.push_back({lo[c], hi[c], en[c]});
+        }
+        cur.swap(nxt);
+    }
+    uint32_t bits = 4;
+    while ((1ULL << bits) * 4 < cur.size()) bits++;
+    ix->dict.assign((16ULL << bits), NM_DICT_EMPTY);
+    const uint64_t mask = (1ULL << bits) - 1;
+    for (const Node &nd : cur) {
+        const uint64_t key = (uint64_t)nd.klo | ((uint64_t)nd.khi << 32);
+        uint64_t b = nm_dict_bucket(key, bits);
+        bool done = false;
+        for (uint32_t probe = 0; probe < NM_DICT_MAX_PROBES && !done; probe++, b = (b + 1) & mask)
+            for (uint32_t j = 0; j < NM_DICT_SLOTS && !done; j++)
+                if (ix->dict[(b * NM_DICT_SLOTS + j) * 2] == NM_DICT_EMPTY) { ix->dict[(b * NM_DICT_SLOTS + j) * 2] = key; ix->dict[(b * NM_DICT_SLOTS + j) * 2 + 1] = nd.entry; done = true; }
+        if (!done) return -1;
+    }
+    ix->v.dict = ix->dict.data();
+    ix->v.dict_len = x;
+    ix->v.dict_bits = bits;
+    return (int64_t)cur.size();
+}
+// what the dictionary says about a raw string of dict_len bases: -1 not in it, else its interval size (saturating)
+int64_t hs_dict_lookup(hs_index *ix, const uint8_t *kmer) {
+    std::vector<nm_enc_word> enc;
+    hs_encode(kmer, ix->v.dict_len, enc);
+    const nm_window w = nm_load_window(enc.data(), 0);
+    uint64_t e;
+    if (!nm_dict_find(ix->v, nm_dict_key(w, ix->v.dict_len), e)) return -1;
+    return (int64_t)(e >> NM_SEED_LO_BITS);
 }
 // level-wise seed construction must reproduce the entry-by-entry one
 uint64_t hs_check_levels(hs_index *ix, uint32_t s) {
@@ -464,8 +513,43 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             for (uint32_t t = 0; t < 4; t++)
                 if ((inb >> t) & 1u) store(q + t, (hit >> t) & 1u ? kmin : 0u);
         }
+        // repeat dictionary (k_sites phases 3D / 4D): a miss settles the position as kmin, a hit walks from the x-mer's interval
+        const bool use_dict = !list && v.dict && kmin >= v.dict_len;
+        bool dict_done = false;
+        if (use_dict && open_total && open_total <= chance_max) {
+            std::vector<std::pair<uint32_t, uint64_t>> walkers;
+            for (uint32_t i = 0; i < BP / 32; i++)
+                for (uint32_t bits = s_need[i]; bits; bits &= bits - 1) {
+                    const uint32_t rel = i * 32 + (uint32_t)__builtin_ctz(bits);
+                    counters[0]++;
+                    uint64_t e;
+                    if (nm_dict_find(v, nm_dict_key(lds_window(rel), v.dict_len), e)) walkers.push_back({rel, e});
+                    else { store(base + rel, kmin); s_need[i] &= ~(1u << (rel & 31)); open_total--; counters[4]++; }
+                }
+            if (walkers.size() <= walk_max && kmax <= NM_SITE_LA_MAX) {
+                for (auto &wk : walkers) {
+                    const uint32_t rel = wk.first;
+                    uint64_t lo, hi;
+                    bool amb0 = false, err = false;
+                    nm_tally t = {0, 0, 0, 0};
+                    uint32_t val;
+                    counters[1]++;
+                    if (nm_seed_decode(wk.second, lo, hi))
+                        val = ix->big ? nm_min_unique_walk<true, true>(v, s_enc.data(), rel, lds_window(rel), 0, lo, hi, v.dict_len, kmin, kmax, err, t)
+                                      : nm_min_unique_walk<false, true>(v, s_enc.data(), rel, lds_window(rel), 0, lo, hi, v.dict_len, kmin, kmax, err, t);
+                    else
+                        val = ix->big ? nm_min_unique_one<true, true>(v, s_enc.data(), rel, kmin, kmax, amb0, err, t) : nm_min_unique_one<false, true>(v, s_enc.data(), rel, kmin, kmax, amb0, err, t);
+                    if (err) { status[1] = 1; if (base + rel < status[2]) status[2] = base + rel; }
+                    status[3] += t.steps; status[4] += t.blocks; status[6] += t.seeds;
+                    store(base + rel, val);
+                    s_need[rel >> 5] &= ~(1u << (rel & 31));
+                }
+                open_total = 0;
+                dict_done = true;
+            }
+        }
         // second chance: the open positions of a block with few of them ask the table with the longer cores
-        if (chance && open_total && open_total <= chance_max)
+        if (!use_dict && chance && open_total && open_total <= chance_max)
             for (uint32_t i = 0; i < BP / 32; i++)
                 for (uint32_t bits = s_need[i]; bits; bits &= bits - 1) {
                     const uint32_t rel = i * 32 + (uint32_t)__builtin_ctz(bits);
@@ -473,7 +557,7 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
                     if (nm_second_chance(v, lds_window(rel), kmin)) { store(base + rel, kmin); s_need[i] &= ~(1u << (rel & 31)); open_total--; counters[4]++; }
                 }
         // a few open positions: the block finishes them itself; many: they stay for the probes and k_resolve
-        const bool self = open_total && open_total <= walk_max && kmax <= NM_SITE_LA_MAX;
+        const bool self = !dict_done && open_total && open_total <= walk_max && kmax <= NM_SITE_LA_MAX;
         if (self) {
             for (uint32_t i = 0; i < BP / 32; i++) {
                 uint32_t bits = s_need[i];

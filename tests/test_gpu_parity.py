@@ -890,6 +890,7 @@ def test_both_range_kernels_agree(mixed_genome, eng):
     with eng.Index(g["idx"], 0) as ix:
         info = ix.info()
         assert 8 <= info["quad_small_core_length"] < info["quad_core_length"] <= info["seed_length"]
+        assert info["seed_length"] < info["dict_length"] <= 20 and info["dict_entries"] > 0
         w = info["quad_small_core_length"] + 4                # the shortest window the sites can use
         for rec in (g["r1"], g["r2"]):
             for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (w + 1, 64), (60, 90), (61, 90), (62, 90),
@@ -916,6 +917,11 @@ def test_both_range_kernels_agree(mixed_genome, eng):
                                 assert np.array_equal(a, c) and amb_c == amb_a, (kernel, big, probes, d_cap, table, kmin, kmax)
                                 if used == 5 and table == 2:
                                     assert ix.info()["last_site_core_length"] == info["quad_small_core_length"]
+                                if used == 5 and table in (0, 2):   # the same without the repeat dictionary (second table + seed walks)
+                                    ix.set_dictionary(False)
+                                    c2, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                                    ix.set_dictionary(True)
+                                    assert np.array_equal(a, c2), ("no dictionary", big, probes, d_cap, table, kmin, kmax)
                 ix.set_site_d(59)
                 ix.set_site_table(0)
                 ix.set_force_big(False)

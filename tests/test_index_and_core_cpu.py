@@ -581,6 +581,38 @@ def test_sites_pipeline_equals_oracle(tmp_path, m, force_big):
                 assert kmin >= w + 2 or int(counters[4]) == 0       # (the second table's window must fit the kmin-mer)
                 second += int(counters[4])
     assert second > 0                                      # (the second table does settle positions)
+    # the repeat dictionary in the second table's place: exactly the strings of x bases that occur twice or more (with
+    # their counts), and the pipeline with it still equals the oracle -- misses settled as kmin, hits walked from x bases on
+    x = w + 2
+    n_strings = sim.build_dict(m, x)
+    assert n_strings > 0
+    text = [bytes(r1).upper(), r2.upper()]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    both = text + [t_.translate(comp)[::-1] for t_ in text]
+    import collections
+    tally = collections.Counter()
+    for t_ in both:
+        for i in range(len(t_) - x + 1):
+            km = t_[i:i + x]
+            if all(ch in b"ACGT" for ch in km):
+                tally[km] += 1
+    repeated = {k_: c for k_, c in tally.items() if c >= 2}
+    assert n_strings == len(repeated)
+    for k_, c in list(repeated.items())[:400]:
+        assert sim.dict_lookup(k_) == c, k_
+    for k_ in [k_ for k_, c in tally.items() if c == 1][:400] + [b"ACGT" * 8]:
+        assert sim.dict_lookup(k_[:x].ljust(x, b"A")) in (-1, repeated.get(k_[:x].ljust(x, b"A"), -1))
+    settled_by_dict = 0
+    for rec in (bytes(r1), r2):
+        for kmin, kmax in ((x, 40), (x + 1, 40), (20, 200), (24, 150), (70, 255)):
+            if kmin < x:
+                continue
+            want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
+            for probes, chance_max, walk_max in ((0, 256, 64), (1, 256, 64), (2, 256, 64), (1, 1 << 20, 64), (1, 1 << 20, 1 << 20), (1, 256, 0), (0, 0, 0)):
+                got, _, code, _, counters = sim.sites(rec, len(rec), kmin, kmax, 59, probes, chance_max=chance_max, walk_max=walk_max)
+                assert code == 0 and np.array_equal(got, want), ("dict", kmin, kmax, probes, chance_max, walk_max, np.flatnonzero(got != want)[:10])
+                settled_by_dict += int(counters[4])
+    assert settled_by_dict > 0
     # list mode: several lengths, the first >= the window
     for ks in ([w, w + 5], [20, 36, 100], [36, 20, 50], [w + 2, 250], [100, 24]):
         if min(ks) < w or ks[0] > 252:

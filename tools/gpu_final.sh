@@ -36,6 +36,8 @@ d)
   python tools/list_mode_timing.py --config hs --passes 3 > $O/list_mode_hs.json 2> $O/list_mode_hs.err; echo "list mode hs rc=$?"
   ;;
 e)
+  bash tools/kernel_trace_ns.sh $(basename $O)/traces > $O/traces.txt 2>&1; tail -6 $O/traces.txt
+  bash tools/profile_c5.sh $O/prof_c5 > $O/prof_c5.txt 2>&1; tail -3 $O/prof_c5.txt
   python tools/e2e_timing.py --config c3 --device-index --out $O/e2e_c3.json > $O/e2e_c3.log 2>&1; echo "e2e rc=$?"
   python tools/fuzz_gpu.py --rounds 150 > $O/fuzz_gpu.log 2>&1; echo "fuzz rc=$?"; tail -1 $O/fuzz_gpu.log
   ;;

@@ -11,7 +11,7 @@ f=$(find $O/trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $
 rm -rf $O/trace
 timeout -k 10 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc1 -o p -- $B > $O/pmc1.json 2> $O/pmc1.log || { echo "pmc1 failed"; exit 1; }
 timeout -k 10 400 rocprofv3 --pmc TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc2 -o p -- $B > $O/pmc2.json 2> $O/pmc2.log || echo "pmc2 failed"
-for k in k_repeat_probe_coarse "k_repeat_probe<" k_resolve k_sites; do
+for k in k_period_runs k_repeat_probe_coarse "k_repeat_probe<" k_resolve k_sites; do
   n=$(echo $k | tr -d '<')
   python3 tools/pmc_summary.py "$k" $O/pmc_c5_${n}_summary.csv $O/trace.json $O/pmc1 $O/pmc2 > /dev/null
 done

@@ -507,42 +507,49 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         __shared__ uint32_t s_wn;
         gather_open();
         const uint32_t n_q = s_qn, x = ix.dict_len;
+        __shared__ uint64_t s_dkey[NM_SITE_CHANCE_MAX];
+        __shared__ uint32_t s_dbkt[NM_SITE_CHANCE_MAX];
         if (tid == 0) s_wn = 0;
+        if (tid < n_q) {                                               // one lane per open position: its key and bucket
+            const uint64_t key = nm_dict_key(lds_window(s_q[tid]), x);
+            s_dkey[tid] = key;
+            s_dbkt[tid] = (uint32_t)nm_dict_bucket(key, ix.dict_bits);
+        }
         __syncthreads();
         const uint32_t sub = tid & 7u, gbase = (tid & 63u) & ~7u;
-        for (uint32_t r0 = 0; r0 < n_q; r0 += 4 * (NM_SITE_BLOCK / 8)) {
+        for (uint32_t r0 = 0; r0 < n_q; r0 += 4 * (NM_SITE_BLOCK / 8)) {  // eight lanes per position read its bucket; four positions per group in flight
             uint64_t key[4], kk[4], vv[4];
-            uint32_t rel[4];
             bool have[4];
 #pragma unroll
             for (uint32_t r = 0; r < 4; r++) {
                 const uint32_t qi = r0 + r * (NM_SITE_BLOCK / 8) + (tid >> 3);
                 have[r] = qi < n_q;
-                rel[r] = have[r] ? s_q[qi] : 0u;
-                key[r] = nm_dict_key(lds_window(rel[r]), x);
-                kk[r] = NM_DICT_EMPTY; vv[r] = 0;
+                kk[r] = NM_DICT_EMPTY; vv[r] = 0; key[r] = 0;
                 if (have[r]) {
-                    const nm_u64x2 v = nm_quad_load16((uint64_t)(ix.dict + (nm_dict_bucket(key[r], ix.dict_bits) * NM_DICT_SLOTS + sub) * 2));
+                    key[r] = s_dkey[qi];
+                    const nm_u64x2 v = nm_quad_load16((uint64_t)(ix.dict + ((uint64_t)s_dbkt[qi] * NM_DICT_SLOTS + sub) * 2));
                     kk[r] = v.x; vv[r] = v.y;
                     n_entries += 2;
                 }
             }
 #pragma unroll
             for (uint32_t r = 0; r < 4; r++) {
+                if (r0 + r * (NM_SITE_BLOCK / 8) >= n_q) break;               // (uniform: no position left for this turn)
                 const uint32_t m8 = (uint32_t)((__ballot(have[r] && kk[r] == key[r]) >> gbase) & 0xFFu);
                 const uint32_t e8 = (uint32_t)((__ballot(have[r] && kk[r] == NM_DICT_EMPTY) >> gbase) & 0xFFu);
                 const int src = m8 ? (int)(gbase + (uint32_t)__builtin_ctz(m8)) : (int)gbase;
                 uint64_t entry = __shfl(vv[r], src, NM_WAVE);
                 if (have[r] && sub == 0) {
+                    const uint32_t rel = s_q[r0 + r * (NM_SITE_BLOCK / 8) + (tid >> 3)];
                     bool hit = m8 != 0;
                     if (!hit && !e8) hit = nm_dict_find(ix, key[r], entry);       // (a full bucket without the key: it may have spilled over)
                     if (hit) {
                         const uint32_t slot = atomicAdd(&s_wn, 1u);
-                        s_wpos[slot] = rel[r];
+                        s_wpos[slot] = rel;
                         s_went[slot] = entry;
                     } else {
-                        nm_store(out, elem_bytes, base + rel[r], kmin);
-                        atomicAnd(&s_need[rel[r] >> 5], ~(1u << (rel[r] & 31)));
+                        nm_store(out, elem_bytes, base + rel, kmin);
+                        atomicAnd(&s_need[rel >> 5], ~(1u << (rel & 31)));
                         atomicSub(&s_open_total, 1u);
                     }
                 }

@@ -58,6 +58,7 @@ struct nm_view {                // the index as the kernels see it
     const uint64_t *quad2;      // a second quad table with longer cores (nullptr = none): k_resolve's second chance
     uint32_t quad2_m;
     const uint64_t *hash_tab;   // NM_HASH_TAB_WORDS words (nm_hash.h): nibble tables + powers of the record fingerprint
+    const nm_lf_entry *lf2;     // two-base LF blocks (below): 16 entries per 64 rows, nullptr = none
     const uint64_t *dict;       // repeat dictionary (below): 2^dict_bits buckets of 128 bytes, nullptr = none
     uint32_t dict_len;          // the length x of the strings it holds
     uint32_t dict_bits;
@@ -219,6 +220,26 @@ NM_HD void nm_lf_interval(const nm_view &ix, uint32_t c, uint64_t &lo, uint64_t 
     hi = nm_lf<BIG>(ix, c, hi);
 }
 
+// ---- two bases per step ------------------------------------------------------------------------------------------
+// A walk is a chain of dependent loads, one per base; where walks are long (repeats: hundreds of bases) the chain IS the
+// run time.  The two-base LF blocks halve it: prepending c1 and then c2 to a pattern maps row i to
+//      C[c2] + rank_c2(C[c1]) + #{ rows i' < i : BWT[i'] = c1 and BWT[LF(i')] = c2 },
+// i.e. a rank over the "BWT of the two preceding symbols" plus one of 16 constants -- per 64 rows and dinucleotide one
+// 16-byte entry {constant + count before the block, indicator bits}: 256 bytes per 64 rows (4 n bytes: 25 GB for a
+// 3 Gbp genome).  A walk takes two bases at a time while the interval keeps two or more rows (so the length at which it
+// first holds one row is still found by single steps: the pair that would cross it is retried base by base).
+// entry of block b, dinucleotide d = 4 * c2 + c1 at index 16 b + d.
+template <bool BIG>
+NM_HD void nm_lf2_interval(const nm_view &ix, uint32_t c1, uint32_t c2, uint64_t &lo, uint64_t &hi) {
+    const uint32_t d = 4u * c2 + c1;
+    const nm_lf_entry *e = ix.lf2 + ((lo >> 6) * 16 + d);
+    const uint64_t base = e->base, bits = e->bits;
+    uint64_t hbase = base, hbits = bits;
+    if ((lo >> 6) != (hi >> 6)) { const nm_lf_entry *f = ix.lf2 + ((hi >> 6) * 16 + d); hbase = f->base; hbits = f->bits; }
+    lo = base + nm_popc64(bits & ((1ULL << (lo & 63)) - 1ULL));
+    hi = hbase + nm_popc64(hbits & ((1ULL << (hi & 63)) - 1ULL));
+}
+
 // the four LF entries of rank block b, from the packed structure (device build at open; host mirror)
 template <bool BIG>
 NM_HD void nm_lf_entries_of_block(const nm_view &ix, uint64_t b, nm_lf_entry out[4]) {
@@ -256,6 +277,16 @@ NM_HD bool nm_bwt_code(const nm_view &ix, uint64_t i, uint32_t &code) {
     return true;
 }
 
+// the dinucleotide (4 * c2 + c1) in front of the suffix of row i, 16 = none (a separator among the two symbols)
+template <bool BIG>
+NM_HD uint32_t nm_bwt2_code(const nm_view &ix, uint64_t i) {
+    uint32_t c1, c2;
+    if (i >= ix.n || !nm_bwt_code(ix, i, c1)) return 16u;
+    const uint64_t j = nm_lf<BIG>(ix, c1, i);
+    if (!nm_bwt_code(ix, j, c2)) return 16u;
+    return 4u * c2 + c1;
+}
+
 struct nm_window { uint64_t lo, hi, amb; };      // sequence positions [pos, pos+64)
 
 NM_HD nm_window nm_window_from(const nm_enc_word &a, const nm_enc_word &b, uint32_t s) {
@@ -276,6 +307,27 @@ NM_HD nm_window nm_load_window(const nm_enc_word *enc, uint64_t pos) {
 
 NM_HD uint32_t nm_window_code(const nm_window &w, uint32_t j) {
     return (uint32_t)((w.lo >> j) & 1ULL) | ((uint32_t)((w.hi >> j) & 1ULL) << 1);
+}
+
+// try to take the bases j and j + 1 of window w (both unambiguous) in one step: true = done (the interval keeps >= 2 rows).
+// A failed try is a wasted load, and in unique sequence nearly every try would fail (the interval shrinks fourfold per
+// base), so a walk only tries where the pair is likely to keep two rows: the interval is wide (>= NM_LF2_WIDE rows: a
+// repeat family, or simply many rows left to shed), or `still` >= NM_LF2_STREAK single steps in a row left the row count
+// unchanged -- the signature of a few exact copies; a failure clears `still`.
+#ifndef NM_LF2_STREAK
+#define NM_LF2_STREAK 2u
+#endif
+#ifndef NM_LF2_WIDE
+#define NM_LF2_WIDE 16u
+#endif
+template <bool BIG>
+NM_HD bool nm_lf2_try(const nm_view &ix, const nm_window &w, uint32_t j, uint64_t &lo, uint64_t &hi, uint32_t &still) {
+    if ((still < NM_LF2_STREAK && hi - lo < NM_LF2_WIDE) || j >= 63 || ((w.amb >> j) & 3ULL)) return false;
+    uint64_t l2 = lo, h2 = hi;
+    nm_lf2_interval<BIG>(ix, 3u - nm_window_code(w, j), 3u - nm_window_code(w, j + 1), l2, h2);
+    if (h2 < l2 + 2) { still = 0; return false; }
+    lo = l2; hi = h2;
+    return true;
 }
 
 // seed-table slot of the s-mer at the start of a window: low s bits = lo plane, next s = hi plane
@@ -309,6 +361,7 @@ template <bool BIG, bool RC>
 NM_HD uint32_t nm_min_unique_walk(const nm_view &ix, const nm_enc_word *enc, uint64_t p, nm_window w,
                                   uint32_t kbase, uint64_t lo, uint64_t hi, uint32_t k, uint32_t kmin,
                                   uint32_t kmax, bool &err, nm_tally &t) {
+    uint32_t still = 0;                                   // single steps in a row that kept every row (nm_lf2_try)
     for (;;) {
         const uint64_t cnt = hi - lo;
         if (cnt == 0) { err = true; return 0; }           // search.py:699-722
@@ -330,11 +383,18 @@ NM_HD uint32_t nm_min_unique_walk(const nm_view &ix, const nm_enc_word *enc, uin
         if (k >= kmax) return 0;
         uint32_t j = k - kbase;
         if (j >= 64) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+        if (RC && ix.lf2 && k + 2 <= kmax && nm_lf2_try<BIG>(ix, w, j, lo, hi, still)) {   // two bases, the interval still holds two rows
+            t.steps += 2;
+            t.blocks += 2;
+            k += 2;
+            continue;
+        }
         if ((w.amb >> j) & 1ULL) return 0;                // k == U_p and still not unique
         const uint32_t c = 3u - nm_window_code(w, j);     // prepend the complement: search rc(k-mer)
         t.steps++;
         t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u;
         nm_lf_interval<BIG>(ix, c, lo, hi);
+        still = hi - lo == cnt ? still + 1u : 0u;
         k++;
     }
     const uint32_t ans = k > kmin ? k : kmin;             // k <= kmax here, kmin <= kmax
@@ -439,6 +499,7 @@ NM_HD void nm_repeat_probe_ex(const nm_view &ix, const nm_enc_word *enc, uint64_
         } else { lo = 0; hi = ix.n; }
     }
     uint32_t first_unique;                                // a lower bound of the least unique length at P
+    uint32_t still = NM_LF2_STREAK;                       // (probes are only sent into dense repeats: try from the start)
     for (;;) {
         const uint64_t cnt = hi - lo;
         if (cnt == 0) return;                             // absent k-mer: the ordinary path reports it
@@ -446,6 +507,7 @@ NM_HD void nm_repeat_probe_ex(const nm_view &ix, const nm_enc_word *enc, uint64_
         if (k >= cap) { first_unique = cap + 1; break; }
         uint32_t j = k - kbase;
         if (j >= 64) { w = nm_load_window(enc, P + k); kbase = k; j = 0; }
+        if (ix.lf2 && k + 2 <= cap && nm_lf2_try<BIG>(ix, w, j, lo, hi, still)) { t.steps += 2; t.blocks += 2; k += 2; continue; }
         if ((w.amb >> j) & 1ULL) {                        // S[P .. P+k) occurs twice and ends the run: all of it is 0
             settled = k < stride ? k : stride;
             return;
@@ -454,6 +516,7 @@ NM_HD void nm_repeat_probe_ex(const nm_view &ix, const nm_enc_word *enc, uint64_
         t.steps++;
         t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u;
         nm_lf_interval<BIG>(ix, c, lo, hi);
+        still = hi - lo == cnt ? still + 1u : 0u;
         k++;
     }
     settled = first_unique > kmax ? first_unique - kmax : 0u;            // q - P < first_unique - kmax
@@ -556,6 +619,7 @@ NM_HD uint32_t nm_fixed_k_one(const nm_view &ix, const nm_enc_word *enc, uint64_
     uint64_t lo = 0, hi = ix.n;
     uint32_t k = 0;
     uint32_t checked = 1;                                 // positions [p, p+checked) known valid
+    uint32_t still = 0;
     const uint32_t s = ix.seed_len;
     for (uint32_t q = 0; q < nk; q++) {
         const uint32_t K = ks[q];
@@ -575,10 +639,13 @@ NM_HD uint32_t nm_fixed_k_one(const nm_view &ix, const nm_enc_word *enc, uint64_
         while (k < L && hi - lo > 1) {
             uint32_t j = k - kbase;
             if (j >= 64 || k < kbase) { w = nm_load_window(enc, p + k); kbase = k; j = 0; }
+            if (RC && ix.lf2 && k + 2 <= L && nm_lf2_try<BIG>(ix, w, j, lo, hi, still)) { t.steps += 2; t.blocks += 2; k += 2; continue; }
             const uint32_t c = 3u - nm_window_code(w, j);
+            const uint64_t before = hi - lo;
             t.steps++;
             t.blocks += ((lo >> 6) == (hi >> 6)) ? 1u : 2u;
             nm_lf_interval<BIG>(ix, c, lo, hi);
+            still = hi - lo == before ? still + 1u : 0u;
             k++;
         }
         const uint64_t cnt = hi - lo;

@@ -405,7 +405,7 @@ struct FastSlot {
 };
 
 // non-zero elements, the largest and the smallest non-zero one (newmap/search.py:331-347), on the device
-#ifdef NM_DRIVER_HOSTSIM      /* tests/hostsim: the driver's host logic under ThreadSanitizer, "device" = host memory */
+#ifdef NM_DRIVER_HOST_SUMMARY      /* tests/test_sanitizers.py: the driver's host logic under ThreadSanitizer, "device" = host memory */
 template <typename T>
 void k_out_summary(const T *out, uint64_t n, unsigned long long *sum) {
     unsigned long long cnt = 0, mx = 0, mn = ~0ULL;

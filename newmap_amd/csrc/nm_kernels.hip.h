@@ -843,6 +843,53 @@ __global__ __launch_bounds__(NM_BLOCK) void k_multi(nm_multi_args a, uint64_t se
     nm_epilogue<false>(inb, amb0, err, p, t, status);
 }
 
+// ---- two-base LF blocks (nm_core.h: nm_lf2_interval), built at open in three passes -------------------------------------
+// pass 1: one wave per 64 rows: every lane finds the dinucleotide in front of its row (two dependent reads: the row's
+// symbol, then the symbol of the row it maps to), sixteen ballots make the indicator words; lane d writes entry d with its
+// popcount in `base`.  pass 2 (k_lf2_chunk_sums / host scan) and pass 3 (k_lf2_finish) turn the counts into
+// "constant + count before the block".
+#define NM_LF2_CHUNK 1024u          /* blocks per chunk of the two-level prefix sum */
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_lf2_bits(nm_view ix, nm_lf_entry *__restrict__ lf2, uint64_t first, uint64_t n_blocks) {
+    const uint64_t b = first + ((blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x) >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (b >= n_blocks) return;
+    const uint32_t d = nm_bwt2_code<BIG>(ix, b * 64 + lane);
+    uint64_t mine = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < 16; x++) {
+        const uint64_t m = __ballot(d == x);
+        if (lane == x) mine = m;
+    }
+    if (lane < 16) { nm_lf_entry e; e.base = nm_popc64(mine); e.bits = mine; lf2[b * 16 + lane] = e; }
+}
+// sums[chunk][d] = rows with dinucleotide d in the chunk's blocks
+__global__ __launch_bounds__(NM_BLOCK) void k_lf2_chunk_sums(const nm_lf_entry *__restrict__ lf2, uint64_t n_blocks, uint64_t n_chunks, uint64_t *__restrict__ sums) {
+    const uint64_t t = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;      // one lane per (chunk, d)
+    if (t >= n_chunks * 16) return;
+    const uint64_t chunk = t >> 4, d = t & 15;
+    const uint64_t b1 = (chunk + 1) * NM_LF2_CHUNK < n_blocks ? (chunk + 1) * NM_LF2_CHUNK : n_blocks;
+    uint64_t s = 0;
+    for (uint64_t b = chunk * NM_LF2_CHUNK; b < b1; b++) s += lf2[b * 16 + d].base;
+    sums[t] = s;
+}
+// starts[chunk][d] = rows with d before the chunk (exclusive scan of the sums, done on the host: n_chunks is small);
+// base = C[c2] + rank_c2(C[c1]) + rows with d before the block
+template <bool BIG>
+__global__ __launch_bounds__(NM_BLOCK) void k_lf2_finish(nm_view ix, nm_lf_entry *__restrict__ lf2, uint64_t n_blocks, uint64_t n_chunks, const uint64_t *__restrict__ starts) {
+    const uint64_t t = blockIdx.x * (uint64_t)NM_BLOCK + threadIdx.x;
+    if (t >= n_chunks * 16) return;
+    const uint64_t chunk = t >> 4;
+    const uint32_t d = (uint32_t)(t & 15), c1 = d & 3u, c2 = d >> 2;
+    const uint64_t b1 = (chunk + 1) * NM_LF2_CHUNK < n_blocks ? (chunk + 1) * NM_LF2_CHUNK : n_blocks;
+    uint64_t run = starts[t] + nm_lf<BIG>(ix, c2, BIG ? ix.superC[c1] : ix.C[c1]);
+    for (uint64_t b = chunk * NM_LF2_CHUNK; b < b1; b++) {
+        const uint64_t c = lf2[b * 16 + d].base;
+        lf2[b * 16 + d].base = run;
+        run += c;
+    }
+}
+
 // ---- repeat dictionary (nm_core.h): built at open, level by level from the seed table: a node = an L-mer that occurs at
 // least twice; its children with at least two occurrences are the nodes of level L + 1; the nodes of level x are hashed
 // into buckets of 8.

@@ -142,6 +142,51 @@ static int nm_build_seed(nm_index *ix, uint32_t s, uint32_t quad_m = 0, uint32_t
     return NM_OK;
 }
 
+// Two-base LF blocks (nm_core.h): 4 bytes per BWT row; built last, where the memory left allows (NEWMAP_AMD_LF2=0: none)
+static int nm_build_lf2(nm_index *ix) {
+    ix->view.lf2 = nullptr;
+    if (const char *e = getenv("NEWMAP_AMD_LF2")) if (e[0] == '0') return NM_OK;
+    if (!ix->view.lfb || ix->h.n < 2) return NM_OK;
+    const uint64_t n_blocks = ix->h.n / 64 + 1, n_chunks = (n_blocks + NM_LF2_CHUNK - 1) / NM_LF2_CHUNK;
+    const uint64_t bytes = n_blocks * 16 * sizeof(nm_lf_entry);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + (16ull << 30) > free_b) return NM_OK;
+    double t0 = nm_now();
+    void *table = nullptr;
+    uint64_t *d_sums = nullptr;
+    if (hipMalloc(&table, bytes) != hipSuccess || hipMalloc((void **)&d_sums, n_chunks * 16 * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        if (table) (void)hipFree(table);
+        return NM_OK;
+    }
+    const nm_view v = ix->view;
+    const uint64_t slice_blocks = 1ULL << 24;                      // (grid * block below 2^32: 64 lanes per block of rows)
+    for (uint64_t first = 0; first < n_blocks; first += slice_blocks) {
+        const uint64_t m = n_blocks - first < slice_blocks ? n_blocks - first : slice_blocks;
+        if (ix->big) hipLaunchKernelGGL(k_lf2_bits<true>, dim3(nm_grid(m * 64)), dim3(NM_BLOCK), 0, ix->stream, v, (nm_lf_entry *)table, first, first + m);
+        else         hipLaunchKernelGGL(k_lf2_bits<false>, dim3(nm_grid(m * 64)), dim3(NM_BLOCK), 0, ix->stream, v, (nm_lf_entry *)table, first, first + m);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_lf2_chunk_sums, dim3(nm_grid(n_chunks * 16)), dim3(NM_BLOCK), 0, ix->stream, (const nm_lf_entry *)table, n_blocks, n_chunks, d_sums);
+    std::vector<uint64_t> sums(n_chunks * 16);
+    HIP_TRY(hipMemcpyAsync(sums.data(), d_sums, sums.size() * 8, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    uint64_t run[16] = {0};
+    for (uint64_t c = 0; c < n_chunks; c++)
+        for (int d = 0; d < 16; d++) { const uint64_t x = sums[c * 16 + d]; sums[c * 16 + d] = run[d]; run[d] += x; }
+    HIP_TRY(hipMemcpyAsync(d_sums, sums.data(), sums.size() * 8, hipMemcpyHostToDevice, ix->stream));
+    if (ix->big) hipLaunchKernelGGL(k_lf2_finish<true>, dim3(nm_grid(n_chunks * 16)), dim3(NM_BLOCK), 0, ix->stream, v, (nm_lf_entry *)table, n_blocks, n_chunks, (const uint64_t *)d_sums);
+    else         hipLaunchKernelGGL(k_lf2_finish<false>, dim3(nm_grid(n_chunks * 16)), dim3(NM_BLOCK), 0, ix->stream, v, (nm_lf_entry *)table, n_blocks, n_chunks, (const uint64_t *)d_sums);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    (void)hipFree(d_sums);
+    ix->d_lf2 = table;
+    ix->device_bytes += bytes;
+    ix->view.lf2 = (const nm_lf_entry *)table;
+    if (nm_verbose()) fprintf(stderr, "[open] two-base LF blocks (%.1f GB): %.3fs\n", bytes / 1e9, nm_now() - t0);
+    return NM_OK;
+}
+
 // The repeat dictionary (nm_core.h): every x-mer that occurs at least twice, x = ceil(log4 n) + 3 (<= 24), derived from the
 // seed table of length s < x level by level (k_dict_expand), then hashed into buckets of 8 (k_dict_insert).  A genome
 // whose repeated x-mers do not fit the memory at hand simply goes without (the second quad table and the seed walks
@@ -366,6 +411,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.hash_tab = (const uint64_t *)ix->d_hash_tab;
     v.dict = nullptr;
     v.dict_len = v.dict_bits = 0;
+    v.lf2 = nullptr;
 
     if (seed_len_override < -1 && h.n >= 2) {
         const char *off = getenv("NEWMAP_AMD_LF_BLOCKS");
@@ -431,6 +477,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (rc != NM_OK) { nm_index_close(ix); return rc; }
     // (not with the small tables of the one-shot CLI: its run is bound by the host, and the dictionary costs ~0.5 s to build)
     if (seed_len_override == -2 && (rc = nm_build_dict(ix)) != NM_OK) { nm_index_close(ix); return rc; }
+    if (seed_len_override == -2 && (rc = nm_build_lf2(ix)) != NM_OK) { nm_index_close(ix); return rc; }
     NM_PHASE(t_open, "repeat dictionary");
     if (const char *cm = getenv("NEWMAP_AMD_COARSE_MIN")) ix->coarse_min = strtoull(cm, nullptr, 10);
     if (const char *cm = getenv("NEWMAP_AMD_COARSE")) ix->coarse_mode = atoi(cm);
@@ -462,7 +509,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     (void)hipDeviceSynchronize();                              // launches on caller streams and side streams included
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->d_hash_tab, ix->d_dict, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->d_hash_tab, ix->d_dict, ix->d_lf2, ix->seq.p,
                     ix->out.p, ix->status.p, ix->starts.p, ix->lens.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -503,6 +550,7 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 21: return ix->last_fingerprint;
         case 22: return ix->initial_len;
         case 23: return ix->guard_segments;
+        case 26: return ix->view.lf2 ? 1 : 0;
         case 24: return ix->view.dict_len;
         case 25: return ix->dict_entries;
         case 14: case 15: case 16: case 17: {              // probe tally of the last range-mode launch
@@ -550,6 +598,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         ix->site_table = (int)value;
         return NM_OK;
     }
+    if (option == NM_OPT_LF2) { ix->view.lf2 = value ? (const nm_lf_entry *)ix->d_lf2 : nullptr; return NM_OK; }
     if (option == NM_OPT_SEGMENT_GUARD) { ix->segment_guard = value != 0; return NM_OK; }
     if (option == NM_OPT_INITIAL_LENGTH) {
         if (value < 0 || value > 0xFFFFFFFFLL) { nm_set_error("initial search length out of range"); return NM_E_ARGUMENT; }

@@ -99,6 +99,7 @@ class Index:
         d["last_site_core_length"] = int(self._L.nm_index_info(self.handle, 20))
         d["dict_length"] = int(self._L.nm_index_info(self.handle, 24))
         d["dict_entries"] = int(self._L.nm_index_info(self.handle, 25))
+        d["lf2_blocks"] = int(self._L.nm_index_info(self.handle, 26))
         return d
 
     def probe_tally(self) -> dict:
@@ -134,6 +135,10 @@ class Index:
     def set_site_table(self, which: int):
         """measurement / tests: the quad table the sites read: 0 = picked per launch, 1 = long cores, 2 = short cores"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SITE_TABLE, int(which)))
+
+    def set_lf2(self, on: bool):
+        """A/B: walks take two bases per step (two-base LF blocks, where built) or one"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LF2, int(bool(on))))
 
     def set_dictionary(self, on: bool):
         """A/B: open positions of the sites ask the repeat dictionary (default, when one was built and kmin allows) or the

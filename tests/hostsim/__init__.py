@@ -28,6 +28,9 @@ def lib():
     L.hs_open.argtypes = [ctypes.c_char_p, i32, i32]
     L.hs_close.argtypes = [vp]
     L.hs_enable_lfb.argtypes = [vp, i32]
+    L.hs_enable_lf2.argtypes = [vp, i32]
+    L.hs_check_lf2.restype = ctypes.c_uint64
+    L.hs_check_lf2.argtypes = [vp]
     L.hs_check_lfb.restype = u64
     L.hs_check_lfb.argtypes = [vp]
     L.hs_check_levels.restype = u64
@@ -95,6 +98,12 @@ class HostSim:
 
     def enable_lfb(self, on=True):
         self.L.hs_enable_lfb(self.h, int(on))
+
+    def enable_lf2(self, on=True):
+        self.L.hs_enable_lf2(self.h, int(on))
+
+    def check_lf2(self):
+        return int(self.L.hs_check_lf2(self.h))
 
     def check_lfb(self):
         return int(self.L.hs_check_lfb(self.h))

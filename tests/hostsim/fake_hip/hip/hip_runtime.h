@@ -3,7 +3,7 @@
 // threads, pinned slots, hand-over to the "device", pwrite of the results, record fingerprints, guard pass) be compiled
 // with g++ and run under ThreadSanitizer / AddressSanitizer -- GPU sanitizers do not exist on the pool.  Memory is host
 // memory, copies are memcpy, streams and events are empty (every "asynchronous" call completes before it returns), the one
-// kernel of the driver (k_out_summary) is replaced by a host loop inside nm_driver.hip (NM_DRIVER_HOSTSIM).  The engine
+// kernel of the driver (k_out_summary) is replaced by a host loop inside nm_driver.hip (NM_DRIVER_HOST_SUMMARY).  The engine
 // entry points the driver calls are stubbed in tests/hostsim/driver_sim.cpp.
 #ifndef NM_FAKE_HIP_RUNTIME_H
 #define NM_FAKE_HIP_RUNTIME_H

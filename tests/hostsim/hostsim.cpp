@@ -22,7 +22,7 @@ struct hs_index {
     std::vector<nm_rank_block> rank;
     std::vector<nm_strand_block> strand;
     std::vector<uint64_t> sep, seed, superC;
-    std::vector<nm_lf_entry> lfb;
+    std::vector<nm_lf_entry> lfb, lf2;
     std::vector<uint64_t> quad, quad2, dict;
     nm_view v;
     bool big;
@@ -69,7 +69,7 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
     v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
     v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
-    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.lfb = nullptr; v.quad = nullptr; v.quad_m = 0; v.quad2 = nullptr; v.quad2_m = 0;
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.lfb = nullptr; v.lf2 = nullptr; v.dict = nullptr; v.dict_len = v.dict_bits = 0; v.quad = nullptr; v.quad_m = 0; v.quad2 = nullptr; v.quad2_m = 0;
     uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
     if (s > 12) s = 12;                     // keep the simulated table small
     if (s && h.n >= 2) {
@@ -95,6 +95,39 @@ void hs_enable_lfb(hs_index *ix, int on) {
         }
     }
     ix->v.lfb = on ? ix->lfb.data() : nullptr;
+}
+// two-base LF blocks: host mirror of k_lf2_bits / k_lf2_chunk_sums / k_lf2_finish (nm_tables.hip.h: nm_build_lf2)
+void hs_enable_lf2(hs_index *ix, int on) {
+    if (on && ix->lf2.empty()) {
+        const nm_view v = ix->v;
+        const uint64_t nb = v.n / 64 + 1;
+        ix->lf2.assign(nb * 16, nm_lf_entry{0, 0});
+        for (uint64_t b = 0; b < nb; b++)
+            for (uint32_t lane = 0; lane < 64; lane++) {
+                const uint32_t d = ix->big ? nm_bwt2_code<true>(v, b * 64 + lane) : nm_bwt2_code<false>(v, b * 64 + lane);
+                if (d < 16) { ix->lf2[b * 16 + d].bits |= 1ULL << lane; ix->lf2[b * 16 + d].base++; }
+            }
+        for (uint32_t d = 0; d < 16; d++) {
+            const uint32_t c1 = d & 3u, c2 = d >> 2;
+            uint64_t run = ix->big ? nm_lf<true>(v, c2, v.superC[c1]) : nm_lf<false>(v, c2, v.C[c1]);
+            for (uint64_t b = 0; b < nb; b++) { const uint64_t c = ix->lf2[b * 16 + d].base; ix->lf2[b * 16 + d].base = run; run += c; }
+        }
+    }
+    ix->v.lf2 = on ? ix->lf2.data() : nullptr;
+}
+// the two-base step against two single steps, at every row and dinucleotide
+uint64_t hs_check_lf2(hs_index *ix) {
+    uint64_t bad = 0;
+    if (!ix->v.lf2) return ~0ULL;
+    for (uint64_t i = 0; i <= ix->v.n; i++)
+        for (uint32_t d = 0; d < 16; d++) {
+            const uint32_t c1 = d & 3u, c2 = d >> 2;
+            uint64_t lo = i, hi = i;
+            if (ix->big) nm_lf2_interval<true>(ix->v, c1, c2, lo, hi); else nm_lf2_interval<false>(ix->v, c1, c2, lo, hi);
+            const uint64_t one = ix->big ? nm_lf<true>(ix->v, c2, nm_lf<true>(ix->v, c1, i)) : nm_lf<false>(ix->v, c2, nm_lf<false>(ix->v, c1, i));
+            if (lo != one || hi != one) bad++;
+        }
+    return bad;
 }
 // LF blocks against the packed rank blocks at every row
 uint64_t hs_check_lfb(hs_index *ix) {

@@ -252,6 +252,60 @@ def test_lf_blocks_equal_packed_rank_blocks(tmp_path, golden_search):
             assert got[rid.encode()].tolist() == exp["values"], (c["name"], rid)
 
 
+@pytest.mark.parametrize("force_big", [False, True])
+def test_two_base_lf_blocks(tmp_path, force_big):
+    """k_lf2_bits / k_lf2_finish (host mirror in tests/hostsim): the two-base step equals two single steps at every row and
+    dinucleotide (records, separators and the sentinel included), and walks, probes and list mode that take two bases at a
+    time still equal the oracle -- with fewer dependent steps."""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    r1 = bytearray(bytes(alpha[rng.integers(0, 4, 9000)]))
+    unit = bytes(alpha[rng.integers(0, 4, 13)])
+    r1[1000:3000] = (unit * 200)[:2000]
+    r1[4000:4003] = b"NRN"
+    r1[6000:6900] = r1[100:1000]
+    r1[7000:7300] = bytes(r1[3200:3500]).lower()
+    r2 = bytes(alpha[rng.integers(0, 4, 2500)]) + bytes(r1[5000:5700])[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")) + b"ACGTA"
+    fa = _write(tmp_path, b">a\n" + bytes(r1) + b"\n>b\n" + r2 + b"\n>c\nAC\n>d\nT\n")
+    idx = tmp_path / "t.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    oracle = rd.OracleIndex([bytes(r1), r2, b"AC", b"T"])
+    for lfb in (False, True):
+        sim = HostSim(idx, 5, force_big)
+        sim.enable_lfb(lfb)
+        sim.enable_lf2(True)
+        assert sim.check_lf2() == 0
+    assert sim.check_quad() == 0
+    for rec in (bytes(r1), r2):
+        for kmin, kmax in ((9, 40), (20, 200), (24, 151), (63, 64), (64, 300), (130, 255)):
+            dtype, _ = rd.output_dtype(kmax)
+            want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
+            steps = {}
+            for on in (False, True):
+                sim.enable_lf2(on)
+                got, status, code = sim.min_unique(rec, len(rec), kmin, kmax, True, dtype)
+                assert code == 0 and np.array_equal(got, want), (on, kmin, kmax, np.flatnonzero(got != want)[:10])
+                steps[on] = int(status[3])
+                for probes in (0, 1, 2):
+                    got, _, code, _, _ = sim.sites(rec, len(rec), kmin, kmax, 59, probes, dtype=dtype)
+                    assert code == 0 and np.array_equal(got, want), (on, kmin, kmax, probes, np.flatnonzero(got != want)[:10])
+    sim.enable_lf2(True)
+    for ks in ([20, 36, 100], [24], [101, 30]):
+        kmax = max(ks)
+        dtype, _ = rd.output_dtype(kmax)
+        for rec in (bytes(r1), r2):
+            seg = rd.Segment(b"r", rec, True)
+            want, _ = rd.linear_search_segment(oracle, seg, ks, kmax, dtype, True)
+            head = len(rec) - kmax + 1
+            keep = np.ones(head, bool)
+            r_at = rec.find(b"R")
+            if r_at >= 0:
+                keep[max(0, r_at - kmax + 1):r_at + 1] = False
+            for probes in (0, 1):
+                got, _, code, _, _ = sim.sites(rec, head, ks[0], kmax, 59, probes, ks=ks, dtype=dtype)
+                assert code == 0 and np.array_equal(got[keep], want[:head][keep]), (ks, probes)
+
+
 def test_repeat_probes_decide_only_what_the_oracle_confirms(tmp_path):
     """nm_repeat_probe / nm_probe_kstar / nm_probe_element (the logic of k_repeat_probe and of its consumers):
     every element the probes decide -- zeros inside long repeats, exact lengths where two neighbouring probes

@@ -104,7 +104,7 @@ def test_native_driver_host_logic_under_tsan(tmp_path):
     sim = ROOT / "tests" / "hostsim" / "driver_sim.cpp"
     deps = [src, sim, src.with_name("nm_fasta_scan.hpp"), src.with_name("nm_hash.h"), ROOT / "tests" / "hostsim" / "fake_hip" / "hip" / "hip_runtime.h"]
     if not so.exists() or so.stat().st_mtime < max(d.stat().st_mtime for d in deps):
-        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-fPIC", "-shared", "-pthread", "-DNM_DRIVER_HOSTSIM",
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-fPIC", "-shared", "-pthread", "-DNM_DRIVER_HOST_SUMMARY",
                         f"-I{ROOT / 'tests' / 'hostsim' / 'fake_hip'}", "-x", "c++", str(src), str(sim), "-o", str(so), "-lz"], check=True)
     code = f"""
 import ctypes, os, sys

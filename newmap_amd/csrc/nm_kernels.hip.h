@@ -529,7 +529,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
                     key[r] = s_dkey[qi];
                     const nm_u64x2 v = nm_quad_load16((uint64_t)(ix.dict + ((uint64_t)s_dbkt[qi] * NM_DICT_SLOTS + sub) * 2));
                     kk[r] = v.x; vv[r] = v.y;
-                    n_entries += 2;
+                    if (sub == 0) n_entries += 2;                 // counted as ONE slot (key + entry, 16 B): what a lookup needs; the bucket's other seven are the layout's cost
                 }
             }
 #pragma unroll

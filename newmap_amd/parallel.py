@@ -86,12 +86,16 @@ def units_for_slice(record_lengths: Sequence[int], lo: int, hi: int, batch: int,
 
 
 def run_slice(records: Sequence[tuple[bytes, bytes]], units: Sequence[Unit],
-              compute: Callable[[bytes, int], np.ndarray], dtype) -> np.ndarray:
-    """results of this rank's units, concatenated in global position order"""
+              compute: Callable[..., np.ndarray], dtype, companions: Sequence[Sequence[bytes]] = ()) -> np.ndarray:
+    """results of this rank's units, concatenated in global position order.  `companions`: the record data of further
+    FASTA files searched in lock-step with `records` (newmap/search.py:251-265: geometry from the first file); with
+    them `compute` is called with the LIST of the files' segments instead of one segment."""
     parts = []
     for u in units:
         data = records[u.record][1]
         seg = data[u.start:u.start + u.seg_len]
+        if companions:
+            seg = [seg] + [c[u.record][u.start:u.start + u.seg_len] for c in companions]
         arr = np.asarray(compute(seg, u.count), dtype=dtype)
         if arr.size != u.count:
             raise RuntimeError("engine returned a result of the wrong length")
@@ -193,14 +197,15 @@ def write_slice_direct(records: Sequence[tuple[bytes, bytes]], local: np.ndarray
     write_ranges_direct(records, parts, path_of, rank, barrier)
 
 
-def search_records_sharded(records: Sequence[tuple[bytes, bytes]], compute: Callable[[bytes, int], np.ndarray],
-                           kmax: int, batch: int, dtype, world: int, rank: int, device=None):
+def search_records_sharded(records: Sequence[tuple[bytes, bytes]], compute: Callable[..., np.ndarray],
+                           kmax: int, batch: int, dtype, world: int, rank: int, device=None,
+                           companions: Sequence[Sequence[bytes]] = ()):
     """Returns {record id: array} on rank 0 (None elsewhere)."""
     lengths = [len(d) for _, d in records]
     total = int(sum(lengths))
     lo, hi = shard_bounds(total, world)[rank]
     units = units_for_slice(lengths, lo, hi, batch, kmax)
-    local = run_slice(records, units, compute, dtype)
+    local = run_slice(records, units, compute, dtype, companions)
     full = gather_to_root(local, total, world, rank, device)
     if full is None:
         return None
@@ -287,8 +292,9 @@ def write_unique_counts_distributed(config) -> None:
 
     kmax, kmin = max(config.kmer_lengths), min(config.kmer_lengths)
     dtype, suffix = S.output_type(kmax)
-    if len(config.fasta_filepaths) != 1 or len(config.fmindex_filepaths) != 1:
-        raise NotImplementedError("the sharded search takes exactly one FASTA and one index")
+    # several FASTA files in lock-step and / or several index files (newmap/search.py:251-265, 656-697): the same plan --
+    # units of the FIRST file's records -- with every file's segment of a unit handed to nm_search_segment_multi
+    multi = len(config.fasta_filepaths) != 1 or len(config.fmindex_filepaths) != 1
 
     def barrier():
         if world > 1:
@@ -304,7 +310,7 @@ def write_unique_counts_distributed(config) -> None:
     gather = world > 1 and os.environ.get("NEWMAP_AMD_GATHER", "0") == "1"
     with open(config.fasta_filepaths[0], "rb") as fh:
         gzipped = fh.read(2) == b"\x1f\x8b"
-    if not gather and not gzipped and os.environ.get("NEWMAP_AMD_PYTHON_DRIVER", "") != "1":
+    if not multi and not gather and not gzipped and os.environ.get("NEWMAP_AMD_PYTHON_DRIVER", "") != "1":
         # every rank runs the native driver on its own interleaved share of the position space
         index = cached_index(config.fmindex_filepaths[0], local_rank if config.device is None else config.device)
         index.set_initial_search_length(config.initial_search_length)
@@ -332,12 +338,31 @@ def write_unique_counts_distributed(config) -> None:
             nothing_found()
         return
     with optional_gzip_open(config.fasta_filepaths[0], "rb") as fh:
-        records = [(rid, data) for rid, data in fasta_records(fh) if S._wanted(config, rid)]
+        every = list(fasta_records(fh))
+    keep = [S._wanted(config, rid) for rid, _ in every]
+    records = [r for r, k in zip(every, keep) if k]
+    del every
     if not records:
         nothing_found()
+    companions = []
+    for path in config.fasta_filepaths[1:]:
+        with optional_gzip_open(path, "rb") as fh:
+            other = [data for rid, data in fasta_records(fh)]
+        # (lock-step is by position in the file, newmap/search.py:260: record i of every file, whatever its id)
+        other = [d for d, k in zip(other, keep) if k]
+        if len(other) < len(records) or any(len(d) != len(r[1]) for d, r in zip(other, records)):
+            raise ValueError(f"{path}: the sharded lock-step search needs the record lengths of {config.fasta_filepaths[0]} "
+                             "(run a single process for files that differ)")
+        companions.append(other[:len(records)])
     index = cached_index(config.fmindex_filepaths[0], local_rank if config.device is None else config.device)
+    indexes = [index] + [cached_index(p, local_rank if config.device is None else config.device) for p in config.fmindex_filepaths[1:]]
 
-    def compute(seg: bytes, count: int) -> np.ndarray:
+    def compute(seg, count: int) -> np.ndarray:
+        if multi:
+            from .engine import search_segment_multi
+            segs = seg if isinstance(seg, list) else [seg]
+            return search_segment_multi(indexes, segs, count, config.kmer_lengths, config.is_binary_search,
+                                        config.use_reverse_complement, dtype)[0]
         if config.is_binary_search:
             return index.min_unique_segment(seg, count, kmin, kmax, config.use_reverse_complement, dtype)[0]
         return index.fixed_k_segment(seg, count, config.kmer_lengths, config.use_reverse_complement, dtype)[0]
@@ -346,7 +371,7 @@ def write_unique_counts_distributed(config) -> None:
         return Path(config.output_directory) / S.UNIQUE_COUNT_FILENAME_FORMAT.format(rid.decode(), suffix)
 
     if gather:                                                          # ranks without a shared file system
-        result = search_records_sharded(records, compute, kmax, config.kmer_batch_size, dtype, world, rank, device)
+        result = search_records_sharded(records, compute, kmax, config.kmer_batch_size, dtype, world, rank, device, companions)
         if result is not None:
             for rid, arr in result.items():
                 with open(path_of(rid), "wb") as fh:
@@ -356,7 +381,7 @@ def write_unique_counts_distributed(config) -> None:
     lengths = [len(d) for _, d in records]
     parts = []
     for lo, hi in interleaved_ranges(int(sum(lengths)), world)[rank]:
-        parts.append((lo, run_slice(records, units_for_slice(lengths, lo, hi, config.kmer_batch_size, kmax), compute, dtype)))
+        parts.append((lo, run_slice(records, units_for_slice(lengths, lo, hi, config.kmer_batch_size, kmax), compute, dtype, companions)))
     if not parts:
         parts = [(0, np.zeros(0, dtype=dtype))]
     write_ranges_direct(records, parts, path_of, rank, barrier)

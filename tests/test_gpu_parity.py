@@ -1181,6 +1181,7 @@ def test_multi_fasta_multi_index_mode(tmp_path, eng):
     import json
     from newmap_amd.search import SearchConfig, write_unique_counts
     cases = json.loads((Path(__file__).resolve().parent / "golden" / "golden_multi.json").read_text())["cases"]
+    sharded_cases = 0
     for n, c in enumerate(cases):
         d = tmp_path / f"m{n}"
         d.mkdir()
@@ -1197,6 +1198,21 @@ def test_multi_fasta_multi_index_mode(tmp_path, eng):
         for rid, e in c["expected"].items():
             got = np.fromfile(out / f"{rid}.unique.{e['dtype']}", dtype=e["dtype"])
             assert got.tolist() == e["values"], (c["name"], rid)
+        # the sharded entry point in this mode (one rank here; the plan over ranks is tests/test_parallel_gloo.py): same files
+        from newmap_amd.parallel import write_unique_counts_distributed
+        out2 = d / "out_sharded"
+        out2.mkdir()
+        try:
+            write_unique_counts_distributed(SearchConfig(fasta_filepaths=fas, fmindex_filepaths=idxs, kmer_lengths=c["kmer_lengths"],
+                                                         is_binary_search=c["is_binary"], kmer_batch_size=c["batch"],
+                                                         output_directory=out2, use_reverse_complement=c["use_reverse_complement"]))
+        except ValueError as e:                    # files whose records differ in length are refused there, by name
+            assert "record lengths" in str(e), e
+            continue
+        sharded_cases += 1
+        for rid, e in c["expected"].items():
+            assert (out2 / f"{rid}.unique.{e['dtype']}").read_bytes() == (out / f"{rid}.unique.{e['dtype']}").read_bytes(), (c["name"], rid)
+    assert sharded_cases > 0
     eng.close_all()
 
 

@@ -34,6 +34,17 @@ def _records_with_duplicates():
     return [r[0], r[1], (b"b", r[0][1][2000:2700]), r[2], (b"a", r[1][1][:900])]
 
 
+def _lock_step_inputs(records):
+    """a second FASTA with the records' geometry and two indexes: of the first file and of another genome that shares a
+    stretch with it.  (No total may fall strictly between 0 and the number of files -- the case the reference never
+    terminates on, SURVEY A.3.7 -- so the second file repeats the first.)"""
+    from oracle import ref_driver as rd
+    rng = np.random.default_rng(5)
+    second = [bytes(bytearray(d)) for _, d in records]          # (a copy: every total doubles, none falls between 0 and 2)
+    other = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 900)]) + records[0][1][3000:3400]
+    return second, [rd.OracleIndex([d for _, d in records]), rd.OracleIndex([other])]
+
+
 def _single_process_files(records, compute, dtype):
     """what newmap_amd.search.write_unique_counts (and the reference, search.py:268-305) leaves on disk"""
     files = {}
@@ -84,6 +95,18 @@ def _worker(rank, world, port, outdir):
     res2 = parallel.search_records_sharded(records2, compute, kmax, batch, np.uint8, world, rank)
     if rank == 0:
         np.savez(os.path.join(outdir, f"w{world}_dup.npz"), **{k.decode(): v for k, v in res2.items()})
+    # two FASTA files in lock-step x two indexes (newmap/search.py:251-265, 656-697): the same plan, every file's segment
+    # of a unit handed to the compute
+    second, indexes = _lock_step_inputs(records)
+
+    def compute_multi(segs, count):
+        assert isinstance(segs, list) and len(segs) == 2 and len(segs[0]) == len(segs[1])
+        arr, _ = rd.binary_search_segments_multi(indexes, [rd.Segment(b"r", s_, True) for s_ in segs], kmin, kmax, np.uint8)
+        return arr[:count]
+
+    res3 = parallel.search_records_sharded(records, compute_multi, kmax, batch, np.uint8, world, rank, None, [second])
+    if rank == 0:
+        np.savez(os.path.join(outdir, f"w{world}_multi.npz"), **{k.decode(): v for k, v in res3.items()})
     dist.destroy_process_group()
 
 
@@ -99,6 +122,13 @@ def test_sharded_search_equals_single_process(tmp_path, world):
     for rid, data in records:
         want = rd.closed_form_min_unique(data, oracle, 8, 40)
         assert np.array_equal(got[rid.decode()], want), rid
+    # lock-step files x several indexes: the reference-shaped single-process loop over whole records
+    second, indexes = _lock_step_inputs(records)
+    multi = np.load(tmp_path / f"w{world}_multi.npz")
+    for (rid, data), other in zip(records, second):
+        want, _ = rd.binary_search_segments_multi(indexes, [rd.Segment(rid, data, True), rd.Segment(rid, other, True)], 8, 40, np.uint8)
+        assert np.array_equal(multi[rid.decode()], want), rid
+    assert any((multi[rid.decode()] != got[rid.decode()]).any() for rid, _ in records)      # (the mode changes results)
     # files written without a collective, and the gathered result, for records that share ids
     want_files = _single_process_files(_records_with_duplicates(), lambda d: rd.closed_form_min_unique(d, oracle, 8, 40), np.uint16)
     dup = np.load(tmp_path / f"w{world}_dup.npz")

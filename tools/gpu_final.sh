@@ -5,13 +5,14 @@
 #   tools/gpu_final.sh c NAME   kernel traces (headline, configs[4]), PMC of configs[4]'s kernels, configs[2]
 #   tools/gpu_final.sh d NAME   configs[4], list mode on the uniform and on the human-shaped 3 Gbp genome
 #   tools/gpu_final.sh e NAME   the CLI process end to end, the A/B soak
+#   tools/gpu_final.sh f NAME   configs[2] and the human-shaped genome, range mode
 #   tools/gpu_final.sh a NAME   the GPU suite
 part=$1
 O=gpurun_out/${2:-final}
 mkdir -p $O profiles/round3
 case $part in
 a)
-  python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/gputest.log
+  python -m pytest tests -m gpu -x -q --durations=12 > $O/gputest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/gputest.log
   ;;
 b)
   bash tools/profile_ns.sh $O/prof_ns > $O/prof_ns.txt 2>&1; tail -3 $O/prof_ns.txt
@@ -40,5 +41,9 @@ e)
   bash tools/profile_c5.sh $O/prof_c5 > $O/prof_c5.txt 2>&1; tail -3 $O/prof_c5.txt
   python tools/e2e_timing.py --config c3 --device-index --out $O/e2e_c3.json > $O/e2e_c3.log 2>&1; echo "e2e rc=$?"
   python tools/fuzz_gpu.py --rounds 150 > $O/fuzz_gpu.log 2>&1; echo "fuzz rc=$?"; tail -1 $O/fuzz_gpu.log
+  ;;
+f)
+  python bench.py --config c3 --steps 5 --warmup 2 --no-end-to-end --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err; echo "c3 rc=$?"; python tools/show_value.py $O/bench_c3.json
+  python bench.py --config hs --steps 3 --warmup 1 --no-end-to-end --no-cpu-baseline --no-configs1 > $O/bench_hs.json 2> $O/bench_hs.err; echo "hs rc=$?"; python tools/show_value.py $O/bench_hs.json
   ;;
 esac

@@ -492,15 +492,44 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
             for (uint32_t bits = s_need[i]; bits; bits &= bits - 1) s_q[atomicAdd(&s_qn, 1u)] = i * 32 + (uint32_t)__builtin_ctz(bits);
         __syncthreads();
     };
-    // ---- phase 3D (range mode with a dictionary, nm_core.h): an open position looks its x-mer up in the repeat dictionary --
-    // ONE 128-byte bucket, read by eight neighbouring lanes (16 bytes each, one line per load instruction and position).
-    // A miss: the x-mer occurs once, the element is kmin.  A hit: the position walks from an interval x bases deep
-    // (phase 4D).  Up to four positions per lane group are in flight.
     nm_tally t = {0, 0, 0, 0};
     bool any_err = false;
     uint64_t err_pos = ~0ULL;
     const bool use_dict = !LIST && ix.dict != nullptr && kmin >= ix.dict_len && !(ix.seed_policy & 0x1000u);
     bool dict_done = false;
+    // ---- phase 3: second chance.  A position no site settled asks the table with the longer cores (nm_second_chance; its
+    // window is in LDS).  All lookups of the block are in flight together; a block with many open positions sits in a
+    // long repeat and skips this.  With a dictionary: first this (one line settles most), then the dictionary for what is
+    // left (seed_policy bit 0x2000, measurement knob: the dictionary alone).
+    if (!(use_dict && (ix.seed_policy & 0x2000u)) && ix.quad2 != nullptr && kmin >= ix.quad2_m + NM_QUAD_EXT && s_open_total && s_open_total <= NM_SITE_CHANCE_MAX) {
+        gather_open();
+        const uint32_t n_q = s_qn;
+        __syncthreads();
+        if (tid == 0) s_qn = 0;
+        {
+            // (every lane takes part in the exchange of halves, with or without a position of its own)
+            const bool have = tid < n_q;
+            const uint32_t rel = have ? s_q[tid] : 0u;
+            const nm_window w = lds_window(rel);
+            const uint32_t m2 = ix.quad2_m;
+            const bool go2 = have && nm_site_core_valid(w, m2);
+            uint32_t b2[4];
+            uint64_t e2[4];
+            nm_quad_index(w, m2, b2);
+            nm_quad_finish_paired(nm_quad_issue_paired(ix.quad2 + nm_quad_slot(w, m2) * NM_QUAD_WORDS, go2, b2), e2);
+            if (have) n_entries += 4;
+            if (go2 && nm_second_chance_bits(ix, w, kmin, b2, e2)) {
+                nm_store(out, elem_bytes, base + rel, kmin);
+                atomicAnd(&s_need[rel >> 5], ~(1u << (rel & 31)));
+                atomicSub(&s_open_total, 1u);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase 3D (range mode with a dictionary, nm_core.h): an open position looks its x-mer up in the repeat dictionary --
+    // ONE 128-byte bucket, read by eight neighbouring lanes (16 bytes each, one line per load instruction and position).
+    // A miss: the x-mer occurs once, the element is kmin.  A hit: the position walks from an interval x bases deep
+    // (phase 4D).  Up to four positions per lane group are in flight.
     if (use_dict && s_open_total && s_open_total <= NM_SITE_CHANCE_MAX) {
         __shared__ uint32_t s_wpos[NM_SITE_CHANCE_MAX];
         __shared__ uint64_t s_went[NM_SITE_CHANCE_MAX];
@@ -576,34 +605,6 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         if (tid == 0) s_qn = 0;
         __syncthreads();
     }
-    // ---- phase 3: second chance.  A position no site settled asks the table with the longer cores (nm_second_chance; its
-    // window is in LDS).  All lookups of the block are in flight together; a block with many open positions sits in a
-    // long repeat and skips this.
-    if (!use_dict && ix.quad2 != nullptr && kmin >= ix.quad2_m + NM_QUAD_EXT && s_open_total && s_open_total <= NM_SITE_CHANCE_MAX) {
-        gather_open();
-        const uint32_t n_q = s_qn;
-        __syncthreads();
-        if (tid == 0) s_qn = 0;
-        {
-            // (every lane takes part in the exchange of halves, with or without a position of its own)
-            const bool have = tid < n_q;
-            const uint32_t rel = have ? s_q[tid] : 0u;
-            const nm_window w = lds_window(rel);
-            const uint32_t m2 = ix.quad2_m;
-            const bool go2 = have && nm_site_core_valid(w, m2);
-            uint32_t b2[4];
-            uint64_t e2[4];
-            nm_quad_index(w, m2, b2);
-            nm_quad_finish_paired(nm_quad_issue_paired(ix.quad2 + nm_quad_slot(w, m2) * NM_QUAD_WORDS, go2, b2), e2);
-            if (have) n_entries += 4;
-            if (go2 && nm_second_chance_bits(ix, w, kmin, b2, e2)) {
-                nm_store(out, elem_bytes, base + rel, kmin);
-                atomicAnd(&s_need[rel >> 5], ~(1u << (rel & 31)));
-                atomicSub(&s_open_total, 1u);
-            }
-        }
-        __syncthreads();
-    }
     // ---- phase 4: a few open positions (the rule outside long repeats): the block finishes them itself -- seed table +
     // walk -- and hands an empty bitmap on.  Many: they stay for the repeat probes and k_resolve.
     const uint32_t open_total = s_open_total;
@@ -659,6 +660,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
 #define NM_RES_BLOCK 256
 #define NM_RES_WORDS 256u           /* one word per lane: the walks at the end of a repeat (up to kmax steps each) run side by side, not in turns */
 #define NM_RES_QCAP 2048u
+#define NM_RES_HASH_BLOCKS 32u
 template <bool BIG, bool STATS, bool LIST>
 __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t num_kmers,
                                                           uint32_t kmin, uint32_t kmax, void *__restrict__ out, int elem_bytes,
@@ -667,11 +669,22 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
                                                           const unsigned long long *__restrict__ work,
                                                           uint64_t seq_len, const uint32_t *__restrict__ list, uint32_t n_list,
                                                           const uint64_t *__restrict__ hash_part, uint32_t n_hash_part) {
-    if (hash_part && blockIdx.x == 0) {                    // the segment's fingerprint: the partial sums of k_sites' blocks (nm_hash.h)
+    // the segment's fingerprint: the partial sums of k_sites' blocks (nm_hash.h), added up by the first blocks of this grid -- a
+    // slice each, so that no lane reads more than a few values one after the other (one block reading them all was a chain of
+    // ~100 dependent loads: 20 - 50 us per launch), and at most NM_RES_HASH_BLOCKS atomics meet on the status word
+    const uint32_t hb = gridDim.x < NM_RES_HASH_BLOCKS ? gridDim.x : NM_RES_HASH_BLOCKS;
+    if (hash_part && blockIdx.x < hb) {
         uint64_t term = 0;
-        for (uint32_t i = threadIdx.x; i < n_hash_part; i += NM_RES_BLOCK) term += hash_part[i];
+        for (uint32_t i = blockIdx.x * NM_RES_BLOCK + threadIdx.x; i < n_hash_part; i += hb * NM_RES_BLOCK) term += hash_part[i];
         for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, NM_WAVE);
-        if ((threadIdx.x & 63) == 0 && term) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)term);
+        __shared__ uint64_t s_term[NM_RES_BLOCK / 64];
+        if ((threadIdx.x & 63) == 0) s_term[threadIdx.x >> 6] = term;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t sum = 0;
+            for (uint32_t i = 0; i < NM_RES_BLOCK / 64; i++) sum += s_term[i];
+            if (sum) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)sum);
+        }
     }
     if (work[NM_WORK_OPEN] == 0) return;                   // every block of k_sites finished its own positions
     __shared__ uint32_t q_p[NM_RES_QCAP];

@@ -147,8 +147,10 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
     nm_pick_site_tables(ix, view, kmin);
     ix->last_site_m = view.quad_m;
     // the repeat dictionary answers for strings of dict_len bases, the second quad table for windows of quad2_m + 4: where the
-    // table's window is at least as long (a 100 Mbp genome: 18 against 17) its one line settles as much as the dictionary's,
-    // with fewer steps in the block -- measured 239 against 220 G positions/s; on 3 Gbp (19 against 20): 182 against 188
+    // table's window is at least as long (a 100 Mbp genome: 18 against 17) the dictionary has nothing to add to the second
+    // chance (measured 239 against 220 G positions/s with it).  Elsewhere the open positions ask the second table first and
+    // the dictionary takes what that leaves (k_sites phases 3, 3D): 3 Gbp, 20:200 179 -> 192 G; 24:150 295 -> 309 G
+    // (`profiles/round3/ab_dictionary_order.json`)
     if (view.dict && view.quad2 && kmin >= view.quad2_m + NM_QUAD_EXT && view.dict_len <= view.quad2_m + NM_QUAD_EXT) view.dict = nullptr;
     uint32_t d = kmin - (view.quad_m + NM_QUAD_EXT);
     if (d > ix->site_d_cap) d = ix->site_d_cap;

@@ -200,6 +200,8 @@ static int nm_build_dict(nm_index *ix) {
     uint32_t x = 1;
     while (x < 32 && (1ULL << (2 * x)) < ix->h.n) x++;
     x += 3;
+    // (its strings must be longer than the second quad table's windows: it takes what the second chance leaves, sec. 4)
+    if (ix->view.quad && ix->d_quad_small && x <= ix->view.quad_m + NM_QUAD_EXT) x = ix->view.quad_m + NM_QUAD_EXT + 1;    // (view.quad: the long cores, the second chance of launches that read the short ones)
     if (const char *e = getenv("NEWMAP_AMD_DICT_LEN")) x = (uint32_t)atoi(e);
     if (x > NM_DICT_MAX_LEN) x = NM_DICT_MAX_LEN;
     if (x <= s) return NM_OK;
@@ -572,7 +574,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_SEED_POLICY) {
-        if (value < 0 || (value & 0xFF) > 2 || value > 0x1FFF) { nm_set_error("seed policy must be 0, 1 or 2 (+ 0x100 / 0x200 timing experiments)"); return NM_E_ARGUMENT; }
+        if (value < 0 || (value & 0xFF) > 2 || value > 0x3FFF) { nm_set_error("seed policy must be 0, 1 or 2 (+ measurement bits 0x100 .. 0x2000)"); return NM_E_ARGUMENT; }
         ix->view.seed_policy = (uint32_t)value;
         return NM_OK;
     }

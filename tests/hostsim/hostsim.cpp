@@ -546,8 +546,16 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             for (uint32_t t = 0; t < 4; t++)
                 if ((inb >> t) & 1u) store(q + t, (hit >> t) & 1u ? kmin : 0u);
         }
-        // repeat dictionary (k_sites phases 3D / 4D): a miss settles the position as kmin, a hit walks from the x-mer's interval
         const bool use_dict = !list && v.dict && kmin >= v.dict_len;
+        // second chance: the open positions of a block with few of them ask the table with the longer cores
+        if (chance && open_total && open_total <= chance_max)
+            for (uint32_t i = 0; i < BP / 32; i++)
+                for (uint32_t bits = s_need[i]; bits; bits &= bits - 1) {
+                    const uint32_t rel = i * 32 + (uint32_t)__builtin_ctz(bits);
+                    counters[0]++;
+                    if (nm_second_chance(v, lds_window(rel), kmin)) { store(base + rel, kmin); s_need[i] &= ~(1u << (rel & 31)); open_total--; counters[4]++; }
+                }
+        // repeat dictionary (k_sites phases 3D / 4D): a miss settles the position as kmin, a hit walks from the x-mer's interval
         bool dict_done = false;
         if (use_dict && open_total && open_total <= chance_max) {
             std::vector<std::pair<uint32_t, uint64_t>> walkers;
@@ -581,14 +589,6 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
                 dict_done = true;
             }
         }
-        // second chance: the open positions of a block with few of them ask the table with the longer cores
-        if (!use_dict && chance && open_total && open_total <= chance_max)
-            for (uint32_t i = 0; i < BP / 32; i++)
-                for (uint32_t bits = s_need[i]; bits; bits &= bits - 1) {
-                    const uint32_t rel = i * 32 + (uint32_t)__builtin_ctz(bits);
-                    counters[0]++;
-                    if (nm_second_chance(v, lds_window(rel), kmin)) { store(base + rel, kmin); s_need[i] &= ~(1u << (rel & 31)); open_total--; counters[4]++; }
-                }
         // a few open positions: the block finishes them itself; many: they stay for the probes and k_resolve
         const bool self = !dict_done && open_total && open_total <= walk_max && kmax <= NM_SITE_LA_MAX;
         if (self) {

@@ -890,7 +890,7 @@ def test_both_range_kernels_agree(mixed_genome, eng):
     with eng.Index(g["idx"], 0) as ix:
         info = ix.info()
         assert 8 <= info["quad_small_core_length"] < info["quad_core_length"] <= info["seed_length"]
-        assert info["seed_length"] < info["dict_length"] <= 20 and info["dict_entries"] > 0
+        assert max(info["seed_length"], info["quad_core_length"] + 4) < info["dict_length"] <= 24 and info["dict_entries"] > 0
         w = info["quad_small_core_length"] + 4                # the shortest window the sites can use
         for rec in (g["r1"], g["r2"]):
             for kmin, kmax in ((20, 200), (8, 30), (20, 1000), (w, 64), (w - 1, 64), (w + 1, 64), (60, 90), (61, 90), (62, 90),

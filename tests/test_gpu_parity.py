@@ -734,11 +734,11 @@ def _records_fasta(recs):
 
 
 def test_config3_human_shaped_24_records(tmp_path, eng):
-    """BASELINE configs[2] at 1/1000 scale: 24 records, search-range 24:150, written through
+    """BASELINE configs[2] at 1/1500 scale: 24 records, search-range 24:150, written through
     write_unique_counts with a batch that splits the larger records."""
     from newmap_amd import synth
     from newmap_amd.search import SearchConfig, write_unique_counts
-    recs = synth.config_genome("c3", 3.0)
+    recs = synth.config_genome("c3", 2.0)
     fa, idx = _build_index(tmp_path, _records_fasta(recs), "c3")
     out = tmp_path / "out"
     out.mkdir()
@@ -754,9 +754,9 @@ def test_config3_human_shaped_24_records(tmp_path, eng):
 
 
 def test_config5_tandem_repeats_20_255(tmp_path, eng):
-    """BASELINE configs[4] at 1/500 scale: 50 % tandem repeats, 20:255 (worst-case walk depth)."""
+    """BASELINE configs[4] at 1/800 scale: 50 % tandem repeats, 20:255 (worst-case walk depth)."""
     from newmap_amd import synth
-    recs = synth.config_genome("c5", 2.0)
+    recs = synth.config_genome("c5", 1.25)
     fa, idx = _build_index(tmp_path, _records_fasta(recs), "c5")
     rec = recs[0][1].tobytes()
     oracle = rd.OracleIndex([rec])
@@ -858,7 +858,7 @@ def test_config4_human_shaped_stand_in(tmp_path, eng):
     fa, idx = _build_index(tmp_path, _records_fasta(recs), "hs")
     oracle = rd.OracleIndex([s.tobytes() for _, s in recs])
     with eng.Index(idx, 0) as ix:
-        for name, seq in recs[:8] + recs[-2:]:
+        for name, seq in recs[:5] + recs[-1:]:
             data = seq.tobytes()
             seg = rd.Segment(name.encode(), data, True)
             for ks in ([36], [100], [24, 36, 50, 100]):

@@ -61,6 +61,8 @@ class Index:
             self.set_kernel(int(os.environ["NEWMAP_AMD_KERNEL"]))
         if os.environ.get("NEWMAP_AMD_REPEAT_PROBES"):
             self.set_repeat_probes(os.environ["NEWMAP_AMD_REPEAT_PROBES"] != "0")
+        if os.environ.get("NEWMAP_AMD_SITE_TABLE"):        # 1: the sites read the long cores, 2: the short ones (set_site_table)
+            self.set_site_table(int(os.environ["NEWMAP_AMD_SITE_TABLE"]))
         if os.environ.get("NEWMAP_AMD_SEED_POLICY"):
             _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SEED_POLICY,
                                                  int(os.environ["NEWMAP_AMD_SEED_POLICY"], 0)))

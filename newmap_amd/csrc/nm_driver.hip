@@ -606,7 +606,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
     // turn: it strips the unit's lines straight into its pinned buffer, submits copy-in, kernels and copy-out (one
     // worker at a time: the handle's calls are made one by one), waits for its event and pwrite()s the result into the
     // record's file.  Strip, transfers, kernels and file writes of different units overlap; nothing is staged twice.
-    int n_workers = d.batch <= (40u << 20) ? 8 : 4;           // (measured on 3.09 Gbp: 8 workers of 32 M units; more workers only contend)
+    int n_workers = d.batch <= (40u << 20) ? 10 : 4;          // (measured on 3.09 Gbp, 16 CPUs granted: 10 workers of 32 M units on 5 streams; 16 workers contend)
     if (const char *e = getenv("NEWMAP_AMD_DRIVER_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_workers = v; }
     if ((size_t)n_workers > units.size()) n_workers = units.empty() ? 1 : (int)units.size();
     const size_t piece_slack = 2 * nm_fasta::kPieceBytes + 4096;    // a unit is stripped piece-wise: whole pieces around it
@@ -616,9 +616,14 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         d.fail(NM_E_DEVICE, std::string("HIP error (") + hipGetErrorString(e) + "): " + what);
         return false;
     };
-    int n_streams = 2;                                          // NEWMAP_AMD_DRIVER_STREAMS = 1 .. 4
-    if (const char *e = getenv("NEWMAP_AMD_DRIVER_STREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 4) n_streams = v; }
+    // (each stream is a chain copy-in -> kernels -> copy-out: a unit of 32 M positions holds its stream for ~4 ms, most of it the
+    // two DMA copies, so the number of streams is the number of copies in flight -- 3.09 Gbp: 2 streams 0.33 s, 4 streams 0.26 s,
+    // 5 streams 0.244 s)
+    int n_streams = 5;                                          // NEWMAP_AMD_DRIVER_STREAMS = 1 .. 5 (the handle has five lanes for caller streams)
+    if (const char *e = getenv("NEWMAP_AMD_DRIVER_STREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 5) n_streams = v; }
     const bool phase_times = getenv("NEWMAP_AMD_DRIVER_TIMING") != nullptr;
+    bool zero_copy = false;
+    if (const char *e = getenv("NEWMAP_AMD_DRIVER_ZEROCOPY")) zero_copy = e[0] == '1';
     std::atomic<uint64_t> t_strip_us{0}, t_submit_us{0}, t_wait_us{0}, t_write_us{0};
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
@@ -643,6 +648,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         }
     }
     if (rc == NM_OK && d.error.load() != NM_OK) rc = d.error.load();
+    const double t_setup = now() - t_begin;
     std::atomic<size_t> next_unit{0};
     std::vector<std::atomic<long>> file_done(d.files.size());
     for (auto &x : file_done) x = 0;
@@ -673,11 +679,13 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
                 bool ok;
                 {
                     std::lock_guard<std::mutex> g(submit_mu);
-                    ok = hip_ok(hipMemcpyAsync(s.d_in, src, u.seg_len, hipMemcpyHostToDevice, st), "copy to device");
+                    // (NEWMAP_AMD_DRIVER_ZEROCOPY=1, experiment: the kernels read the pinned slot over the bus themselves)
+                    const void *dev_in = zero_copy ? (const void *)src : (const void *)s.d_in;
+                    ok = zero_copy || hip_ok(hipMemcpyAsync(s.d_in, src, u.seg_len, hipMemcpyHostToDevice, st), "copy to device");
                     if (ok) {
                         const int e = d.range_mode
-                            ? nm_min_unique_segment_dev(d.ix, s.d_in, u.seg_len, u.count, d.kmin, d.kmax, d.use_rc, d.elem_bytes, s.d_out, s.d_status, st)
-                            : nm_fixed_k_segment_dev(d.ix, s.d_in, u.seg_len, u.count, d.ks.data(), (uint32_t)d.ks.size(), d.use_rc, d.elem_bytes, s.d_out, s.d_status, st);
+                            ? nm_min_unique_segment_dev(d.ix, dev_in, u.seg_len, u.count, d.kmin, d.kmax, d.use_rc, d.elem_bytes, s.d_out, s.d_status, st)
+                            : nm_fixed_k_segment_dev(d.ix, dev_in, u.seg_len, u.count, d.ks.data(), (uint32_t)d.ks.size(), d.use_rc, d.elem_bytes, s.d_out, s.d_status, st);
                         if (e != NM_OK) { d.fail(e, nm_last_error()); ok = false; }
                     }
                     if (ok) {
@@ -775,8 +783,8 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
     for (hipStream_t st : d.streams) { (void)nm_stream_release(ix, st); (void)hipStreamDestroy(st); }
     unmap();
     if (phase_times)
-        fprintf(stderr, "[driver] total %.3fs, %d workers, %zu units; summed over the workers: strip %.3f, submit %.3f, wait for the device %.3f, write %.3f s\n",
-                now() - t_begin, n_workers, units.size(), t_strip_us.load() * 1e-6, t_submit_us.load() * 1e-6, t_wait_us.load() * 1e-6, t_write_us.load() * 1e-6);
+        fprintf(stderr, "[driver] total %.3fs (streams, pinned slots, device buffers: %.3f), %d workers, %zu units; summed over the workers: strip %.3f, submit %.3f, wait for the device %.3f, write %.3f s\n",
+                now() - t_begin, t_setup, n_workers, units.size(), t_strip_us.load() * 1e-6, t_submit_us.load() * 1e-6, t_wait_us.load() * 1e-6, t_write_us.load() * 1e-6);
     if (rc != NM_OK) return rc;
     if (rec_info) {
         rec_info->clear();

@@ -81,7 +81,9 @@ void nm_index_close(nm_index *ix);
  * range-mode launch's repeat probes (waits for the device; 14..16 need
  * NM_OPT_COUNT_STEPS): 14 LF steps, 15 rank blocks read, 16 seed entries read, 17 positions
  * settled without a search; 18 core length of the quad table (0 = none), 19 core length of the second quad table with
- * short cores (0 = none), 20 core length of the table the sites of the last launch read */
+ * short cores (0 = none), 20 core length of the table the sites of the last launch read; 21 fingerprint of the last
+ * host-buffer segment call, 22 initial search length, 23 segments that went through the exact guard, 24 / 25 string length
+ * and entries of the repeat dictionary (0 = none), 26 two-base LF blocks built (1) or not */
 uint64_t nm_index_info(const nm_index *ix, int what);
 
 /* ------------------------------------------------------------------------- compat seam ------

@@ -901,6 +901,10 @@ def test_both_range_kernels_agree(mixed_genome, eng):
                 a, amb_a = ix.min_unique_segment(rec, len(rec), kmin, kmax)
                 if (kmin, kmax) in ((20, 200), (w, 64), (252, 255)):
                     assert np.array_equal(a, rd.closed_form_min_unique(rec, g["oracle"], kmin, kmax))
+                ix.set_lf2(False)                                 # single LF steps only (the two-base LF blocks are an A/B switch)
+                a1, _ = ix.min_unique_segment(rec, len(rec), kmin, kmax)
+                ix.set_lf2(True)
+                assert info["lf2_blocks"] == 1 and np.array_equal(a, a1), ("two-base steps", kmin, kmax)
                 sites_ok = w <= kmin <= 252                       # NM_SITE_MAX_KMIN
                 for big in (False, True):
                     ix.set_force_big(big)

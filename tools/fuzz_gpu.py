@@ -79,6 +79,7 @@ def main():
                 plain.set_kernel(1)
                 plain.set_repeat_probes(False)
                 plain.set_list_via_range(False)
+                plain.set_lf2(False)                       # the plain side walks base by base
                 fast.set_force_big(bool(rng.random() < 0.5))
                 w = (fast.info()["quad_small_core_length"] or fast.info()["quad_core_length"]) + 4
                 for _ in range(6):
@@ -86,6 +87,7 @@ def main():
                     fast.set_repeat_probes(bool(rng.random() < 0.8))
                     fast.set_site_table(int(rng.choice([0, 0, 1, 2])))
                     fast.set_dictionary(bool(rng.random() < 0.7))
+                    fast.set_lf2(bool(rng.random() < 0.8))
                     kmin = int(rng.choice([w, w + 1, 20, 24, 36, 60, 61, 62, 64, 100, 124, 125, 190, 252, 253, int(rng.integers(1, 200))]))
                     kmax = int(kmin + rng.choice([0, 1, 5, 40, 130, 231, int(rng.integers(0, 3000))]))
                     batch = int(rng.choice([1 << 30, 10_007, 65_536, int(rng.integers(500, 200_000))]))

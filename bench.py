@@ -567,6 +567,13 @@ def end_to_end(args, wl: Workload, fa, idx, dev_index, gpu_run: Run):
         t0 = time.time()
         total = ix.search_fasta(fa, out, [wl.krange[0], wl.krange[1]], True, True, REFERENCE_BATCH)   # the CLI's default --kmer-batch-size
         t_search = time.time() - t0
+        # (the first call of a handle also creates its lanes' scratch and the driver's pinned slots; a resident handle's next call,
+        #  into an empty directory again -- truncating 3 GB of cached files is not the driver's time:)
+        shutil.rmtree(out, ignore_errors=True)
+        out.mkdir(parents=True)
+        t0 = time.time()
+        ix.search_fasta(fa, out, [wl.krange[0], wl.krange[1]], True, True, REFERENCE_BATCH)
+        t_again = time.time() - t0
     checked = 0
     for (so, seg_len, cnt, oo, i) in gpu_run.segs[:2]:
         u = gpu_run.units[i]
@@ -579,7 +586,7 @@ def end_to_end(args, wl: Workload, fa, idx, dev_index, gpu_run: Run):
         checked += n
     files = sorted(out.iterdir())
     res = {"what": "nm_search_fasta: FASTA in -> <id>.unique.uint8 files out (auto-small tables), 1 GPU",
-           "cli_search_s": t_search, "index_open_s": t_open, "positions": int(total["positions"]),
+           "cli_search_s": t_search, "cli_search_s_second_call": t_again, "index_open_s": t_open, "positions": int(total["positions"]),
            "positions_per_s": total["positions"] / t_search, "positions_per_s_with_index_open": total["positions"] / (t_search + t_open),
            "files": len(files), "bytes_written": int(sum(f.stat().st_size for f in files)),
            "verified_bytes_equal_bench_pass": checked}

@@ -159,6 +159,9 @@ static int nm_build_lf2(nm_index *ix) {
         if (table) (void)hipFree(table);
         return NM_OK;
     }
+    ix->d_lf2 = table;                                             // (nm_index_close frees it, whatever happens below)
+    ix->device_bytes += bytes;
+    struct Sums { uint64_t *p; ~Sums() { if (p) (void)hipFree(p); } } sums_guard{d_sums};
     const nm_view v = ix->view;
     const uint64_t slice_blocks = 1ULL << 24;                      // (grid * block below 2^32: 64 lanes per block of rows)
     for (uint64_t first = 0; first < n_blocks; first += slice_blocks) {
@@ -179,9 +182,6 @@ static int nm_build_lf2(nm_index *ix) {
     else         hipLaunchKernelGGL(k_lf2_finish<false>, dim3(nm_grid(n_chunks * 16)), dim3(NM_BLOCK), 0, ix->stream, v, (nm_lf_entry *)table, n_blocks, n_chunks, (const uint64_t *)d_sums);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ix->stream));
-    (void)hipFree(d_sums);
-    ix->d_lf2 = table;
-    ix->device_bytes += bytes;
     ix->view.lf2 = (const nm_lf_entry *)table;
     if (nm_verbose()) fprintf(stderr, "[open] two-base LF blocks (%.1f GB): %.3fs\n", bytes / 1e9, nm_now() - t0);
     return NM_OK;

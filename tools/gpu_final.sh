@@ -23,6 +23,7 @@ b)
   python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err; echo "bench (driver's flags) rc=$?"; python tools/show_value.py $O/bench_driver_flags.json
   NEWMAP_AMD_BENCH_REHEARSE=1 python bench.py --gpus 2 --steps 5 --warmup 1 --mbp 600 > $O/bench_n2_rehearsal.json 2> $O/bench_n2_rehearsal.err; echo "n2 rc=$?"
   NEWMAP_AMD_BENCH_REHEARSE=1 python bench.py --gpus 3 --steps 5 --warmup 1 --mbp 600 > $O/bench_n3_rehearsal.json 2> $O/bench_n3_rehearsal.err; echo "n3 rc=$?"
+  NEWMAP_AMD_BENCH_REHEARSE=1 python bench.py --gpus 4 --steps 3 --warmup 1 --mbp 400 > $O/bench_n4_rehearsal.json 2> $O/bench_n4_rehearsal.err; echo "n4 rc=$?"
   ;;
 c)
   bash tools/kernel_trace_ns.sh $(basename $O)/traces > $O/traces.txt 2>&1; tail -12 $O/traces.txt

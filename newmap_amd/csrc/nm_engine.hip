@@ -20,15 +20,19 @@
 // The per-position logic lives in nm_core.h.
 #include <hip/hip_runtime.h>
 
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/newmap_amd.h"
 #include "nm_format.h"

@@ -9,11 +9,9 @@ import threading
 from pathlib import Path
 from typing import Sequence
 
-import numpy as np
+from ._lazy import np        # numpy, imported at its first use: the one-shot CLI's native path never needs it (0.15 s)
 
 from . import _lib
-
-_DTYPES = {1: np.uint8, 2: np.uint16, 4: np.uint32}
 
 
 def default_device() -> int:
@@ -304,8 +302,8 @@ class Index:
         (length, fingerprint of this rank's share, searched) per FASTA record with data -- the caller joins the ranks
         (newmap_amd/parallel.py).  With one rank the record check and the exact guard run inside the call.  Returns the
         totals as a dict."""
-        ks = np.ascontiguousarray([min(kmer_lengths), max(kmer_lengths)] if is_range else list(kmer_lengths),
-                                  dtype=np.uint32)
+        lengths = [min(kmer_lengths), max(kmer_lengths)] if is_range else [int(k) for k in kmer_lengths]
+        ks = (ctypes.c_uint32 * len(lengths))(*lengths)                     # (no numpy on this path: newmap_amd/_lazy.py)
         fields = [f[0] for f in _lib.SearchSummary._fields_]
 
         def _cb(rec_id, summary, _user):
@@ -317,13 +315,13 @@ class Index:
         exc = (ctypes.c_char_p * max(len(exclude), 1))(*[bytes(x) for x in exclude])
         total = _lib.SearchSummary()
         cap = 1 << 20
-        info = np.zeros(3 * cap if record_info is not None else 3, dtype=np.uint64)
+        info = (ctypes.c_uint64 * (3 * cap if record_info is not None else 3))()
         n_info = ctypes.c_uint64(0)
         with self._lock:
-            rc = self._L.nm_search_fasta_shard_ex(self.handle, os.fsencode(fasta_path), os.fsencode(out_dir), ks.ctypes.data,
-                                                  ks.size, int(bool(is_range)), int(bool(use_revcomp)), int(batch),
+            rc = self._L.nm_search_fasta_shard_ex(self.handle, os.fsencode(fasta_path), os.fsencode(out_dir), ctypes.addressof(ks),
+                                                  len(lengths), int(bool(is_range)), int(bool(use_revcomp)), int(batch),
                                                   inc, len(include), exc, len(exclude), cb, None, ctypes.byref(total),
-                                                  int(rank), int(world), info.ctypes.data if record_info is not None else None,
+                                                  int(rank), int(world), ctypes.addressof(info) if record_info is not None else None,
                                                   cap if record_info is not None else 0, ctypes.byref(n_info))
         if record_info is not None:
             if n_info.value > cap:

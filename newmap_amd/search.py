@@ -15,7 +15,7 @@ from math import ceil, log2
 from pathlib import Path
 from typing import Callable, Sequence
 
-import numpy as np
+from ._lazy import np        # numpy, imported at its first use: the one-shot CLI's native path never needs it (0.15 s)
 
 from .engine import Index, cached_index
 from .fasta import SequenceSegment, sequence_segments

@@ -9,7 +9,13 @@ extern "C" int nm_min_unique_segment_dev(nm_index *ix, const void *d_seq, uint64
     if (!d_status) { nm_set_error("d_status is required"); return NM_E_ARGUMENT; }
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    const double t_call = nm_verbose() ? nm_now() : 0.0;
     if ((rc = nm_lane_for(ix, st)) != NM_OK) return rc;
+    const double t_lane = nm_verbose() ? nm_now() : 0.0;
+    struct Slow {                                                  // NEWMAP_AMD_VERBOSE: calls that held the host for long (first use of a lane)
+        double t0, t1; uint64_t n;
+        ~Slow() { if (t0 > 0 && nm_now() - t0 > 2e-3) fprintf(stderr, "[segment] host side of a launch of %llu positions: %.1f ms (lane %.1f ms)\n", (unsigned long long)n, (nm_now() - t0) * 1e3, (t1 - t0) * 1e3); }
+    } slow{t_call, t_lane, num_kmers};
     if (num_kmers == 0) return nm_reset_status(ix, d_status, st);
     nm_view view;
     if ((rc = nm_view_for(ix, kmin, &view)) != NM_OK) return rc;

@@ -39,7 +39,7 @@ def main():
         wall = time.time() - t0
         print(f"--- run {rep}: process wall {wall:.3f}s, rc {p.returncode}")
         for line in p.stderr.splitlines():
-            if line.startswith(("[open]", "[driver]", "[child]")):
+            if line.startswith(("[open]", "[driver]", "[child]", "[segment]")):
                 print("   ", line)
         shutil.rmtree(out, ignore_errors=True)
 

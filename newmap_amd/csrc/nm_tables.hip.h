@@ -333,7 +333,29 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     ix->h = h;
     ix->big = h.n_super > 1;
     int rc = NM_OK;
-    auto fail = [&](int code) { fclose(fp); nm_index_close(ix); return code; };
+    struct Stage {                                                 // two pinned buffers the index file is uploaded through (below)
+        uint8_t *buf[2] = {nullptr, nullptr};
+        hipEvent_t sent[2] = {nullptr, nullptr};
+        bool used[2] = {false, false};
+        uint64_t turn = 0;
+        bool ok = false;
+        void release() {                                           // (the caller has waited for the copies out of the buffers)
+            for (int i = 0; i < 2; i++) {
+                if (sent[i]) (void)hipEventDestroy(sent[i]);
+                if (buf[i]) (void)hipHostFree(buf[i]);
+                sent[i] = nullptr; buf[i] = nullptr;
+            }
+            ok = false;
+        }
+        ~Stage() { release(); }
+    } stage;
+    auto fail = [&](int code) {
+        if (ix->stream) (void)hipStreamSynchronize(ix->stream);   // (a copy out of a staging buffer may be on its way)
+        stage.release();
+        fclose(fp);
+        nm_index_close(ix);
+        return code;
+    };
     if (hipSetDevice(device) != hipSuccess) { nm_set_error("hipSetDevice(%d) failed", device); return fail(NM_E_DEVICE); }
     if (hipStreamCreate(&ix->stream) != hipSuccess) { nm_set_error("hipStreamCreate failed"); return fail(NM_E_DEVICE); }
     ix->lanes[0].owner = ix->stream;
@@ -352,20 +374,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     // stage through two pinned buffers: the file is read once, sequentially, and the read of a chunk (page cache -> pinned)
     // overlaps the DMA of the chunk before it (a pageable buffer made every chunk wait for its own copy: 4.6 GB of a human
     // index in ~0.25 s of the one-shot CLI's 1.2 s)
-    struct Stage {
-        uint8_t *buf[2] = {nullptr, nullptr};
-        hipEvent_t sent[2] = {nullptr, nullptr};
-        bool used[2] = {false, false};
-        hipStream_t *stream = nullptr;
-        uint64_t turn = 0;
-        bool ok = false;
-        ~Stage() {
-            if (stream && *stream) (void)hipStreamSynchronize(*stream);
-            for (int i = 0; i < 2; i++) { if (sent[i]) (void)hipEventDestroy(sent[i]); if (buf[i]) (void)hipHostFree(buf[i]); }
-        }
-    } stage;
     const uint64_t chunk = 64ULL << 20;
-    stage.stream = &ix->stream;
     stage.ok = hipHostMalloc((void **)&stage.buf[0], chunk, hipHostMallocDefault) == hipSuccess &&
                hipHostMalloc((void **)&stage.buf[1], chunk, hipHostMallocDefault) == hipSuccess &&
                hipEventCreateWithFlags(&stage.sent[0], hipEventDisableTiming) == hipSuccess &&
@@ -420,6 +429,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if ((rc = upload(&ix->d_strand, h.off_strand, strand_bytes)) != NM_OK) return fail(rc);
     if ((rc = upload(&ix->d_sep, h.off_sep, h.n_sep * sizeof(uint64_t))) != NM_OK) return fail(rc);
     if (hipStreamSynchronize(ix->stream) != hipSuccess) { nm_set_error("upload of %s failed", index_path); return fail(NM_E_DEVICE); }
+    stage.release();
     (void)sep_bytes;
     if (hipMalloc(&ix->d_super, superC.size() * sizeof(uint64_t)) != hipSuccess ||
         hipMemcpy(ix->d_super, superC.data(), superC.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {

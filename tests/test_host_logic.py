@@ -177,3 +177,14 @@ def test_native_fasta_scan_equals_python_reader(tmp_path, golden_host):
         assert lens[0] == len(data)
         for (i, lo, hi), piece in zip(ranges, pieces):
             assert piece == data[lo:hi], (threads, chunk, lo, hi)
+
+
+def test_cli_imports_stay_light():
+    """the one-shot CLI's native path needs no numpy on the Python side: importing the command line must not import it
+    (0.2 s of a 0.9 s process on a 3 Gbp genome); the first array use does"""
+    import subprocess
+    import sys
+    code = ("import sys; import newmap_amd.main; assert 'numpy' not in sys.modules, 'numpy imported by the CLI modules'; "
+            "from newmap_amd import engine; assert engine.np.dtype('uint8').itemsize == 1 and 'numpy' in sys.modules; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr

@@ -306,6 +306,43 @@ def test_two_base_lf_blocks(tmp_path, force_big):
                 assert code == 0 and np.array_equal(got[keep], want[:head][keep]), (ks, probes)
 
 
+def test_two_base_lf_blocks_random_texts(tmp_path):
+    """small random multi-record texts (tandem stretches, copies, N runs, one-base records): the two-base step equals two
+    single steps everywhere, and walks with it equal walks without it and the oracle"""
+    rng = np.random.default_rng(2028)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    for trial in range(6):
+        recs = []
+        for r in range(int(rng.integers(1, 5))):
+            n = int(rng.integers(1, 1500))
+            d = bytearray(bytes(alpha[rng.integers(0, 4, n)]))
+            if n > 200:
+                u = bytes(alpha[rng.integers(0, 4, int(rng.integers(1, 9)))])
+                a = int(rng.integers(0, n - 150))
+                d[a:a + 120] = (u * 120)[:120]
+                b = int(rng.integers(0, n - 60))
+                d[b:b + 50] = d[a + 10:a + 60]
+                d[int(rng.integers(0, n))] = ord("N")
+            recs.append(bytes(d))
+        fa = _write(tmp_path, b"".join(b">r%d\n" % i + d + b"\n" for i, d in enumerate(recs)), f"t{trial}.fa")
+        idx = tmp_path / f"t{trial}.awfmi"
+        generate_fm_index(str(fa), str(idx), 8, 12)
+        oracle = rd.OracleIndex(recs)
+        for big in (False, True):
+            sim = HostSim(idx, 4, big)
+            sim.enable_lfb(bool(trial & 1))
+            sim.enable_lf2(True)
+            assert sim.check_lf2() == 0, (trial, big)
+            for rec in recs:
+                for kmin, kmax in ((1, 30), (5, 90), (20, 200)):
+                    dtype, _ = rd.output_dtype(kmax)
+                    want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
+                    for on in (True, False):
+                        sim.enable_lf2(on)
+                        got, _, code = sim.min_unique(rec, len(rec), kmin, kmax, True, dtype)
+                        assert code == 0 and np.array_equal(got, want), (trial, big, on, kmin, kmax)
+
+
 def test_repeat_probes_decide_only_what_the_oracle_confirms(tmp_path):
     """nm_repeat_probe / nm_probe_kstar / nm_probe_element (the logic of k_repeat_probe and of its consumers):
     every element the probes decide -- zeros inside long repeats, exact lengths where two neighbouring probes

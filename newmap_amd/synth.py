@@ -143,6 +143,17 @@ def write_fasta(path, records: list[tuple[str, np.ndarray]], width: int = 60):
     return path
 
 
+def _records_in_parallel(names, make) -> list[tuple[str, np.ndarray]]:
+    """the 24 records of a genome, each from its own seed: generated by a few threads (numpy's generators and gathers run
+    without the interpreter lock), same bytes as one after the other"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4))
+    with ThreadPoolExecutor(workers) as pool:
+        seqs = list(pool.map(lambda t: make(t[0], t[1]), enumerate(HUMAN_SHAPED)))
+    return list(zip(names, seqs))
+
+
 def config_genome(name: str, scale_mbp: float | None = None) -> list[tuple[str, np.ndarray]]:
     """Records of a BASELINE config: 'c2' (100 Mbp uniform, seed 20260515), 'c3' (24 human-shaped
     records, seeds 20260516+i), 'c5' (1 Gbp, 50 % tandem repeats, seed 20260517), 'hs' (24 records of
@@ -155,8 +166,7 @@ def config_genome(name: str, scale_mbp: float | None = None) -> list[tuple[str, 
         total = sum(HUMAN_SHAPED)
         f = 1.0 if scale_mbp is None else scale_mbp * 1e6 / total
         names = [f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY"]
-        return [(nm, uniform_dna(max(1000, int(L * f)), 20260516 + i))
-                for i, (nm, L) in enumerate(zip(names, HUMAN_SHAPED))]
+        return _records_in_parallel(names, lambda i, L: uniform_dna(max(1000, int(L * f)), 20260516 + i))
     if name == "c5":
         n = int((scale_mbp or 1000) * 1e6)
         return [("rep1", tandem_dna(n, 20260517))]
@@ -164,6 +174,5 @@ def config_genome(name: str, scale_mbp: float | None = None) -> list[tuple[str, 
         total = sum(HUMAN_SHAPED)
         f = 1.0 if scale_mbp is None else scale_mbp * 1e6 / total
         names = [f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY"]
-        return [(nm, human_like_dna(max(100_000, int(L * f)), 20260600 + i))
-                for i, (nm, L) in enumerate(zip(names, HUMAN_SHAPED))]
+        return _records_in_parallel(names, lambda i, L: human_like_dna(max(100_000, int(L * f)), 20260600 + i))
     raise ValueError(f"unknown config {name!r}")

@@ -137,7 +137,7 @@ def write_fasta(path, records: list[tuple[str, np.ndarray]], width: int = 60):
                 block = np.empty((full, width + 1), dtype=np.uint8)
                 block[:, :width] = seq[:full * width].reshape(full, width)
                 block[:, width] = 10
-                fh.write(block.tobytes())
+                fh.write(block.reshape(-1).data)                  # (the array's own buffer: no second copy of a 250 MB record)
             if n % width:
                 fh.write(seq[full * width:].tobytes() + b"\n")
     return path

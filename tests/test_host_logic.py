@@ -188,3 +188,16 @@ def test_cli_imports_stay_light():
             "from newmap_amd import engine; assert engine.np.dtype('uint8').itemsize == 1 and 'numpy' in sys.modules; print('ok')")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+
+
+def test_synthetic_genomes_do_not_depend_on_the_thread_pool():
+    """the records of the bench genomes come from their own seeds: generated by a thread pool, same bytes as one by one"""
+    from newmap_amd import synth
+    got = synth.config_genome("c3", 0.5)
+    f = 0.5e6 / sum(synth.HUMAN_SHAPED)
+    assert len(got) == 24 and got[0][0] == "chr1" and got[-1][0] == "chrY"
+    for i, (name, seq) in enumerate(got):
+        assert np.array_equal(seq, synth.uniform_dna(max(1000, int(synth.HUMAN_SHAPED[i] * f)), 20260516 + i)), name
+    hs = synth.config_genome("hs", 3.0)
+    for i in (0, 7, 23):
+        assert np.array_equal(hs[i][1], synth.human_like_dna(max(100_000, int(synth.HUMAN_SHAPED[i] * 3.0e6 / sum(synth.HUMAN_SHAPED))), 20260600 + i))

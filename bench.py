@@ -371,7 +371,9 @@ class Run:
         for seg in self.segs:
             self.step([seg])
             torch.cuda.synchronize()
-            tallies += self.d_status[seg[4]].cpu().numpy()
+            row = self.d_status[seg[4]].cpu().numpy()
+            tallies[:12] += row[:12]
+            tallies[12:14] = np.maximum(tallies[12:14], row[12:14])       # (k_sweep: longest chain / longest wave, in turns)
             for k_, v_ in self.ix.probe_tally().items():
                 probe[k_] += v_
         self.ix.set_count_steps(False)
@@ -487,7 +489,9 @@ def pipeline_block(run: Run, kinds, tallies, probe):
     return {"kernels": "k_reset_status + k_sites (encodes the raw bytes itself) + k_repeat_probe(_coarse) + k_resolve", "avg_segment_ms": all_ms / max(n_seg_launch, 1),
             "segments": n_seg_launch, "algorithmic_bytes_per_segment": alg_all / max(len(run.segs), 1),
             "resolve": {"lf_steps_per_position": float(tallies[3] / searched), "rank_blocks_per_position": float(tallies[4] / searched),
-                        "table_words_per_position": float(tallies[6] / searched)},
+                        "table_words_per_position": float(tallies[6] / searched),
+                        "sweep": {"words": int(tallies[9]), "turns_per_word": float(tallies[10] / max(tallies[9], 1)), "busy_lane_share": float(tallies[10] / max(tallies[11], 1)),
+                                  "longest_word_turns": int(tallies[12]), "longest_wave_turns": int(tallies[13])}},
             "repeat_probes": {"enabled": bool(run.info.get("repeat_probes", 0)), "settled_fraction": probe["settled"] / max(run.my_positions, 1),
                               "lf_steps_per_position": probe["lf_steps"] / max(run.my_positions, 1),
                               "seed_lookups_per_position": probe["seed_lookups"] / max(run.my_positions, 1)}}

@@ -28,6 +28,7 @@ NM_OPT_SITE_TABLE = 13
 NM_OPT_INITIAL_LENGTH = 14
 NM_OPT_SEGMENT_GUARD = 15
 NM_OPT_LF2 = 16
+NM_OPT_SWEEP = 17
 
 EXPORTS = [
     "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_close",

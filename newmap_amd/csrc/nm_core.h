@@ -1269,6 +1269,269 @@ NM_HD bool nm_second_chance(const nm_view &ix, const nm_window &w, uint32_t kmin
     return (nm_site_bits(w, m, b, e) & usable) != 0;
 }
 
+// ---- both directions: the rows of a string AND of its reverse complement ----------------------------------------------
+// The text holds every run together with its reverse complement (nm_format.h), so a string X and rc(X) occur equally
+// often, and the separators sort before A.  Let [k, k + s) be the rows of X and [l, l + s) those of rc(X).  Prepending c
+// to X is one LF step at both ends of [k, k + s); it APPENDS comp(c) to rc(X), whose rows inside [l, l + s) follow those of
+// rc(X) before a separator (as many as rows of X after one: s minus the four extension sizes) and of rc(X) y for
+// y < comp(c) (as many as rows of x X for x > c).  So one step, in either direction, reads the rank blocks at the two ends
+// of ONE of the intervals and moves both (the FMD-index of Li 2012, restated for this text and block layout).
+struct nm_bi { uint64_t k, l, s; };
+
+// occurrences of the four bases in BWT[superblock start .. i) from one loaded block (three popcounts: T = both planes,
+// C and G = one plane each minus T, A = the rest minus the separators, which are stored as A)
+NM_HD void nm_rank4_blk(const nm_view &ix, uint64_t i, const nm_blk &b, uint32_t r[4]) {
+    const uint32_t off = (uint32_t)(i & 63);
+    const uint64_t below = (1ULL << off) - 1ULL;
+    const uint64_t lo = b.lo & below, hi = b.hi & below;
+    const uint32_t n_lo = nm_popc64(lo), n_hi = nm_popc64(hi), n_t = nm_popc64(lo & hi);
+    uint32_t sep = 0;
+    if ((b.c0 & NM_SEP_FLAG) && off) sep = nm_sep_between(ix, i - off, i);
+    r[0] = (b.c0 & ~NM_SEP_FLAG) + (off - (n_lo + n_hi - n_t)) - sep;
+    r[1] = b.c1 + (n_lo - n_t);
+    r[2] = b.c2 + (n_hi - n_t);
+    r[3] = b.c3 + n_t;
+}
+
+// x = {rows of X, rows of rc(X), size} -> the same for c X, from the rank blocks of x.k (ba) and x.k + x.s (bb) and the four
+// C[c] + counts before the superblock of x.k (cs)
+template <bool BIG>
+NM_HD void nm_bi_extend_blk(const nm_view &ix, nm_bi &x, uint32_t c, const nm_blk &ba, const nm_blk &bb, const uint64_t cs[4]) {
+    uint32_t a[4], b[4];
+    const uint64_t end = x.k + x.s;
+    nm_rank4_blk(ix, x.k, ba, a);
+    nm_rank4_blk(ix, end, bb, b);
+    uint64_t s0 = (uint64_t)b[0] - a[0], s1 = (uint64_t)b[1] - a[1], s2 = (uint64_t)b[2] - a[2], s3 = (uint64_t)b[3] - a[3];
+    if (BIG && (end >> NM_SUPER_SHIFT) != (x.k >> NM_SUPER_SHIFT)) {      // the interval crosses a superblock start: counts relative to two of them
+        const uint64_t *cb = ix.superC + (end >> NM_SUPER_SHIFT) * 4;
+        s0 += cb[0] - cs[0]; s1 += cb[1] - cs[1]; s2 += cb[2] - cs[2]; s3 += cb[3] - cs[3];
+    }
+    const uint64_t after_sep = x.s - (s0 + s1 + s2 + s3);
+    const uint64_t above = c == 0 ? s1 + s2 + s3 : (c == 1 ? s2 + s3 : (c == 2 ? s3 : 0ULL));
+    x.l += after_sep + above;
+    x.k = c == 0 ? cs[0] + a[0] : (c == 1 ? cs[1] + a[1] : (c == 2 ? cs[2] + a[2] : cs[3] + a[3]));
+    x.s = c == 0 ? s0 : (c == 1 ? s1 : (c == 2 ? s2 : s3));
+}
+
+// (the same, loading what it needs: table construction checks, tests)
+template <bool BIG>
+NM_HD void nm_bi_extend(const nm_view &ix, nm_bi &x, uint32_t c, nm_tally &t) {
+    const uint64_t end = x.k + x.s;
+    const bool same = (x.k >> 6) == (end >> 6);
+    const nm_blk ba = nm_load_blk(ix, x.k);
+    const uint64_t *cs = BIG ? ix.superC + (x.k >> NM_SUPER_SHIFT) * 4 : ix.C;
+    const uint64_t c4[4] = {cs[0], cs[1], cs[2], cs[3]};
+    t.steps++;
+    t.blocks += same ? 1u : 2u;
+    nm_bi_extend_blk<BIG>(ix, x, c, ba, same ? ba : nm_load_blk(ix, end), c4);
+}
+
+// ---- the sweep: consecutive open positions share their walks (k_sweep) ------------------------------------------------
+// e(q) = q + (least unique length at q) never decreases with q.  Take the open positions of a stretch from RIGHT to LEFT
+// and keep, for the position q just decided, the rows of a string S[q .. F) that still occurs twice -- with F + 1 = e(q)
+// when the walk found it (EXACT), or F = the end of what a walk may read (kmax bases, an ambiguous byte).  ONE step to the
+// left gives the rows of S[q - 1 .. F).  Two rows or more: S[q - 1 .. F + 1) contains the string that occurs once and
+// S[q - 1 .. F) does not occur once, so e(q - 1) = e(q): the position is decided by that one step (not EXACT: nothing
+// up to F occurs once, element 0 as for q).  One row: the end moved left, and the position walks for itself (seed table,
+// then base by base to the right, both intervals kept) and leaves a new string behind.  Where a stretch of a repeat
+// family member differs from its nearest relative every 5 - 20 bases, a walk is paid once per such run of positions and
+// one step for each of the others -- the reference pays ~7 probes of 20 - 200 bases for every position on its own
+// (newmap/search.py:464-544).  Results are those of nm_min_unique_one / nm_fixed_k_one.
+// One lane sweeps one word of the need bitmap (64 positions).  A chain is a sequence of DEPENDENT reads of lines no other lane
+// wants, so a turn of the state machine is shaped by two things: its latency -- ONE round of reads per turn, whatever the
+// lane is doing (an extension: the rank blocks of the interval's two ends; the seed window; the two seed entries), so that
+// the lanes of a wave stay in step -- and the number of load instructions, each of which costs the L1 one cycle per lane
+// when every lane reads its own line (measured: with eight loads per turn the kernel ran at the L1's pace, 12 us per turn).
+// Hence the bases come from registers (the word's own planes, the walk's window), the superblock constants from `sc`
+// (the caller's copy: LDS on the device), and the second rank block is read only where the interval leaves the first.
+#define NM_SW_IDLE 0u
+#define NM_SW_SEED 1u              /* read the window of the position's first bases */
+#define NM_SW_SEED2 2u             /* read the seed entries of the window and of its reverse complement (slots in iv.k, iv.l) */
+#define NM_SW_WALK 3u
+#define NM_SW_LEFT 4u
+#define NM_SW_VALID 1u             /* flags: iv holds the rows of S[64 word + qo .. 64 word + Fo), two or more */
+#define NM_SW_EXACT 2u             /*        and S[64 word + qo .. 64 word + Fo + 1) occurs once */
+#define NM_SW_EMIT 1u              /* step result: element `out_v` of position `out_p` is decided */
+#define NM_SW_ERR 2u               /*              a k-mer of position `out_p` is absent from the index */
+#define NM_SW_DONE 4u              /*              the word is finished */
+#define NM_SW_NONE 0xFFFFFFFFu     /* no unique length as far as a walk may look */
+
+struct nm_sweep_args {
+    uint32_t kmin, kmax;           // list mode: the first and the longest listed length
+    uint64_t seq_len;
+    const uint32_t *list;          // nullptr: range mode
+    uint32_t n_list;
+    const uint64_t *sc;            // [n_super][4]: C[c] + occurrences of c before the superblock (ix.superC, or a nearer copy)
+};
+
+struct nm_sweep {
+    uint64_t bits;                 // open positions of the word not yet taken
+    uint64_t wlo, whi;             // planes of the word's own 64 bases
+    nm_bi iv;                      // k: rows of the string, l: rows of its reverse complement
+    nm_window w;                   // WALK: bases [p + kbase, p + kbase + 64) of the position being decided
+    uint32_t word;                 // the word of the need bitmap being swept: positions 64 word ..
+    uint32_t qo, Fo;               // the chain's string, offsets from the word's first position
+    uint32_t flags, mode;
+    uint32_t po, k, kbase;         // the position being decided; WALK: iv spells its first k bases
+};
+
+struct nm_q4 { uint64_t x[4]; };   // 32 bytes as loaded
+NM_HD nm_q4 nm_load_q4(const void *p) {
+    const uint64_t *q = (const uint64_t *)p;
+    nm_q4 r;
+    r.x[0] = q[0]; r.x[1] = q[1]; r.x[2] = q[2]; r.x[3] = q[3];
+    return r;
+}
+// The two reads of a turn are issued back to back and waited for ONCE.  The device build spells them out (nm_engine.hip:
+// written as plain loads, the compiler waits for the first block before it issues the second wherever the second is
+// conditional); here, for the host mirror, they are plain loads.
+#ifndef NM_Q4_ISSUE
+typedef nm_q4 nm_q4_raw;
+#define NM_Q4_ZERO(r) ((r).x[0] = (r).x[1] = (r).x[2] = (r).x[3] = 0)
+#define NM_Q4_ISSUE(r, p) ((r) = nm_load_q4(p))
+#define NM_Q4_WAIT2(a, b) ((void)0)
+#define NM_Q4_VALUE(r) (r)
+#endif
+NM_HD nm_blk nm_blk_of(const nm_q4 &q) {
+    nm_blk b;
+    b.c0 = (uint32_t)q.x[0]; b.c1 = (uint32_t)(q.x[0] >> 32); b.c2 = (uint32_t)q.x[1]; b.c3 = (uint32_t)(q.x[1] >> 32);
+    b.lo = q.x[2]; b.hi = q.x[3];
+    return b;
+}
+
+NM_HD void nm_sweep_begin(nm_sweep &st, uint64_t word, uint64_t bits, uint64_t wlo, uint64_t whi) {
+    st.word = (uint32_t)word; st.bits = bits; st.wlo = wlo; st.whi = whi;
+    st.flags = 0; st.mode = NM_SW_IDLE;
+    st.qo = st.Fo = st.po = st.k = st.kbase = 0;
+    st.iv.k = st.iv.l = st.iv.s = 0;
+    st.w.lo = st.w.hi = st.w.amb = 0;
+}
+
+// the element of a position whose least unique length is L (NM_SW_NONE: none within reach)
+NM_HD uint32_t nm_sweep_element(const nm_enc_word *enc, const nm_sweep_args &a, uint64_t p, uint32_t L) {
+    if (!a.list) return L > a.kmax ? 0u : (L > a.kmin ? L : a.kmin);       // (an open position has kmin unambiguous bases)
+    // newmap/search.py:551-644: the first listed length whose (truncated, :590) k-mer occurs once; an ambiguous base inside
+    // a listed k-mer drops the position for good (:593-596)
+    const uint32_t U = nm_upper_one(enc, p, a.kmax);
+    const uint64_t rem = a.seq_len - p;
+    for (uint32_t i = 0; i < a.n_list; i++) {
+        const uint32_t K = a.list[i];
+        const uint32_t Lt = (uint64_t)K < rem ? K : (uint32_t)rem;
+        if (Lt > U) return 0;
+        if (L <= Lt) return K;
+    }
+    return 0;
+}
+
+template <bool BIG>
+NM_HD uint32_t nm_sweep_step(const nm_view &ix, const nm_enc_word *enc, const nm_sweep_args &a, nm_sweep &st, uint64_t &out_p,
+                             uint32_t &out_v, nm_tally &t) {
+    if (st.mode == NM_SW_IDLE) {
+        if (!st.bits) return NM_SW_DONE;
+        const uint32_t o = 63u - (uint32_t)__builtin_clzll(st.bits);
+        st.bits &= ~(1ULL << o);
+        st.po = o;
+        st.mode = ((st.flags & NM_SW_VALID) && st.qo == o + 1) ? NM_SW_LEFT : NM_SW_SEED;
+    }
+    const uint64_t p = (uint64_t)st.word * 64 + st.po;
+    out_p = p;
+    // ---- the turn's reads: addresses from the state alone, nothing used before all of them are on their way
+    const uint32_t mode = st.mode;
+    const bool walk = mode == NM_SW_WALK, ext = walk || mode == NM_SW_LEFT;
+    const uint64_t row = walk ? st.iv.l : st.iv.k;         // the interval an extension reads (to the right: the reverse complement's)
+    const uint64_t end = row + st.iv.s;
+    const bool same = (row >> 6) == (end >> 6);
+    uint32_t j = st.k - st.kbase;                          // WALK: the base the step takes, in the window
+    const bool reload = walk && j >= 64;                   // (a walk longer than its window: the next 64 bases)
+    const bool window = mode == NM_SW_SEED || reload;
+    const uint64_t wat = reload ? p + st.k : p;            // first base of the window to read
+    const void *pa, *pb;
+    if (window) { pa = enc + (wat >> 6); pb = enc + (wat >> 6) + 1; }
+    else if (ext) { pa = ix.rank + (row >> 6); pb = ix.rank + (end >> 6); }
+    else { pa = ix.seed + (st.iv.l & ~3ULL); pb = ix.seed + (st.iv.k & ~3ULL); }      // SEED2: the aligned four entries that hold the slot
+    const bool one = ext && !reload && same;               // (the second rank block only where the interval leaves the first)
+    nm_q4_raw ra, rb;
+    NM_Q4_ZERO(rb);
+    NM_Q4_ISSUE(ra, pa);
+    if (!one) NM_Q4_ISSUE(rb, pb);
+    NM_Q4_WAIT2(ra, rb);                                   // ONE wait per turn, after every read of the turn is on its way
+    const nm_q4 A = NM_Q4_VALUE(ra), B = NM_Q4_VALUE(rb);
+    // ---- and what they mean
+    if (window) {
+        const uint32_t sh = (uint32_t)(wat & 63);
+        st.w.lo = A.x[0]; st.w.hi = A.x[1]; st.w.amb = A.x[2];
+        if (sh) { st.w.lo = (st.w.lo >> sh) | (B.x[0] << (64 - sh)); st.w.hi = (st.w.hi >> sh) | (B.x[1] << (64 - sh)); st.w.amb = (st.w.amb >> sh) | (B.x[2] << (64 - sh)); }
+        if (reload) { st.kbase = st.k; return 0; }
+        const uint32_t sl = ix.seed_len;
+        st.flags = 0;
+        st.kbase = 0;
+        if (ix.seed && sl && a.kmin >= sl && (st.w.amb & ((1ULL << sl) - 1ULL)) == 0) {
+            st.iv.l = nm_seed_slot(st.w, sl);              // an entry holds the rows of the reverse complement of its slot's string
+            st.iv.k = nm_slot_revcomp(st.iv.l, sl);
+            st.mode = NM_SW_SEED2;
+        } else {                                           // no seed table for this search (or, list mode, fewer unambiguous bases): from the first base
+            st.iv.k = 0; st.iv.l = 0; st.iv.s = ix.n; st.k = 0;
+            st.mode = NM_SW_WALK;
+        }
+        return 0;
+    }
+    if (mode == NM_SW_SEED2) {
+        uint64_t rlo, rhi, flo, fhi;
+        t.seeds += 2;
+        const uint32_t ir = (uint32_t)(st.iv.l & 3), jf = (uint32_t)(st.iv.k & 3);     // (selects: an indexed read would put the loads into scratch)
+        const uint64_t er = ir == 0 ? A.x[0] : (ir == 1 ? A.x[1] : (ir == 2 ? A.x[2] : A.x[3]));
+        const uint64_t ef = jf == 0 ? B.x[0] : (jf == 1 ? B.x[1] : (jf == 2 ? B.x[2] : B.x[3]));
+        if (nm_seed_decode(er, rlo, rhi) && nm_seed_decode(ef, flo, fhi) && rhi - rlo >= 2 && fhi - flo == rhi - rlo) {
+            st.iv.k = flo; st.iv.l = rlo; st.iv.s = rhi - rlo;
+            st.k = ix.seed_len;
+        } else {                                           // saturated, or fewer than two rows: walk from the first base
+            st.iv.k = 0; st.iv.l = 0; st.iv.s = ix.n; st.k = 0;
+        }
+        st.mode = NM_SW_WALK;
+        return 0;
+    }
+    // ONE extension: to the right (WALK: appending a base = prepending its complement to the reverse complement) or to the left
+    const uint32_t code = walk ? 3u - nm_window_code(st.w, j)
+                               : ((uint32_t)((st.wlo >> st.po) & 1ULL) | ((uint32_t)((st.whi >> st.po) & 1ULL) << 1));
+    if (walk && (st.k >= a.kmax || ((st.w.amb >> j) & 1ULL))) {      // nothing up to kmax / up to U_p occurs once
+        st.qo = st.po; st.Fo = st.po + st.k;
+        st.flags = NM_SW_VALID;
+        st.mode = NM_SW_IDLE;
+        out_v = nm_sweep_element(enc, a, p, NM_SW_NONE);
+        return NM_SW_EMIT;
+    }
+    nm_bi x;
+    x.k = row; x.l = walk ? st.iv.k : st.iv.l; x.s = st.iv.s;
+    t.steps++;
+    t.blocks += same ? 1u : 2u;
+    const uint64_t *cp = BIG ? a.sc + (row >> NM_SUPER_SHIFT) * 4 : ix.C;
+    const uint64_t cs[4] = {cp[0], cp[1], cp[2], cp[3]};
+    nm_bi_extend_blk<BIG>(ix, x, code, nm_blk_of(A), nm_blk_of(one ? A : B), cs);
+    if (x.s >= 2) {
+        st.iv.k = walk ? x.l : x.k; st.iv.l = walk ? x.k : x.l; st.iv.s = x.s;
+        if (walk) { st.k++; return 0; }
+        st.qo = st.po;                                     // LEFT: decided by the one step
+        st.mode = NM_SW_IDLE;
+        out_v = nm_sweep_element(enc, a, p, (st.flags & NM_SW_EXACT) ? st.Fo + 1 - st.po : NM_SW_NONE);
+        return NM_SW_EMIT;
+    }
+    if (!walk) {                                           // LEFT: the end moved, this position walks for itself
+        st.flags = 0;
+        st.mode = NM_SW_SEED;
+        return 0;
+    }
+    st.mode = NM_SW_IDLE;
+    if (x.s == 0) {                                        // search.py:699-722
+        st.flags = 0;
+        out_v = 0;
+        return NM_SW_EMIT | NM_SW_ERR;
+    }
+    st.qo = st.po; st.Fo = st.po + st.k;                   // S[p .. p + k) still occurs twice, one base more and it occurs once
+    st.flags = NM_SW_VALID | NM_SW_EXACT;
+    out_v = nm_sweep_element(enc, a, p, st.k + 1);
+    return NM_SW_EMIT;
+}
+
 // Which strides get a repeat probe when the probes run AFTER the sites: a stretch that occurs twice over more than a
 // stride leaves (nearly) all its positions unsettled, so a probe is worth its walk only where the stride itself or
 // the stride before it (whose positions read this stride's word, nm_probe_kstar) is mostly unsettled.  A stride

@@ -44,7 +44,22 @@ extern "C" int nm_index_has_record(const nm_index *ix, uint64_t length, uint64_t
 struct nm_view;
 static __device__ __forceinline__ uint64_t nm_seed_load_policy(const nm_view &ix, uint64_t slot);
 #define NM_SEED_LOAD(ix, slot) nm_seed_load_policy((ix), (slot))
+// the two 32-byte reads of a turn of the sweep (nm_core.h: nm_sweep_step): issued back to back, ONE wait
+typedef unsigned int nm_u32x4 __attribute__((ext_vector_type(4)));
+struct nm_q4_raw { nm_u32x4 lo, hi; };
+#define NM_Q4_ZERO(r) ((r).lo = (r).hi = nm_u32x4{0u, 0u, 0u, 0u})
+#define NM_Q4_ISSUE(r, p) asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"((r).lo), "=&v"((r).hi) : "v"(p) : "memory")
+#define NM_Q4_WAIT2(a, b) asm volatile("s_waitcnt vmcnt(0)" : "+v"((a).lo), "+v"((a).hi), "+v"((b).lo), "+v"((b).hi) : : "memory")
+#define NM_Q4_VALUE(r) nm_q4_of_raw(r)
+struct nm_q4;
+static __device__ __forceinline__ nm_q4 nm_q4_of_raw(const nm_q4_raw &r);
 #include "nm_core.h"
+static __device__ __forceinline__ nm_q4 nm_q4_of_raw(const nm_q4_raw &r) {
+    nm_q4 q;
+    q.x[0] = (uint64_t)r.lo.x | ((uint64_t)r.lo.y << 32); q.x[1] = (uint64_t)r.lo.z | ((uint64_t)r.lo.w << 32);
+    q.x[2] = (uint64_t)r.hi.x | ((uint64_t)r.hi.y << 32); q.x[3] = (uint64_t)r.hi.z | ((uint64_t)r.hi.w << 32);
+    return q;
+}
 
 // seed-table gather under a selectable cache policy (NM_OPT_SEED_POLICY; measurement knob)
 static __device__ __forceinline__ uint64_t nm_seed_load_policy(const nm_view &ix, uint64_t slot) {

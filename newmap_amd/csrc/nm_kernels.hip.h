@@ -763,6 +763,180 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
     }
 }
 
+// ---- k_open_words + k_sweep: the positions k_sites left open, neighbours sharing their walks (nm_core.h "the sweep") -------
+// Stands in for k_resolve (NM_OPT_SWEEP, default).  k_open_words lists the words of the need bitmap that hold open positions
+// (work[NM_WORK_LIST] = their number); k_sweep gives every lane one listed word at a time -- a word = one chain from its last
+// open position down to its first -- so that waves are dense whatever the open positions' distribution over the segment
+// (repeats come in clusters: with a block per stretch of the bitmap the longest block set the launch's duration).  Every
+// turn of the loop is ONE extension step for every lane that has work.  What the repeat probes decide is stored when a
+// word is taken, as in k_resolve.
+#define NM_WORK_LIST 6              /* number of entries k_open_words wrote */
+#define NM_WORK_TAKEN 7             /* entries the waves of k_sweep have taken */
+#define NM_SWEEP_CHUNK 128u         /* entries a wave takes at a time */
+#define NM_SWEEP_BLOCK 256
+#define NM_SWEEP_MAX_BLOCKS 2048u   /* 256 CUs x 8 resident blocks: a lane takes every (grid size)-th word of the list */
+#define NM_OPEN_PER_LANE 8u
+__global__ __launch_bounds__(NM_BLOCK) void k_open_words(const uint64_t *__restrict__ need, uint64_t n_need, uint32_t *__restrict__ list,
+                                                         unsigned long long *__restrict__ work) {
+    if (work[NM_WORK_OPEN] == 0) return;
+    __shared__ uint32_t s_idx[NM_BLOCK * NM_OPEN_PER_LANE];
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t first = (uint64_t)blockIdx.x * (NM_BLOCK * NM_OPEN_PER_LANE);
+    // (in word order within the block, wave by wave: neighbouring words go to neighbouring lanes of k_sweep)
+    for (uint32_t r = 0; r < NM_OPEN_PER_LANE; r++) {
+        const uint64_t w = first + (uint64_t)r * NM_BLOCK + threadIdx.x;
+        const bool open = w < n_need && need[w] != 0;
+        const uint64_t mask = __ballot(open);
+        uint32_t at = 0;
+        if ((threadIdx.x & 63) == 0 && mask) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
+        at = __shfl(at, 0, NM_WAVE);
+        if (open) s_idx[at + (uint32_t)__popcll(mask & ((1ULL << (threadIdx.x & 63)) - 1ULL))] = (uint32_t)w;
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    if (!n) return;
+    if (threadIdx.x == 0) s_base = (uint32_t)atomicAdd(&work[NM_WORK_LIST], (unsigned long long)n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += NM_BLOCK) list[s_base + i] = s_idx[i];
+}
+
+template <bool BIG, bool STATS, bool LIST>
+__global__ __launch_bounds__(NM_SWEEP_BLOCK) void k_sweep(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t num_kmers,
+                                                          uint32_t kmin, uint32_t kmax, void *__restrict__ out, int elem_bytes,
+                                                          uint64_t *__restrict__ status, const uint64_t *__restrict__ need,
+                                                          const uint32_t *__restrict__ open_list, const uint32_t *__restrict__ probe,
+                                                          unsigned long long *__restrict__ work,
+                                                          uint64_t seq_len, const uint32_t *__restrict__ list, uint32_t n_list,
+                                                          const uint64_t *__restrict__ hash_part, uint32_t n_hash_part) {
+    // the segment's fingerprint from the partial sums of k_sites' blocks, as in k_resolve
+    const uint32_t hb = gridDim.x < NM_RES_HASH_BLOCKS ? gridDim.x : NM_RES_HASH_BLOCKS;
+    if (hash_part && blockIdx.x < hb) {
+        uint64_t term = 0;
+        for (uint32_t i = blockIdx.x * NM_SWEEP_BLOCK + threadIdx.x; i < n_hash_part; i += hb * NM_SWEEP_BLOCK) term += hash_part[i];
+        for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, NM_WAVE);
+        __shared__ uint64_t s_term[NM_SWEEP_BLOCK / 64];
+        if ((threadIdx.x & 63) == 0) s_term[threadIdx.x >> 6] = term;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t sum = 0;
+            for (uint32_t i = 0; i < NM_SWEEP_BLOCK / 64; i++) sum += s_term[i];
+            if (sum) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)sum);
+        }
+    }
+    if (work[NM_WORK_OPEN] == 0) return;                   // every block of k_sites finished its own positions
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t n_words = (uint32_t)work[NM_WORK_LIST];
+    // a wave's share of the list, staged in LDS when it is taken: the word, its open bits, its two probe words
+    __shared__ uint32_t s_cur[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK], s_pj[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK], s_pj1[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK];
+    __shared__ uint64_t s_bits[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK], s_wlo[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK], s_whi[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK];
+    __shared__ uint64_t s_super[NM_MAX_SUPER * 4];         // C[c] + counts before each superblock: read every turn, by row
+    if (BIG) {
+        if (tid < ix.n_super * 4) s_super[tid] = ix.superC[tid];
+        __syncthreads();
+    }
+    uint32_t w_base = 0, w_next = 0, w_end = 0;            // (the same in every lane of the wave)
+    nm_sweep_args args;
+    args.kmin = kmin; args.kmax = kmax; args.seq_len = seq_len; args.list = LIST ? list : nullptr; args.n_list = n_list;
+    args.sc = s_super;
+    nm_sweep st;
+    nm_sweep_begin(st, 0, 0, 0, 0);
+    nm_tally t = {0, 0, 0, 0};
+    bool any_err = false;
+    uint64_t err_pos = ~0ULL;
+    uint32_t turns_word = 0, turns_lane = 0, turns_wave = 0, turns_max = 0, words_taken = 0;    // counter build: shape of the chains
+    for (;;) {
+        // the lanes that have finished their word take the next words of the wave's share, in list order; a wave whose share
+        // is used up takes the next NM_SWEEP_CHUNK entries of the list (one atomic per chunk: waves that start late, or
+        // whose words were short, simply find less left) and stages them -- all its lanes read, once per chunk, what a
+        // lane taking a word would otherwise wait for in the middle of everybody's chain
+        const bool want = st.mode == NM_SW_IDLE && !st.bits;
+        const uint64_t wmask = __ballot(want);
+        if (wmask) {
+            if (w_next == w_end) {
+                const uint64_t act = __ballot(true);
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(act)) base = (uint32_t)atomicAdd(&work[NM_WORK_TAKEN], (unsigned long long)NM_SWEEP_CHUNK);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                w_base = w_next = base < n_words ? base : n_words;
+                w_end = base + NM_SWEEP_CHUNK < n_words ? base + NM_SWEEP_CHUNK : n_words;
+                const uint32_t n_act = (uint32_t)__popcll(act), mine = (uint32_t)__popcll(act & ((1ULL << lane) - 1ULL));
+                for (uint32_t i = mine; i < w_end - w_base; i += n_act) {
+                    const uint32_t cur = open_list[w_base + i];
+                    s_cur[wv][i] = cur;
+                    s_bits[wv][i] = need[cur];
+                    s_pj[wv][i] = probe ? probe[cur] : 0u;
+                    s_pj1[wv][i] = probe ? probe[cur + 1] : 0u;
+                    s_wlo[wv][i] = enc[cur].lo;
+                    s_whi[wv][i] = enc[cur].hi;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (want) {
+                if (w_next == w_end) break;                // the list is used up
+                const uint32_t slot = w_next + (uint32_t)__popcll(wmask & ((1ULL << lane) - 1ULL));
+                if (slot < w_end) {
+                    const uint32_t i = slot - w_base;
+                    const uint64_t cur = s_cur[wv][i];
+                    uint64_t bits = s_bits[wv][i];
+                    if (probe) {
+                        const uint32_t wj = s_pj[wv][i], wj1 = s_pj1[wv][i];
+                        const uint32_t zeros = wj & 0xFFu;         // positions repeated over more than kmax bases: element 0, as stored
+                        bits &= zeros >= 64 ? 0ULL : ~((1ULL << zeros) - 1ULL);
+                        const uint32_t kj = wj >> 8, kj1 = wj1 >> 8;
+                        if (bits && kj1 && kj == kj1 + NM_PROBE_STRIDE) {      // the same end on both sides: every length is known (nm_probe_kstar)
+                            for (; bits; bits &= bits - 1) {
+                                const uint32_t o = (uint32_t)__builtin_ctzll(bits);
+                                const uint32_t v = nm_sweep_element(enc, args, cur * 64 + o, kj - o);
+                                if (v) nm_store(out, elem_bytes, cur * 64 + o, v);
+                            }
+                        }
+                    }
+                    nm_sweep_begin(st, cur, bits, s_wlo[wv][i], s_whi[wv][i]);
+                    if (STATS) { if (turns_word > turns_max) turns_max = turns_word; turns_word = 0; words_taken++; }
+                }
+            }
+            const uint32_t n_want = (uint32_t)__popcll(wmask);
+            w_next = w_next + n_want < w_end ? w_next + n_want : w_end;
+            if (st.mode == NM_SW_IDLE && !st.bits) continue;   // (nothing left in the share this turn, or a word the probes decide completely)
+        }
+        uint64_t p;
+        uint32_t v;
+        if (STATS) { turns_word++; turns_lane++; turns_wave++; }
+        const uint32_t ret = nm_sweep_step<BIG>(ix, enc, args, st, p, v, t);
+        if (ret & NM_SW_ERR) {
+            bool amb0 = false, err = true;
+            if (LIST) v = nm_fixed_k_one<BIG, true>(ix, enc, p, seq_len, list, n_list, amb0, err, t);   // (which listed k-mer is absent decides: the plain form)
+            if (err) { any_err = true; if (p < err_pos) err_pos = p; }
+        }
+        if (ret & NM_SW_EMIT) nm_store(out, elem_bytes, p, v);
+    }
+    (void)num_kmers;
+    if (__ballot(any_err)) {
+        if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
+        if ((tid & 63) == 0) atomicOr((unsigned long long *)&status[1], 1ULL);
+    }
+    if (STATS) {
+        const uint32_t a = wave_sum(t.steps), b = wave_sum(t.blocks), c = wave_sum(t.seeds);
+        if (turns_word > turns_max) turns_max = turns_word;
+        const uint32_t tl = wave_sum(turns_lane), nw = wave_sum(words_taken);
+        uint32_t tw = turns_wave, tm = turns_max;          // (turns of the wave = of its lane that stayed longest)
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o1 = __shfl_down(tw, off, NM_WAVE), o2 = __shfl_down(tm, off, NM_WAVE); tw = o1 > tw ? o1 : tw; tm = o2 > tm ? o2 : tm; }
+        if ((tid & 63) == 0 && (a | b | c)) {
+            atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[9], (unsigned long long)nw);               // words swept
+            atomicAdd((unsigned long long *)&status[10], (unsigned long long)tl);              // turns, summed over the lanes
+            atomicAdd((unsigned long long *)&status[11], (unsigned long long)tw * 64ull);      // turns of the waves x 64: [10] / [11] = share of busy lanes
+            atomicMax((unsigned long long *)&status[12], (unsigned long long)tm);              // the longest chain of a word, in turns
+            atomicMax((unsigned long long *)&status[13], (unsigned long long)tw);              // the longest wave, in turns
+        }
+    }
+}
+
 // quad table from the seed table of the same length (nm_core.h: nm_quad_build_one)
 template <bool BIG>
 __global__ __launch_bounds__(NM_BLOCK) void k_quad_build(nm_view ix, uint64_t *__restrict__ quad, uint64_t first_slot,

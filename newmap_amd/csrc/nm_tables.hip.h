@@ -550,6 +550,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (const char *cs = getenv("NEWMAP_AMD_COARSE_STRIDE")) { const int v = atoi(cs); if (v == 128 || v == 256 || v == 512) ix->coarse_stride = (uint32_t)v; }
     if (const char *pb = getenv("NEWMAP_AMD_PROBES_BESIDE")) ix->probes_beside = pb[0] != '0';
     if (const char *pr = getenv("NEWMAP_AMD_PERIODIC")) ix->periodic_runs = pr[0] != '0';
+    if (const char *sw = getenv("NEWMAP_AMD_SWEEP")) ix->sweep = sw[0] != '0';
     if (const char *sb = getenv("NEWMAP_AMD_SITES_BLOCKS_PER_CU")) ix->sites_blocks_per_cu = atoi(sb);
     if (const char *sd = getenv("NEWMAP_AMD_SITE_D")) { ix->site_d_cap = (uint32_t)atoi(sd); if (ix->site_d_cap > NM_SITE_MAX_D) ix->site_d_cap = NM_SITE_MAX_D; }
     if (hipHostMalloc((void **)&ix->h_repeats_seen, 64, hipHostMallocMapped) == hipSuccess) {
@@ -580,7 +581,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (nm_lane &L : ix->lanes) {
-        for (void *p : {L.enc.p, L.ks.p, L.work.p, L.settled.p, L.coarse.p, L.need.p, L.hashp.p})
+        for (void *p : {L.enc.p, L.ks.p, L.work.p, L.settled.p, L.coarse.p, L.need.p, L.hashp.p, L.open_list.p})
             if (p) (void)hipFree(p);
         if (L.side) (void)hipStreamDestroy(L.side);
         for (hipEvent_t e : {L.ev_fork, L.ev_join, L.ev_last})
@@ -665,6 +666,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_LF2) { ix->view.lf2 = value ? (const nm_lf_entry *)ix->d_lf2 : nullptr; return NM_OK; }
+    if (option == NM_OPT_SWEEP) { ix->sweep = value != 0; return NM_OK; }
     if (option == NM_OPT_SEGMENT_GUARD) { ix->segment_guard = value != 0; return NM_OK; }
     if (option == NM_OPT_INITIAL_LENGTH) {
         if (value < 0 || value > 0xFFFFFFFFLL) { nm_set_error("initial search length out of range"); return NM_E_ARGUMENT; }

@@ -140,6 +140,11 @@ class Index:
         """A/B: walks take two bases per step (two-base LF blocks, where built) or one"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LF2, int(bool(on))))
 
+    def set_sweep(self, on: bool):
+        """A/B: the positions the sites leave open are swept right to left, neighbours sharing their walks (k_sweep,
+        default) or each walks for itself (k_resolve)"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SWEEP, int(bool(on))))
+
     def set_dictionary(self, on: bool):
         """A/B: open positions of the sites ask the repeat dictionary (default, when one was built and kmin allows) or the
         second quad table / the seed table"""

@@ -31,6 +31,9 @@ def lib():
     L.hs_enable_lf2.argtypes = [vp, i32]
     L.hs_check_lf2.restype = ctypes.c_uint64
     L.hs_check_lf2.argtypes = [vp]
+    L.hs_check_bi.restype = u64
+    L.hs_check_bi.argtypes = [vp, vp, u64, u64, u64]
+    L.hs_set_sweep.argtypes = [i32]
     L.hs_check_lfb.restype = u64
     L.hs_check_lfb.argtypes = [vp]
     L.hs_check_levels.restype = u64
@@ -104,6 +107,16 @@ class HostSim:
 
     def check_lf2(self):
         return int(self.L.hs_check_lf2(self.h))
+
+    def check_bi(self, seq: bytes = b"", rounds=2000, seed=12345):
+        """nm_bi_extend (rows of a string and of its reverse complement, extended to either side) against plain backward
+        searches, on strings that follow `seq` and on random ones; returns the number of disagreements"""
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        return int(self.L.hs_check_bi(self.h, buf.ctypes.data if buf.size else None, buf.size, rounds, seed))
+
+    def set_sweep(self, on=True):
+        """sites() finishes the open positions with the sweep (k_sweep) instead of one walk per position (k_resolve)"""
+        self.L.hs_set_sweep(int(on))
 
     def check_lfb(self):
         return int(self.L.hs_check_lfb(self.h))

@@ -129,6 +129,61 @@ uint64_t hs_check_lf2(hs_index *ix) {
         }
     return bad;
 }
+// both-direction steps (nm_bi_extend) against two independent backward searches: strings grown base by base to the left and
+// to the right, following the text `seq` around a random position (so that they occur) or at random; returns the number of
+// disagreements
+uint64_t hs_check_bi(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t rounds, uint64_t rng) {
+    const nm_view &v = ix->v;
+    uint64_t bad = 0;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    auto search = [&](const std::vector<uint32_t> &x, uint64_t &lo, uint64_t &hi) {      // rows of x by a plain backward search
+        lo = 0; hi = v.n;
+        for (size_t i = x.size(); i-- > 0 && lo < hi;) {
+            if (ix->big) nm_lf_interval<true>(v, x[i], lo, hi); else nm_lf_interval<false>(v, x[i], lo, hi);
+        }
+        if (hi < lo) hi = lo;
+    };
+    for (uint64_t r = 0; r < rounds; r++) {
+        std::vector<uint32_t> x;
+        const bool follow = seq_len > 0 && (r & 3) != 0;
+        uint64_t a = follow ? next() % seq_len : 0, b = a;          // the string is seq[a .. b) when it follows the text
+        nm_bi iv = {0, 0, v.n};
+        nm_tally t = {0, 0, 0, 0};
+        for (uint32_t step = 0; step < 48 && iv.s; step++) {
+            bool left = next() & 1;
+            uint32_t c = (uint32_t)(next() & 3);
+            if (follow) {
+                if (left && a == 0) left = false;
+                if (!left && b >= seq_len) left = true;
+                if (left && a == 0) break;
+                const uint32_t code = nm_base_code(seq[left ? a - 1 : b]);
+                if (code > 3) break;
+                c = code;
+                if (left) a--; else b++;
+            }
+            if (left) {
+                if (ix->big) nm_bi_extend<true>(v, iv, c, t); else nm_bi_extend<false>(v, iv, c, t);
+                x.insert(x.begin(), c);
+            } else {
+                nm_bi y = {iv.l, iv.k, iv.s};
+                if (ix->big) nm_bi_extend<true>(v, y, 3u - c, t); else nm_bi_extend<false>(v, y, 3u - c, t);
+                iv.k = y.l; iv.l = y.k; iv.s = y.s;
+                x.push_back(c);
+            }
+            std::vector<uint32_t> rc(x.size());
+            for (size_t i = 0; i < x.size(); i++) rc[i] = 3u - x[x.size() - 1 - i];
+            uint64_t lo, hi, rlo, rhi;
+            search(x, lo, hi);
+            search(rc, rlo, rhi);
+            if (hi - lo != iv.s || rhi - rlo != iv.s) { bad++; break; }
+            if (iv.s && (lo != iv.k || rlo != iv.l)) { bad++; break; }
+            if (follow && iv.s == 0) { bad++; break; }            // a string of the text occurs
+        }
+    }
+    return bad;
+}
+static int g_sweep = 0;
+void hs_set_sweep(int on) { g_sweep = on; }
 // LF blocks against the packed rank blocks at every row
 uint64_t hs_check_lfb(hs_index *ix) {
     nm_view packed = ix->v;
@@ -644,8 +699,52 @@ int hs_sites(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_t num_km
             words[j] = ix->big ? nm_repeat_probe<true>(v, enc.data(), P, kmax, stride, t) : nm_repeat_probe<false>(v, enc.data(), P, kmax, stride, t);
         }
     }
-    // ---- k_resolve
+    // ---- k_sweep (NM_OPT_SWEEP): one lane per word, right to left, ONE extension per step (nm_core.h "the sweep")
     if (!any_open) probes = 0;
+    if (g_sweep) {
+        nm_sweep_args args;
+        args.kmin = kmin; args.kmax = kmax; args.seq_len = seq_len; args.list = list; args.n_list = n_list; args.sc = v.superC;
+        for (uint64_t cur = 0; any_open && cur < n_need; cur++) {
+            uint64_t bits = need[cur];
+            if (!bits) continue;
+            if (probes) {
+                const uint32_t wj = words[cur], wj1 = words[cur + 1];
+                const uint32_t zeros = wj & 0xFFu;
+                const uint64_t before = bits;
+                bits &= zeros >= 64 ? 0ULL : ~((1ULL << zeros) - 1ULL);
+                counters[3] += nm_popc64(before ^ bits);
+                const uint32_t kj = wj >> 8, kj1 = wj1 >> 8;
+                if (bits && kj1 && kj == kj1 + 64) {
+                    for (; bits; bits &= bits - 1) {
+                        const uint32_t o = (uint32_t)__builtin_ctzll(bits);
+                        const uint32_t val = nm_sweep_element(enc.data(), args, cur * 64 + o, kj - o);
+                        if (val) store(cur * 64 + o, val);
+                        counters[3]++;
+                    }
+                }
+            }
+            nm_sweep st;
+            nm_sweep_begin(st, cur, bits, enc[cur].lo, enc[cur].hi);
+            nm_tally t = {0, 0, 0, 0};
+            for (uint64_t guard = 0;; guard++) {
+                if (guard > 64ull * ((uint64_t)kmax + 80)) return -3;     // (the state machine must end)
+                uint64_t p = 0;
+                uint32_t val = 0;
+                const uint32_t ret = ix->big ? nm_sweep_step<true>(v, enc.data(), args, st, p, val, t) : nm_sweep_step<false>(v, enc.data(), args, st, p, val, t);
+                if (ret & NM_SW_DONE) break;
+                if (ret & NM_SW_ERR) {
+                    bool amb0 = false, err = true;
+                    if (list) val = ix->big ? nm_fixed_k_one<true, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t)
+                                            : nm_fixed_k_one<false, true>(v, enc.data(), p, seq_len, list, n_list, amb0, err, t);
+                    if (err) { status[1] = 1; if (p < status[2]) status[2] = p; }
+                }
+                if (ret & NM_SW_EMIT) { store(p, val); counters[1]++; }
+            }
+            status[3] += t.steps; status[4] += t.blocks; status[6] += t.seeds;
+        }
+        any_open = false;
+    }
+    // ---- k_resolve
     for (uint64_t cur = 0; any_open && cur < n_need; cur++) {
         uint64_t bits = need[cur];
         uint32_t wj = 0, wj1 = 0;

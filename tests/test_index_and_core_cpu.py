@@ -748,3 +748,88 @@ def test_word_wide_base_classification_equals_the_bytewise_one():
     value in every position of the word, with varying neighbours"""
     from tests.hostsim import check_codes4
     assert check_codes4(300) == 0
+
+
+def _family_genome(rng):
+    """two records with members of one 300-base repeat family at 3 - 15 % divergence between unique spacers, a soft-masked
+    exact copy, a tandem array, N runs: open positions come in stretches whose least unique lengths end at common points"""
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+
+    def rnd(n):
+        return bytes(alpha[rng.integers(0, 4, n)])
+
+    def mutate(b, rate):
+        a = bytearray(b)
+        for i in range(len(a)):
+            if rng.random() < rate:
+                a[i] = alpha[rng.integers(0, 4)]
+        return bytes(a)
+
+    fam = rnd(300)
+    parts = []
+    for _ in range(30):
+        parts.append(rnd(int(rng.integers(50, 400))))
+        parts.append(mutate(fam, rng.choice([0.03, 0.08, 0.15])))
+    r1 = bytearray(b"".join(parts))
+    r1[1000:1005] = b"NNNNN"
+    r1[5000:5200] = bytes(r1[2000:2200]).lower()
+    r1[7000:7600] = (rnd(7) * 100)[:600]
+    r2 = rnd(1500) + mutate(fam, 0.1) + b"NN" + rnd(100)
+    return bytes(r1), r2
+
+
+@pytest.mark.parametrize("m,force_big", [(5, False), (4, True)])
+def test_sweep_equals_oracle_and_shares_walks(tmp_path, m, force_big):
+    """k_sweep (nm_core.h "the sweep"): the open positions of a word are taken right to left; one step to the left decides a
+    position while the string kept from its right neighbour still occurs twice, a walk (both intervals kept, nm_bi_extend) is
+    paid only where the end moves.  Same elements as the oracle's closed form / the reference's linear search and as k_resolve,
+    with fewer rank-block reads; nm_bi_extend itself against plain backward searches."""
+    rng = np.random.default_rng(70 + m)
+    r1, r2 = _family_genome(rng)
+    fa = _write(tmp_path, b">a\n" + r1 + b"\n>b\n" + r2 + b"\n")
+    idx = tmp_path / "f.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12)
+    sim = HostSim(idx, m, force_big)
+    assert sim.check_quad() == 0
+    assert sim.check_bi(r1, 2000) == 0 and sim.check_bi(b"", 300) == 0
+    oracle = rd.OracleIndex([r1, r2])
+    w = m + 4
+    lines = [0, 0]
+    try:
+        for rec in (r1, r2):
+            for kmin, kmax in ((w, 40), (w + 2, 30), (20, 200), (24, 150), (70, 255), (12, 14)):
+                dtype, _ = rd.output_dtype(kmax)
+                want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
+                for probes in (0, 1, 2):
+                    for chance_max, walk_max in ((256, 64), (0, 0)):
+                        for sweep in (False, True):
+                            sim.set_sweep(sweep)
+                            got, status, code, _, _ = sim.sites(rec, len(rec), kmin, kmax, 59, probes, dtype=dtype, chance_max=chance_max, walk_max=walk_max)
+                            assert code == 0 and np.array_equal(got, want), (kmin, kmax, probes, sweep, np.flatnonzero(got != want)[:10])
+                            lines[sweep] += int(status[4])
+            # a prefix: the last word is cut, the lookahead is left behind
+            sim.set_sweep(True)
+            for cut in (1, 65, 517, len(rec) - 20):
+                got, _, code, _, _ = sim.sites(rec, cut, 20, 200, 59, 1, chance_max=0, walk_max=0)
+                assert code == 0 and np.array_equal(got, rd.closed_form_min_unique(rec, oracle, 20, 200, True)[:cut])
+            # list mode
+            for ks in ([w, w + 5], [20, 36, 100], [36, 20, 50], [100, 24]):
+                kmax = max(ks)
+                dtype, _ = rd.output_dtype(kmax)
+                seg = rd.Segment(b"r", rec, True)
+                want, _ = rd.linear_search_segment(oracle, seg, ks, kmax, dtype, True)
+                head = len(rec) - kmax + 1
+                for probes in (0, 1):
+                    for chance_max, walk_max in ((256, 64), (0, 0)):
+                        got, _, code, _, _ = sim.sites(rec, head, ks[0], kmax, 59, probes, ks=ks, dtype=dtype, chance_max=chance_max, walk_max=walk_max)
+                        assert code == 0 and np.array_equal(got, want[:head]), (ks, probes)
+        assert lines[1] * 2 < lines[0]                     # (on a 3 Gbp genome walks are 20 - 40 bases longer and the gap is wider)
+        # a FASTA that is not the indexed genome: an absent k-mer is reported, as by the walks
+        foreign = bytearray(r1[:3000])
+        foreign[1500:1520] = b"ACGTTGCAACGTTGCAACGT"
+        for sweep in (False, True):
+            sim.set_sweep(sweep)
+            _, status, code, _, _ = sim.sites(bytes(foreign), len(foreign), 20, 200, 59, 1, chance_max=0, walk_max=0)
+            assert code == 8 and int(status[1]) == 1
+    finally:
+        sim.set_sweep(False)

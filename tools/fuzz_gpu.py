@@ -1,4 +1,4 @@
-"""Randomised A/B soak on the GPU: the default range path (sites on the quad table + gated repeat probes + resolve,
+"""Randomised A/B soak on the GPU: the default range path (sites on the quad table + gated repeat probes + sweep / resolve,
 list modes routed through it; random cap of the group size; the > 2^31-row instantiations on every other index)
 against the plain one-lane-per-position kernels without probes (and, half of the time, the same segments again through the
 device-pointer entry dealt over 2..7 streams = the handle's lanes, incl. lanes changing hands), on genomes with tandem arrays, dispersed and
@@ -30,7 +30,7 @@ def genome(rng):
         n = int(rng.integers(2_000, 400_000))
         s = bytearray(bytes(ALPHA[rng.integers(0, 4, n)]))
         for _ in range(int(rng.integers(0, 12))):
-            kind = int(rng.integers(0, 5))
+            kind = int(rng.integers(0, 7))
             a = int(rng.integers(0, n))
             m = int(min(n - a, rng.integers(1, 30_000)))
             if m <= 0:
@@ -47,8 +47,15 @@ def genome(rng):
             elif kind == 3:                                 # ambiguous run
                 m = int(min(m, rng.integers(1, 300)))
                 s[a:a + m] = bytes(rng.choice(np.frombuffer(b"NnRYKMSWBDHV", np.uint8), m))
-            else:                                           # soft-masked stretch
+            elif kind == 4:                                 # soft-masked stretch
                 s[a:a + m] = bytes(s[a:a + m]).lower()
+            else:                                           # diverged copy (a repeat family member), either strand: the ends of
+                b = int(rng.integers(0, n - m + 1))         # neighbouring positions' least unique strings coincide in runs
+                src = bytes(s[b:b + m]) if kind == 5 else bytes(s[b:b + m]).translate(COMP)[::-1]
+                cp = np.frombuffer(src, np.uint8).copy()
+                hit = np.flatnonzero(rng.random(m) < float(rng.choice([0.02, 0.05, 0.1, 0.2])))
+                cp[hit] = ALPHA[rng.integers(0, 4, hit.size)]
+                s[a:a + m] = cp.tobytes()
         recs.append((f"r{r}".encode(), bytes(s)))
     if len(recs) > 1 and rng.random() < 0.5:                # a copy across records
         src = recs[0][1]
@@ -88,6 +95,7 @@ def main():
                     fast.set_site_table(int(rng.choice([0, 0, 1, 2])))
                     fast.set_dictionary(bool(rng.random() < 0.7))
                     fast.set_lf2(bool(rng.random() < 0.8))
+                    fast.set_sweep(bool(rng.random() < 0.8))
                     kmin = int(rng.choice([w, w + 1, 20, 24, 36, 60, 61, 62, 64, 100, 124, 125, 190, 252, 253, int(rng.integers(1, 200))]))
                     kmax = int(kmin + rng.choice([0, 1, 5, 40, 130, 231, int(rng.integers(0, 3000))]))
                     batch = int(rng.choice([1 << 30, 10_007, 65_536, int(rng.integers(500, 200_000))]))

@@ -376,6 +376,8 @@ class Run:
             tallies[12:14] = np.maximum(tallies[12:14], row[12:14])       # (k_sweep: longest chain / longest wave, in turns)
             for k_, v_ in self.ix.probe_tally().items():
                 probe[k_] += v_
+            ow = self.ix.open_words()
+            self.open_words = [a_ + b_ for a_, b_ in zip(getattr(self, "open_words", [0] * 8), ow["words"] + ow["positions"])]
         self.ix.set_count_steps(False)
         return tallies, probe
 
@@ -491,7 +493,8 @@ def pipeline_block(run: Run, kinds, tallies, probe):
             "resolve": {"lf_steps_per_position": float(tallies[3] / searched), "rank_blocks_per_position": float(tallies[4] / searched),
                         "table_words_per_position": float(tallies[6] / searched),
                         "sweep": {"words": int(tallies[9]), "turns_per_word": float(tallies[10] / max(tallies[9], 1)), "busy_lane_share": float(tallies[10] / max(tallies[11], 1)),
-                                  "longest_word_turns": int(tallies[12]), "longest_wave_turns": int(tallies[13])}},
+                                  "longest_word_turns": int(tallies[12]), "longest_wave_turns": int(tallies[13]),
+                                  "open_words_by_class": getattr(run, "open_words", [0] * 8)[:4], "open_positions_by_class": getattr(run, "open_words", [0] * 8)[4:]}},
             "repeat_probes": {"enabled": bool(run.info.get("repeat_probes", 0)), "settled_fraction": probe["settled"] / max(run.my_positions, 1),
                               "lf_steps_per_position": probe["lf_steps"] / max(run.my_positions, 1),
                               "seed_lookups_per_position": probe["seed_lookups"] / max(run.my_positions, 1)}}

@@ -167,8 +167,9 @@ enum {
                                       default 1, 0 = always the list kernel, for A/B */
     NM_OPT_SITE_TABLE = 13,        /* measurement / tests: which quad table the sites read: 0 pick per launch (default), 1 the one
                                       with long cores, 2 the one with short cores (the other backs it up in k_resolve) */
-    NM_OPT_SWEEP = 17,             /* A/B: the positions the sites leave open are swept right to left, neighbours sharing their walks
-                                      (k_sweep, default 1) or walk one by one (k_resolve) */
+    NM_OPT_SWEEP = 17,             /* the positions the sites leave open: 1 (default) = launches list the words that hold them and k_sweep takes
+                                      the launch where they are dense (neighbours share their walks), once the handle has met open positions;
+                                      2 = from the first launch on (tests); 0 = every position walks for itself (k_resolve), for A/B */
     NM_OPT_LF2 = 16,               /* A/B: walks take two bases per step on the two-base LF blocks (default 1 where they were built) */
     NM_OPT_SEGMENT_GUARD = 15,     /* default 1: nm_min_unique_segment / nm_fixed_k_segment (host buffers: the seam of binary_search /
                                       linear_search) run the exact zero-count guard unless the segment is a whole indexed record;

@@ -26,7 +26,7 @@ struct nm_lane {
     hipStream_t side = nullptr;           // repeat probes of repeat-rich input run here, beside k_sites (launch_sites)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_last = nullptr;         // end of the lane's last call on its owner's stream
-    nm_buffer enc, ks, work, settled, coarse, need, hashp, open_list;   // grown on demand
+    nm_buffer enc, ks, work, settled, coarse, need, need2, hashp, open_list;   // grown on demand
     uint64_t enc_words = 0;               // words written by the last nm_encode
 };
 
@@ -74,7 +74,7 @@ struct nm_index {
     bool periodic_runs = true;            // NEWMAP_AMD_PERIODIC=0: the coarse probes walk every stride (A/B) instead of one walk per tandem run
     int site_table = 0;                   // measurement knob (NM_OPT_SITE_TABLE): 0 = pick per launch, 1 = long cores, 2 = short cores
     uint32_t site_d_cap = NM_SITE_MAX_D;  // measurement knob (NEWMAP_AMD_SITE_D): cap on d = kmin - window of the sites
-    bool sweep = true;                    // NM_OPT_SWEEP: the open positions go through k_sweep (default) or k_resolve (A/B)
+    int sweep = 1;                        // NM_OPT_SWEEP: 1 = open positions are offered to k_sweep once the handle has met any (default), 2 = always, 0 = k_resolve only (A/B)
     bool count_steps = false;
     int last_kernel = 0;                  // which range kernel the last launch used (nm_index_info 8)
     uint64_t guard_segments = 0;          // segments that went through the exact guard (nm_index_info 23; tests)

@@ -72,7 +72,7 @@ static __device__ __forceinline__ void nm_quad_finish_paired(const nm_quad_infli
 
 // ------------------------------------------------------------------------------ kernels ----
 
-#define NM_WORK_WORDS 8             /* handle-owned counters: [1..4] probe tally, [5] NM_WORK_OPEN */
+#define NM_WORK_WORDS 16            /* handle-owned counters: [1..4] probe tally, [5] NM_WORK_OPEN, [6..] the sweep's lists */
 #define NM_WORK_OPEN 5              /* some block of k_sites left positions open: k_repeat_probe / k_resolve have work (tally = work + 1) */
 
 // the status words of a launch (and the handle's counters) start from zero; folded into the encode
@@ -649,6 +649,21 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
     }
 }
 
+// ---- which kernel finishes the open positions of a launch: decided on the device, per word and per launch -------------------
+// k_open_words sorts the words of the need bitmap by their number of open positions.  Dense words (repeat family members:
+// stretches of open positions whose least unique strings end at common points) go to the sweep, which shares the walks
+// (k_sweep); in sparse words (fewer than 8 open positions: the scattered repeated windows of ordinary sequence, what the repeat
+// probes leave at the ends of tandem arrays) every position walks for itself, two bases per step (k_resolve on the bitmap of
+// those words).  A launch whose open positions lie mostly in sparse words is k_resolve's altogether: the few dense words it
+// has are long chains (the last kmax positions of a tandem array: one walk of up to kmax steps, then a step per position) that
+// would keep the launch waiting for their latency.  Both kernels are launched; what has nothing to do returns at once.
+#define NM_WORK_TAKEN 6             /* entries the waves of k_sweep have taken */
+#define NM_WORK_LIST 8              /* [8 + c]: number of words of class c that k_open_words listed, [12 + c]: their open positions */
+#define NM_SWEEP_CLASSES 4u         /* words by number of open positions: >= 48, >= 24, >= 8, fewer -- the long chains start first */
+__device__ __forceinline__ bool nm_sweep_mode(const unsigned long long *work) {
+    return work[NM_WORK_LIST + 4] + work[NM_WORK_LIST + 5] + work[NM_WORK_LIST + 6] >= work[NM_WORK_LIST + 7];  // most open positions lie in dense words
+}
+
 // ---- k_resolve: the positions k_sites left open -----------------------------------------------------
 // A block owns NM_RES_WORDS words of the need bitmap (64 positions each; one word per lane).  Scan: a lane goes
 // through the set bits of its words; what the repeat probes decide (nm_probe_kstar) is stored at once, everything else
@@ -668,7 +683,14 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
                                                           uint64_t n_need, const uint32_t *__restrict__ probe,
                                                           const unsigned long long *__restrict__ work,
                                                           uint64_t seq_len, const uint32_t *__restrict__ list, uint32_t n_list,
-                                                          const uint64_t *__restrict__ hash_part, uint32_t n_hash_part) {
+                                                          const uint64_t *__restrict__ hash_part, uint32_t n_hash_part, int after_sweep,
+                                                          volatile uint32_t *open_seen, uint32_t *__restrict__ seen_latch, const uint64_t *__restrict__ need_sparse) {
+    // (after_sweep: k_sweep ran before this kernel, added the fingerprint up, and took the launch if its words are dense)
+    if (after_sweep) {
+        hash_part = nullptr;
+        if (work[NM_WORK_OPEN] == 0) return;
+        if (nm_sweep_mode(work)) need = need_sparse;       // the dense words were k_sweep's
+    }
     // the segment's fingerprint: the partial sums of k_sites' blocks (nm_hash.h), added up by the first blocks of this grid -- a
     // slice each, so that no lane reads more than a few values one after the other (one block reading them all was a chain of
     // ~100 dependent loads: 20 - 50 us per launch), and at most NM_RES_HASH_BLOCKS atomics meet on the status word
@@ -687,6 +709,10 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
         }
     }
     if (work[NM_WORK_OPEN] == 0) return;                   // every block of k_sites finished its own positions
+    // tell the host (pinned word [1], once per handle, as the fine probes do for long repeats) that this input leaves positions
+    // open: from then on a launch also lists the open words and offers them to k_sweep.  Input that never does -- a genome
+    // without repeats: every block of k_sites finishes its own few -- is spared the two launches.
+    if (open_seen && blockIdx.x == 0 && threadIdx.x == 0 && seen_latch[1] == 0u) { seen_latch[1] = 1u; open_seen[1] = 1u; }
     __shared__ uint32_t q_p[NM_RES_QCAP];
     __shared__ uint32_t q_n;
     const uint32_t tid = threadIdx.x;
@@ -770,43 +796,72 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
 // (repeats come in clusters: with a block per stretch of the bitmap the longest block set the launch's duration).  Every
 // turn of the loop is ONE extension step for every lane that has work.  What the repeat probes decide is stored when a
 // word is taken, as in k_resolve.
-#define NM_WORK_LIST 6              /* number of entries k_open_words wrote */
-#define NM_WORK_TAKEN 7             /* entries the waves of k_sweep have taken */
 #define NM_SWEEP_CHUNK 128u         /* entries a wave takes at a time */
 #define NM_SWEEP_BLOCK 256
-#define NM_SWEEP_MAX_BLOCKS 2048u   /* 256 CUs x 8 resident blocks: a lane takes every (grid size)-th word of the list */
+#define NM_SWEEP_MAX_BLOCKS 2048u   /* 256 CUs x 8 blocks: the waves take words until the lists are used up */
 #define NM_OPEN_PER_LANE 8u
-__global__ __launch_bounds__(NM_BLOCK) void k_open_words(const uint64_t *__restrict__ need, uint64_t n_need, uint32_t *__restrict__ list,
-                                                         unsigned long long *__restrict__ work) {
+#ifndef NM_SWEEP_WAVES
+#define NM_SWEEP_WAVES 0            /* measurement builds: waves per SIMD the register allocation of k_sweep aims at (0 = as compiled) */
+#endif
+#if NM_SWEEP_WAVES
+#define NM_SWEEP_ATTR __attribute__((amdgpu_waves_per_eu(NM_SWEEP_WAVES)))
+#else
+#define NM_SWEEP_ATTR
+#endif
+__device__ __forceinline__ uint32_t nm_sweep_class(uint64_t bits) {
+    const uint32_t n = nm_popc64(bits);
+    return n >= 48 ? 0u : (n >= 24 ? 1u : (n >= 8 ? 2u : 3u));
+}
+// list[c * n_need + i] = i-th word of class c (in word order within a block: neighbouring words go to neighbouring lanes).
+// The class is that of the positions the repeat probes leave: what lies inside a stretch repeated over more than kmax bases is
+// 0 already, and between two probes that saw the same end every length is known (nm_probe_kstar) -- such a word is listed
+// (its elements are stored when it is taken) but counts as sparse.
+__global__ __launch_bounds__(NM_BLOCK) void k_open_words(const uint64_t *__restrict__ need, uint64_t n_need, const uint32_t *__restrict__ probe,
+                                                         uint32_t *__restrict__ list, unsigned long long *__restrict__ work, uint64_t *__restrict__ need_sparse) {
     if (work[NM_WORK_OPEN] == 0) return;
-    __shared__ uint32_t s_idx[NM_BLOCK * NM_OPEN_PER_LANE];
-    __shared__ uint32_t s_n, s_base;
-    if (threadIdx.x == 0) s_n = 0;
+    __shared__ uint32_t s_idx[NM_SWEEP_CLASSES][NM_BLOCK * NM_OPEN_PER_LANE];
+    __shared__ uint32_t s_n[NM_SWEEP_CLASSES], s_base[NM_SWEEP_CLASSES], s_pos[NM_SWEEP_CLASSES];
+    if (threadIdx.x < NM_SWEEP_CLASSES) { s_n[threadIdx.x] = 0; s_pos[threadIdx.x] = 0; }
     __syncthreads();
     const uint64_t first = (uint64_t)blockIdx.x * (NM_BLOCK * NM_OPEN_PER_LANE);
-    // (in word order within the block, wave by wave: neighbouring words go to neighbouring lanes of k_sweep)
     for (uint32_t r = 0; r < NM_OPEN_PER_LANE; r++) {
         const uint64_t w = first + (uint64_t)r * NM_BLOCK + threadIdx.x;
-        const bool open = w < n_need && need[w] != 0;
-        const uint64_t mask = __ballot(open);
-        uint32_t at = 0;
-        if ((threadIdx.x & 63) == 0 && mask) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
-        at = __shfl(at, 0, NM_WAVE);
-        if (open) s_idx[at + (uint32_t)__popcll(mask & ((1ULL << (threadIdx.x & 63)) - 1ULL))] = (uint32_t)w;
+        uint64_t bits = w < n_need ? need[w] : 0ULL;
+        uint32_t cls = 3u;
+        if (bits && probe) {
+            const uint32_t wj = probe[w], wj1 = probe[w + 1], zeros = wj & 0xFFu;
+            bits &= zeros >= 64 ? 0ULL : ~((1ULL << zeros) - 1ULL);
+            if (!((wj1 >> 8) && (wj >> 8) == (wj1 >> 8) + NM_PROBE_STRIDE)) cls = nm_sweep_class(bits);
+        } else if (bits) cls = nm_sweep_class(bits);
+        if (w < n_need) need_sparse[w] = bits && cls == 3u ? need[w] : 0ULL;   // (as k_sites left it: k_resolve applies the probe words itself)
+#pragma unroll
+        for (uint32_t c = 0; c < NM_SWEEP_CLASSES; c++) {
+            const bool mine = bits != 0 && cls == c;
+            const uint64_t mask = __ballot(mine);
+            if (!mask) continue;                           // (uniform)
+            uint32_t at = 0;
+            if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(mask)) at = atomicAdd(&s_n[c], (uint32_t)__popcll(mask));
+            at = __shfl(at, __builtin_ctzll(mask), NM_WAVE);
+            if (mine) s_idx[c][at + (uint32_t)__popcll(mask & ((1ULL << (threadIdx.x & 63)) - 1ULL))] = (uint32_t)w;
+            const uint32_t n_pos = wave_sum(mine ? nm_popc64(bits) : 0u);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&s_pos[c], n_pos);
+        }
     }
     __syncthreads();
-    const uint32_t n = s_n;
-    if (!n) return;
-    if (threadIdx.x == 0) s_base = (uint32_t)atomicAdd(&work[NM_WORK_LIST], (unsigned long long)n);
+    if (threadIdx.x < NM_SWEEP_CLASSES && s_n[threadIdx.x]) {
+        s_base[threadIdx.x] = (uint32_t)atomicAdd(&work[NM_WORK_LIST + threadIdx.x], (unsigned long long)s_n[threadIdx.x]);
+        atomicAdd(&work[NM_WORK_LIST + NM_SWEEP_CLASSES + threadIdx.x], (unsigned long long)s_pos[threadIdx.x]);
+    }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += NM_BLOCK) list[s_base + i] = s_idx[i];
+    for (uint32_t c = 0; c < NM_SWEEP_CLASSES; c++)
+        for (uint32_t i = threadIdx.x; i < s_n[c]; i += NM_BLOCK) list[(uint64_t)c * n_need + s_base[c] + i] = s_idx[c][i];
 }
 
 template <bool BIG, bool STATS, bool LIST>
-__global__ __launch_bounds__(NM_SWEEP_BLOCK) void k_sweep(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t num_kmers,
+__global__ __launch_bounds__(NM_SWEEP_BLOCK) NM_SWEEP_ATTR void k_sweep(nm_view ix, const nm_enc_word *__restrict__ enc, uint64_t num_kmers,
                                                           uint32_t kmin, uint32_t kmax, void *__restrict__ out, int elem_bytes,
                                                           uint64_t *__restrict__ status, const uint64_t *__restrict__ need,
-                                                          const uint32_t *__restrict__ open_list, const uint32_t *__restrict__ probe,
+                                                          uint64_t n_need, const uint32_t *__restrict__ open_list, const uint32_t *__restrict__ probe,
                                                           unsigned long long *__restrict__ work,
                                                           uint64_t seq_len, const uint32_t *__restrict__ list, uint32_t n_list,
                                                           const uint64_t *__restrict__ hash_part, uint32_t n_hash_part) {
@@ -825,9 +880,11 @@ __global__ __launch_bounds__(NM_SWEEP_BLOCK) void k_sweep(nm_view ix, const nm_e
             if (sum) atomicAdd((unsigned long long *)&status[NM_STATUS_HASH], (unsigned long long)sum);
         }
     }
-    if (work[NM_WORK_OPEN] == 0) return;                   // every block of k_sites finished its own positions
+    if (work[NM_WORK_OPEN] == 0 || !nm_sweep_mode(work)) return;   // every block of k_sites finished its own positions / sparse: k_resolve's
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t n_words = (uint32_t)work[NM_WORK_LIST];
+    // the lists of the four classes, one after the other: entry e of the whole is entry e - first[c] of class c
+    const uint32_t n0 = (uint32_t)work[NM_WORK_LIST], n1 = n0 + (uint32_t)work[NM_WORK_LIST + 1], n2 = n1 + (uint32_t)work[NM_WORK_LIST + 2];
+    const uint32_t n_words = n2;                           // (the sparse words, class 3, are k_resolve's)
     // a wave's share of the list, staged in LDS when it is taken: the word, its open bits, its two probe words
     __shared__ uint32_t s_cur[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK], s_pj[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK], s_pj1[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK];
     __shared__ uint64_t s_bits[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK], s_wlo[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK], s_whi[NM_SWEEP_BLOCK / 64][NM_SWEEP_CHUNK];
@@ -863,7 +920,8 @@ __global__ __launch_bounds__(NM_SWEEP_BLOCK) void k_sweep(nm_view ix, const nm_e
                 w_end = base + NM_SWEEP_CHUNK < n_words ? base + NM_SWEEP_CHUNK : n_words;
                 const uint32_t n_act = (uint32_t)__popcll(act), mine = (uint32_t)__popcll(act & ((1ULL << lane) - 1ULL));
                 for (uint32_t i = mine; i < w_end - w_base; i += n_act) {
-                    const uint32_t cur = open_list[w_base + i];
+                    const uint32_t e = w_base + i;
+                    const uint32_t cur = e < n0 ? open_list[e] : (e < n1 ? open_list[n_need + (e - n0)] : open_list[2 * n_need + (e - n1)]);
                     s_cur[wv][i] = cur;
                     s_bits[wv][i] = need[cur];
                     s_pj[wv][i] = probe ? probe[cur] : 0u;

@@ -199,25 +199,27 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
     if (beside) HIP_TRY(hipStreamWaitEvent(st, ix->cur->ev_join, 0));
     else if (ix->repeat_probes && (rc = nm_launch_probes<BIG>(ix, view, n, kmax, st, &probe, need)) != NM_OK) return rc;
     // what is still open: the sweep (neighbouring positions share their walks, nm_core.h) or, for A/B, one walk per position
-    const bool sweep = ix->sweep;
+    // (default: once the handle has met open positions -- k_resolve's latch; NM_OPT_SWEEP = 2: from the first launch on)
+    const bool sweep = ix->sweep == 2 || (ix->sweep == 1 && ix->h_repeats_seen && ((volatile uint32_t *)ix->h_repeats_seen)[1] != 0);
     uint32_t *open_list = nullptr;
     if (sweep) {
-        if ((rc = nm_grow(ix->cur->open_list, (n_need + 1) * sizeof(uint32_t))) != NM_OK) return rc;
+        if ((rc = nm_grow(ix->cur->open_list, (NM_SWEEP_CLASSES * n_need + 1) * sizeof(uint32_t))) != NM_OK) return rc;
         open_list = (uint32_t *)ix->cur->open_list.p;
+        if ((rc = nm_grow(ix->cur->need2, (n_need + 1) * sizeof(uint64_t))) != NM_OK) return rc;
     }
     const uint64_t sweep_blocks = (n_need + NM_SWEEP_BLOCK - 1) / NM_SWEEP_BLOCK;
-    const dim3 rgrid(sweep ? (unsigned)(sweep_blocks < NM_SWEEP_MAX_BLOCKS ? sweep_blocks : NM_SWEEP_MAX_BLOCKS) : (unsigned)((n_need + NM_RES_WORDS - 1) / NM_RES_WORDS)),
-               rblock(sweep ? NM_SWEEP_BLOCK : NM_RES_BLOCK);
+    const dim3 wgrid((unsigned)(sweep_blocks < NM_SWEEP_MAX_BLOCKS ? sweep_blocks : NM_SWEEP_MAX_BLOCKS)), wblock(NM_SWEEP_BLOCK);
+    const dim3 rgrid((unsigned)((n_need + NM_RES_WORDS - 1) / NM_RES_WORDS)), rblock(NM_RES_BLOCK);
 #define NM_RES_TAIL seq_len, d_list, n_list, (const uint64_t *)hash_part, (uint32_t)sgrid.x
 #define NM_LAUNCH_RES(STATS_, LIST_) do { \
-        if (sweep) hipLaunchKernelGGL((k_sweep<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, d_status, (const uint64_t *)need, \
-                                      (const uint32_t *)open_list, probe, work, NM_RES_TAIL); \
-        else hipLaunchKernelGGL((k_resolve<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, d_status, (const uint64_t *)need, n_need, \
-                                probe, (const unsigned long long *)work, NM_RES_TAIL); } while (0)
+        if (sweep) hipLaunchKernelGGL((k_sweep<BIG, STATS_, LIST_>), wgrid, wblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, d_status, (const uint64_t *)need, \
+                                      n_need, (const uint32_t *)open_list, probe, work, NM_RES_TAIL); \
+        hipLaunchKernelGGL((k_resolve<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, d_status, (const uint64_t *)need, n_need, \
+                           probe, (const unsigned long long *)work, NM_RES_TAIL, sweep ? 1 : 0, ix->d_repeats_seen, ix->d_seen_latch, (const uint64_t *)ix->cur->need2.p); } while (0)
     {
         nm_timed timed(ix, st, 4);
         if (sweep) hipLaunchKernelGGL(k_open_words, dim3((unsigned)((n_need + NM_BLOCK * NM_OPEN_PER_LANE - 1) / (NM_BLOCK * NM_OPEN_PER_LANE))), dim3(NM_BLOCK), 0, st,
-                                      (const uint64_t *)need, n_need, open_list, work);
+                                      (const uint64_t *)need, n_need, probe, open_list, work, (uint64_t *)ix->cur->need2.p);
         if (d_list) { if (ix->count_steps) NM_LAUNCH_RES(true, true); else NM_LAUNCH_RES(false, true); }
         else        { if (ix->count_steps) NM_LAUNCH_RES(true, false); else NM_LAUNCH_RES(false, false); }
     }

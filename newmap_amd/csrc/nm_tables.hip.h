@@ -550,11 +550,11 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (const char *cs = getenv("NEWMAP_AMD_COARSE_STRIDE")) { const int v = atoi(cs); if (v == 128 || v == 256 || v == 512) ix->coarse_stride = (uint32_t)v; }
     if (const char *pb = getenv("NEWMAP_AMD_PROBES_BESIDE")) ix->probes_beside = pb[0] != '0';
     if (const char *pr = getenv("NEWMAP_AMD_PERIODIC")) ix->periodic_runs = pr[0] != '0';
-    if (const char *sw = getenv("NEWMAP_AMD_SWEEP")) ix->sweep = sw[0] != '0';
+    if (const char *sw = getenv("NEWMAP_AMD_SWEEP")) { const int v = atoi(sw); if (v >= 0 && v <= 2) ix->sweep = v; }
     if (const char *sb = getenv("NEWMAP_AMD_SITES_BLOCKS_PER_CU")) ix->sites_blocks_per_cu = atoi(sb);
     if (const char *sd = getenv("NEWMAP_AMD_SITE_D")) { ix->site_d_cap = (uint32_t)atoi(sd); if (ix->site_d_cap > NM_SITE_MAX_D) ix->site_d_cap = NM_SITE_MAX_D; }
     if (hipHostMalloc((void **)&ix->h_repeats_seen, 64, hipHostMallocMapped) == hipSuccess) {
-        *ix->h_repeats_seen = 0;
+        ix->h_repeats_seen[0] = ix->h_repeats_seen[1] = 0;     // [0]: long repeats met (fine probes), [1]: open positions met (k_resolve)
         if (hipHostGetDevicePointer((void **)&ix->d_repeats_seen, ix->h_repeats_seen, 0) != hipSuccess ||
             hipMalloc((void **)&ix->d_seen_latch, 64) != hipSuccess || hipMemset(ix->d_seen_latch, 0, 64) != hipSuccess) {
             (void)hipGetLastError();
@@ -581,7 +581,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (nm_lane &L : ix->lanes) {
-        for (void *p : {L.enc.p, L.ks.p, L.work.p, L.settled.p, L.coarse.p, L.need.p, L.hashp.p, L.open_list.p})
+        for (void *p : {L.enc.p, L.ks.p, L.work.p, L.settled.p, L.coarse.p, L.need.p, L.need2.p, L.hashp.p, L.open_list.p})
             if (p) (void)hipFree(p);
         if (L.side) (void)hipStreamDestroy(L.side);
         for (hipEvent_t e : {L.ev_fork, L.ev_join, L.ev_last})
@@ -620,6 +620,12 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 26: return ix->view.lf2 ? 1 : 0;
         case 24: return ix->view.dict_len;
         case 25: return ix->dict_entries;
+        case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: {      // k_open_words of the last launch: words / open positions by class
+            unsigned long long v = 0;
+            if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
+            if (hipMemcpy(&v, (const unsigned long long *)ix->cur->work.p + NM_WORK_LIST + (what - 27), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+            return v;
+        }
         case 14: case 15: case 16: case 17: {              // probe tally of the last range-mode launch
             unsigned long long v = 0;
             if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
@@ -666,7 +672,11 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_LF2) { ix->view.lf2 = value ? (const nm_lf_entry *)ix->d_lf2 : nullptr; return NM_OK; }
-    if (option == NM_OPT_SWEEP) { ix->sweep = value != 0; return NM_OK; }
+    if (option == NM_OPT_SWEEP) {
+        if (value < 0 || value > 2) { nm_set_error("sweep must be 0 (k_resolve only), 1 (once the handle has met open positions) or 2 (always)"); return NM_E_ARGUMENT; }
+        ix->sweep = (int)value;
+        return NM_OK;
+    }
     if (option == NM_OPT_SEGMENT_GUARD) { ix->segment_guard = value != 0; return NM_OK; }
     if (option == NM_OPT_INITIAL_LENGTH) {
         if (value < 0 || value > 0xFFFFFFFFLL) { nm_set_error("initial search length out of range"); return NM_E_ARGUMENT; }

@@ -108,6 +108,12 @@ class Index:
         names = ["lf_steps", "rank_blocks", "seed_lookups", "settled"]
         return {n: int(self._L.nm_index_info(self.handle, 14 + i)) for i, n in enumerate(names)}
 
+    def open_words(self) -> dict:
+        """k_open_words of the last launch: words of the need bitmap that hold open positions, and those positions, by class
+        (>= 48, >= 24, >= 8, fewer open positions per word)"""
+        v = [int(self._L.nm_index_info(self.handle, 27 + i)) for i in range(8)]
+        return {"words": v[:4], "positions": v[4:]}
+
     def set_count_steps(self, on: bool):
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_COUNT_STEPS, int(bool(on))))
 
@@ -141,9 +147,10 @@ class Index:
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LF2, int(bool(on))))
 
     def set_sweep(self, on: bool):
-        """A/B: the positions the sites leave open are swept right to left, neighbours sharing their walks (k_sweep,
-        default) or each walks for itself (k_resolve)"""
-        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SWEEP, int(bool(on))))
+        """A/B: the positions the sites leave open are swept right to left where they are dense, neighbours sharing their walks
+        (k_sweep; True = from the first launch on, 1 = the default: once the handle has met open positions) or each walks
+        for itself (k_resolve; False)"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SWEEP, 2 if on is True else int(on)))
 
     def set_dictionary(self, on: bool):
         """A/B: open positions of the sites ask the repeat dictionary (default, when one was built and kmin allows) or the

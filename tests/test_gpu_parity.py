@@ -799,6 +799,7 @@ def test_repeat_probes_change_the_work_not_the_result(tmp_path, mixed_genome, en
     with eng.Index(idx, 0) as ix:
         assert ix.info()["repeat_probes"] == 1
         ix.set_count_steps(True)
+        ix.set_sweep(True)                                  # (from the first launch on; the default waits until the handle has met open positions)
         for kernel in (0, 1):
             ix.set_kernel(kernel)
             ix.set_repeat_probes(True)

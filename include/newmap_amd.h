@@ -157,8 +157,13 @@ enum {
     NM_OPT_KERNEL = 4,             /* range-mode kernel: 0 automatic (default), 1 one lane per position (k_min_unique),
                                       5 the sites (k_sites + k_resolve: one 128-byte quad-table line per group of
                                       kmin - core length + 1 positions; needs core length + 4 <= kmin <= 252) */
-    NM_OPT_FORCE_BIG = 6,          /* tests: use the kernels for indexes beyond 2^31 positions */
-    NM_OPT_SEED_POLICY = 7,        /* measurement: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1) */
+    NM_OPT_FORCE_BIG = 6,          /* test hook: the instantiations for indexes beyond 2^31 rows (what a 3 Gbp genome runs) on a small
+                                      index; same results */
+    NM_OPT_SEED_POLICY = 7,        /* A/B switches, same results: seed-table load 0 default, 1 non-temporal, 2 agent-scope (sc1);
+                                      + 0x800 the blocks of k_sites never walk themselves, + 0x1000 no repeat dictionary, + 0x2000 the
+                                      dictionary in the second chance's place.  (The two switches that cut work out of the kernels
+                                      and give wrong results, 0x100 / 0x200, exist in the measurement build only -- `make measure`,
+                                      libnewmap_amd_measure.so, loaded by tools/ -- this library rejects them.) */
     NM_OPT_LF_BLOCKS = 9,          /* LF steps on the 16-byte LF entries (default when built) or the packed rank blocks */
     NM_OPT_REPEAT_PROBES = 10,     /* both-strand range mode: one probe per 64 positions settles stretches that occur
                                       twice over more than kmax bases (default 1; 0 = every position searches for itself) */
@@ -181,11 +186,11 @@ enum {
 };
 int nm_set_option(nm_index *ix, int option, int64_t value);
 
-/* NM_OPT_TIMING = 1 records HIP events on the launch stream, five kinds of start/stop pairs per segment:
+/* NM_OPT_TIMING = 1 records HIP events on the launch stream, six kinds of start/stop pairs per segment:
  * kind 0 around the search kernel alone (k_sites / k_min_unique / k_fixed_k), kind 1 around ALL kernels of the
- * segment (encode pass, sites, repeat probes, resolve), kinds 2 / 3 / 4 around the coarse repeat probes, the fine
- * repeat probes and k_resolve, each on the stream the kernel is launched on (bench.py quotes the roofline figure
- * for the kind with the largest total).
+ * segment (encode pass, sites, repeat probes, finishing stage), kinds 2 / 3 / 4 around the coarse repeat probes, the fine
+ * repeat probes and the finishing stage (k_open_words + k_sweep + k_resolve), kind 5 around k_sweep alone, each on the
+ * stream the kernel is launched on (bench.py quotes the roofline figure for the kernel with the largest total).
  * nm_timing_read_kind waits for the events of one kind, returns their number, summed and longest duration in
  * ms, and resets that record; nm_timing_read = kind 0. */
 int nm_timing_read(nm_index *ix, uint64_t *n_launches, double *total_ms, double *max_ms);

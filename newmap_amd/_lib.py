@@ -8,7 +8,7 @@ import sys
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libnewmap_amd.so"
+LIB_PATH = Path(os.environ["NEWMAP_AMD_LIB"]) if os.environ.get("NEWMAP_AMD_LIB") else _HERE / "libnewmap_amd.so"    # (NEWMAP_AMD_LIB: tools/ load the measurement build)
 
 NM_OK = 0
 NM_E_FILE_OPEN, NM_E_ALLOC, NM_E_FILE_EXISTS, NM_E_FILE_WRITE, NM_E_FILE_FORMAT = 1, 2, 3, 4, 5

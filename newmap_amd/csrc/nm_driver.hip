@@ -491,7 +491,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
     for (uint32_t i = 1; i < nk; i++) { if (ks[i] < d.kmin) d.kmin = ks[i]; if (ks[i] > d.kmax) d.kmax = ks[i]; }
     d.elem_bytes = d.kmax <= 0xFF ? 1 : (d.kmax <= 0xFFFF ? 2 : 4);      // newmap/search.py:204-212
     const char *suffix = d.elem_bytes == 1 ? "uint8" : (d.elem_bytes == 2 ? "uint16" : "uint32");
-    d.batch = batch;
+    d.batch = batch >= 64 ? batch & ~63ull : batch;          // (segments start at multiples of 64 bases of their record: their fingerprints join, nm_hash.h)
     d.lookahead = d.kmax - 1;                                            // newmap/search.py:229
     auto unmap = [&]() { if (base) munmap((void *)base, size); };
 
@@ -580,6 +580,9 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
         const char *fz = getenv("NEWMAP_AMD_DRIVER_FUSE");
         const uint64_t launch = 32ull << 20;
         if (!(fz && fz[0] == '0') && d.batch < launch) d.batch *= launch / d.batch;
+        // (units after a record's first start at a multiple of the working batch: kept a multiple of 64 bases, so that their
+        // fingerprints join -- nm_hash.h -- whatever --kmer-batch-size is; the output does not depend on where segments are cut)
+        if (d.batch >= 64) d.batch &= ~63ull;
     }
     struct Unit { int rec; uint64_t start, count, seg_len; };
     std::vector<Unit> units;
@@ -839,7 +842,7 @@ static int guard_pass(nm_index *ix, const char *fasta_path, const uint32_t *ks, 
     d.kmin = d.kmax = ks[0];
     for (uint32_t i = 1; i < nk; i++) { if (ks[i] < d.kmin) d.kmin = ks[i]; if (ks[i] > d.kmax) d.kmax = ks[i]; }
     d.elem_bytes = 1;
-    d.batch = batch;
+    d.batch = batch >= 64 ? batch & ~63ull : batch;          // (segments start at multiples of 64 bases of their record: their fingerprints join, nm_hash.h)
     d.lookahead = d.kmax - 1;
     d.include = include;
     d.exclude = exclude;
@@ -918,7 +921,7 @@ static int search_fasta_impl(nm_index *ix, const char *fasta_path, const char *o
     d.kmax = kmax;
     d.elem_bytes = d.kmax <= 0xFF ? 1 : (d.kmax <= 0xFFFF ? 2 : 4);      // newmap/search.py:204-212
     d.suffix = d.elem_bytes == 1 ? "uint8" : (d.elem_bytes == 2 ? "uint16" : "uint32");
-    d.batch = batch;
+    d.batch = batch >= 64 ? batch & ~63ull : batch;          // (segments start at multiples of 64 bases of their record: their fingerprints join, nm_hash.h)
     d.lookahead = d.kmax - 1;                                            // newmap/search.py:229
     d.out_dir = out_dir;
     d.include = include;

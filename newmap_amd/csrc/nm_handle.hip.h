@@ -18,7 +18,7 @@ struct nm_buffer {
 };
 
 #define NM_LANES 6
-#define NM_TIMING_KINDS 5
+#define NM_TIMING_KINDS 6
 struct nm_lane {
     hipStream_t owner = nullptr;          // the stream whose launches use this scratch
     bool ready = false;                   // side stream and events exist
@@ -84,10 +84,11 @@ struct nm_index {
     // NM_OPT_TIMING: HIP events on the launch stream, NM_TIMING_KINDS kinds of start/stop pairs:
     // kind 0 around the dominant search kernel of a segment (k_sites / k_min_unique / k_fixed_k), kind 1 around ALL the
     // kernels of the segment (encode pass, sites, probes, resolve), kinds 2 / 3 / 4 around the coarse probes, the fine
-    // probes and k_resolve (each on the stream it is launched on: the probes may run on the lane's side stream)
+    // probes and the finishing stage (k_open_words + k_sweep + k_resolve), kind 5 around k_sweep alone (each on the stream it is
+    // launched on: the probes may run on the lane's side stream)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool[NM_TIMING_KINDS];   // start/stop pairs, reused
-    size_t ev_used[NM_TIMING_KINDS] = {0, 0, 0, 0, 0};  // events consumed since the last read
+    size_t ev_used[NM_TIMING_KINDS] = {0, 0, 0, 0, 0, 0};  // events consumed since the last read
 };
 
 struct nm_timed {                         // records start on construction, stop on destruction

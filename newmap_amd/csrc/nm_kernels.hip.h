@@ -13,6 +13,14 @@
 #ifndef NM_QUAD_NT
 #define NM_QUAD_NT 1
 #endif
+// Measurement builds (make measure: -DNM_MEASURE, libnewmap_amd_measure.so, loaded by tools/ only) keep two switches of
+// NM_OPT_SEED_POLICY that cut work out of the kernels -- and give WRONG results: 0x100 no walks in k_resolve, 0x200 no table
+// load in k_sites.  The product library has no such code and rejects the bits.
+#ifdef NM_MEASURE
+#define NM_CUT(policy, bit) (((policy) & (bit)) != 0)
+#else
+#define NM_CUT(policy, bit) false
+#endif
 typedef unsigned long long nm_u64x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ uint32_t nm_swap1(uint32_t v) {      // the value of lane ^ 1
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
     for (int s = 0; s < NM_SITE_PER_LANE; s++) {
         const uint32_t g = (uint32_t)s * NM_SITE_BLOCK + tid;          // group g: positions base + g G .. + G - 1, site at + d
         win[s] = lds_window(g * G + d);
-        go[s] = base + (uint64_t)g * G < num_kmers && nm_site_core_valid(win[s], m) && !(ix.seed_policy & 0x200u);
+        go[s] = base + (uint64_t)g * G < num_kmers && nm_site_core_valid(win[s], m) && !NM_CUT(ix.seed_policy, 0x200u);
         nm_quad_index(win[s], m, bidx[s]);
         // one 128-byte line; its two 16-byte halves are read by this lane and its neighbour (nm_quad_issue_paired)
         fly[s] = nm_quad_issue_paired(ix.quad + nm_quad_slot(win[s], m) * NM_QUAD_WORDS, go[s], bidx[s]);
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
         __syncthreads();
         // ---- phase 4D: the positions whose x-mer is repeated walk on from its interval (a few: here; many: a long repeat, k_resolve)
         const uint32_t n_w = s_wn;
-        if (n_w <= NM_SITE_WALK_MAX && kmax <= NM_SITE_LA_MAX && !(ix.seed_policy & 0x900u)) {
+        if (n_w <= NM_SITE_WALK_MAX && kmax <= NM_SITE_LA_MAX && !(ix.seed_policy & 0x800u) && !NM_CUT(ix.seed_policy, 0x100u)) {
             if (tid < n_w) {
                 const uint32_t relw = s_wpos[tid];
                 uint64_t lo, hi;
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
     // (the walks read the block's staged words -- positions relative to its first base -- so the lookahead of the
     // longest walk must have been staged: kmax <= NM_SITE_LA_MAX)
     // (seed_policy bit 0x800, measurement knob: the blocks never walk themselves, every open position goes to k_resolve)
-    const bool self = !dict_done && open_total && open_total <= NM_SITE_WALK_MAX && kmax <= NM_SITE_LA_MAX && !(ix.seed_policy & 0x900u);
+    const bool self = !dict_done && open_total && open_total <= NM_SITE_WALK_MAX && kmax <= NM_SITE_LA_MAX && !(ix.seed_policy & 0x800u) && !NM_CUT(ix.seed_policy, 0x100u);
     if (self) {
         gather_open();
         if (tid < s_qn) {
@@ -762,7 +770,7 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
         }
         __syncthreads();
         // ---- walk
-        const uint32_t n_walk = (ix.seed_policy & 0x100u) ? 0u : (q_n < NM_RES_QCAP ? q_n : NM_RES_QCAP);   // (0x100: timing experiment, wrong results)
+        const uint32_t n_walk = NM_CUT(ix.seed_policy, 0x100u) ? 0u : (q_n < NM_RES_QCAP ? q_n : NM_RES_QCAP);   // (measurement builds: no walks)
         for (uint32_t i = tid; i < n_walk; i += NM_RES_BLOCK) {
             const uint64_t p = wbase * 64 + q_p[i];
             bool amb0 = false, err = false;
@@ -986,6 +994,8 @@ __global__ __launch_bounds__(NM_SWEEP_BLOCK) NM_SWEEP_ATTR void k_sweep(nm_view 
             atomicAdd((unsigned long long *)&status[3], (unsigned long long)a);
             atomicAdd((unsigned long long *)&status[4], (unsigned long long)b);
             atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[14], (unsigned long long)b);               // rank blocks (32 B) read HERE ([4]: by k_resolve too, 16-byte LF entries)
+            atomicAdd((unsigned long long *)&status[15], (unsigned long long)c);               // seed entries read HERE ([6]: by k_resolve too)
             atomicAdd((unsigned long long *)&status[9], (unsigned long long)nw);               // words swept
             atomicAdd((unsigned long long *)&status[10], (unsigned long long)tl);              // turns, summed over the lanes
             atomicAdd((unsigned long long *)&status[11], (unsigned long long)tw * 64ull);      // turns of the waves x 64: [10] / [11] = share of busy lanes

@@ -212,8 +212,9 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
     const dim3 rgrid((unsigned)((n_need + NM_RES_WORDS - 1) / NM_RES_WORDS)), rblock(NM_RES_BLOCK);
 #define NM_RES_TAIL seq_len, d_list, n_list, (const uint64_t *)hash_part, (uint32_t)sgrid.x
 #define NM_LAUNCH_RES(STATS_, LIST_) do { \
-        if (sweep) hipLaunchKernelGGL((k_sweep<BIG, STATS_, LIST_>), wgrid, wblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, d_status, (const uint64_t *)need, \
-                                      n_need, (const uint32_t *)open_list, probe, work, NM_RES_TAIL); \
+        if (sweep) { nm_timed sweep_alone(ix, st, 5); \
+                     hipLaunchKernelGGL((k_sweep<BIG, STATS_, LIST_>), wgrid, wblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, d_status, (const uint64_t *)need, \
+                                        n_need, (const uint32_t *)open_list, probe, work, NM_RES_TAIL); } \
         hipLaunchKernelGGL((k_resolve<BIG, STATS_, LIST_>), rgrid, rblock, 0, st, view, enc, n, kmin, kmax, d_out, elem_bytes, d_status, (const uint64_t *)need, n_need, \
                            probe, (const unsigned long long *)work, NM_RES_TAIL, sweep ? 1 : 0, ix->d_repeats_seen, ix->d_seen_latch, (const uint64_t *)ix->cur->need2.p); } while (0)
     {

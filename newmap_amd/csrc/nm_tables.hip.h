@@ -228,11 +228,15 @@ static int nm_build_dict(nm_index *ix) {
         cleanup();
         return NM_OK;
     }
+    void *table = nullptr;
+    // (an error return frees the scratch and the table too: HIP_TRY alone would leave them behind)
+#define DICT_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { nm_set_error("HIP error %d (%s) at %s:%d: %s", (int)e__, hipGetErrorString(e__), __FILE__, __LINE__, #expr); \
+                                                                           cleanup(); if (table) (void)hipFree(table); return NM_E_DEVICE; } } while (0)
     nm_view v = ix->view;
     uint64_t n_nodes = 0;
     int cur = 0;
     for (uint32_t L = s; L < x; L++) {
-        HIP_TRY(hipMemsetAsync(counter, 0, 8, ix->stream));
+        DICT_TRY(hipMemsetAsync(counter, 0, 8, ix->stream));
         const uint64_t n_in = L == s ? (1ULL << (2 * s)) : n_nodes;
         const uint64_t slice = 1ULL << 30;
         for (uint64_t first = 0; first < n_in; first += slice) {
@@ -241,11 +245,11 @@ static int nm_build_dict(nm_index *ix) {
             const uint64_t *seed = L == s ? v.seed : nullptr;
             if (ix->big) hipLaunchKernelGGL(k_dict_expand<true>, grid, block, 0, ix->stream, v, seed, first, (const nm_dict_node *)lists[cur ^ 1], n_in, L, lists[cur], counter, cap);
             else         hipLaunchKernelGGL(k_dict_expand<false>, grid, block, 0, ix->stream, v, seed, first, (const nm_dict_node *)lists[cur ^ 1], n_in, L, lists[cur], counter, cap);
-            HIP_TRY(hipGetLastError());
+            DICT_TRY(hipGetLastError());
         }
         unsigned long long got = 0;
-        HIP_TRY(hipMemcpyAsync(&got, counter, 8, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipStreamSynchronize(ix->stream));
+        DICT_TRY(hipMemcpyAsync(&got, counter, 8, hipMemcpyDeviceToHost, ix->stream));
+        DICT_TRY(hipStreamSynchronize(ix->stream));
         if (got > cap) {                                            // more repeated strings than the lists hold: no dictionary
             if (nm_verbose()) fprintf(stderr, "[open] repeat dictionary: %llu nodes at length %u do not fit: none built\n", got, L + 1);
             cleanup();
@@ -257,16 +261,16 @@ static int nm_build_dict(nm_index *ix) {
     const nm_dict_node *nodes = lists[cur ^ 1];
     uint32_t bits = 4;
     while ((1ULL << bits) * 4 < n_nodes) bits++;                    // <= 4 of 8 slots per bucket on average
-    void *table = nullptr;
     if (hipMalloc(&table, (128ULL << bits)) != hipSuccess) { (void)hipGetLastError(); cleanup(); return NM_OK; }
-    HIP_TRY(hipMemsetAsync(table, 0xFF, (128ULL << bits), ix->stream));
-    HIP_TRY(hipMemsetAsync(fail, 0, 4, ix->stream));
+    DICT_TRY(hipMemsetAsync(table, 0xFF, (128ULL << bits), ix->stream));
+    DICT_TRY(hipMemsetAsync(fail, 0, 4, ix->stream));
     if (n_nodes) hipLaunchKernelGGL(k_dict_insert, dim3(nm_grid(n_nodes)), dim3(NM_BLOCK), 0, ix->stream, nodes, n_nodes, (uint64_t *)table, bits, fail);
     unsigned int failed = 0;
-    HIP_TRY(hipMemcpyAsync(&failed, fail, 4, hipMemcpyDeviceToHost, ix->stream));
-    HIP_TRY(hipStreamSynchronize(ix->stream));
+    DICT_TRY(hipMemcpyAsync(&failed, fail, 4, hipMemcpyDeviceToHost, ix->stream));
+    DICT_TRY(hipStreamSynchronize(ix->stream));
     cleanup();
     if (failed) { (void)hipFree(table); return NM_OK; }
+#undef DICT_TRY
     ix->d_dict = table;
     ix->dict_entries = n_nodes;
     ix->device_bytes += 128ULL << bits;
@@ -551,7 +555,9 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if (const char *pb = getenv("NEWMAP_AMD_PROBES_BESIDE")) ix->probes_beside = pb[0] != '0';
     if (const char *pr = getenv("NEWMAP_AMD_PERIODIC")) ix->periodic_runs = pr[0] != '0';
     if (const char *sw = getenv("NEWMAP_AMD_SWEEP")) { const int v = atoi(sw); if (v >= 0 && v <= 2) ix->sweep = v; }
-    if (const char *sb = getenv("NEWMAP_AMD_SITES_BLOCKS_PER_CU")) ix->sites_blocks_per_cu = atoi(sb);
+#ifdef NM_MEASURE
+    if (const char *sb = getenv("NEWMAP_AMD_SITES_BLOCKS_PER_CU")) ix->sites_blocks_per_cu = atoi(sb);      // occupancy cap of k_sites (LDS padding)
+#endif
     if (const char *sd = getenv("NEWMAP_AMD_SITE_D")) { ix->site_d_cap = (uint32_t)atoi(sd); if (ix->site_d_cap > NM_SITE_MAX_D) ix->site_d_cap = NM_SITE_MAX_D; }
     if (hipHostMalloc((void **)&ix->h_repeats_seen, 64, hipHostMallocMapped) == hipSuccess) {
         ix->h_repeats_seen[0] = ix->h_repeats_seen[1] = 0;     // [0]: long repeats met (fine probes), [1]: open positions met (k_resolve)
@@ -645,7 +651,10 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_SEED_POLICY) {
-        if (value < 0 || (value & 0xFF) > 2 || value > 0x3FFF) { nm_set_error("seed policy must be 0, 1 or 2 (+ measurement bits 0x100 .. 0x2000)"); return NM_E_ARGUMENT; }
+        if (value < 0 || (value & 0xFF) > 2 || value > 0x3FFF) { nm_set_error("seed policy must be 0, 1 or 2 (+ A/B bits 0x800 .. 0x2000)"); return NM_E_ARGUMENT; }
+#ifndef NM_MEASURE
+        if (value & 0x700) { nm_set_error("seed policy bits 0x100 / 0x200 cut work out of the kernels and give wrong results: measurement build only (make -C newmap_amd/csrc measure)"); return NM_E_ARGUMENT; }
+#endif
         ix->view.seed_policy = (uint32_t)value;
         return NM_OK;
     }
@@ -694,7 +703,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
 
 extern "C" int nm_timing_read_kind(nm_index *ix, int kind, uint64_t *n_launches, double *total_ms, double *max_ms) {
     if (!ix) { nm_set_error("null handle"); return NM_E_ARGUMENT; }
-    if (kind < 0 || kind >= NM_TIMING_KINDS) { nm_set_error("timing kind must be 0 (dominant kernel), 1 (all kernels of a segment), 2 (coarse probes), 3 (fine probes) or 4 (k_resolve)"); return NM_E_ARGUMENT; }
+    if (kind < 0 || kind >= NM_TIMING_KINDS) { nm_set_error("timing kind must be 0 (search kernel), 1 (all kernels of a segment), 2 (coarse probes), 3 (fine probes), 4 (k_open_words + k_sweep + k_resolve) or 5 (k_sweep)"); return NM_E_ARGUMENT; }
     HIP_TRY(hipSetDevice(ix->device));
     double total = 0.0, mx = 0.0;
     std::vector<hipEvent_t> &pool = ix->ev_pool[kind];

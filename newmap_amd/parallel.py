@@ -103,9 +103,19 @@ def run_slice(records: Sequence[tuple[bytes, bytes]], units: Sequence[Unit],
     return np.concatenate(parts) if parts else np.zeros(0, dtype=dtype)
 
 
+def _group_formed() -> bool:
+    """a torch.distributed process group exists (a job launched by torch.distributed.run, even with ONE rank: its
+    collectives then run over RCCL / gloo like those of a larger job)"""
+    import sys
+    if "torch" not in sys.modules:
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def gather_to_root(local: np.ndarray, total: int, world: int, rank: int, device=None) -> np.ndarray | None:
     """ONE collective: equal padded slices -> rank 0.  Returns the full array on rank 0."""
-    if world == 1:
+    if world == 1 and not _group_formed():
         return local
     import torch
     import torch.distributed as dist
@@ -223,7 +233,7 @@ def search_records_sharded(records: Sequence[tuple[bytes, bytes]], compute: Call
 def _raise_together(world: int, rank: int, failure: Exception | None) -> None:
     """every rank learns whether any rank failed (one small all-reduce in the place of a bare barrier): the failing rank
     re-raises its own exception, the others raise a RuntimeError naming it -- nobody is left waiting in a collective"""
-    if world <= 1:
+    if world <= 1 and not _group_formed():
         if failure is not None:
             raise failure
         return
@@ -245,7 +255,7 @@ def unverified_records(index, info, world: int) -> list[int]:
     n = len(info)
     fps = np.array([fp for _, fp, _ in info], dtype=np.uint64)
     searched = np.array([s for _, _, s in info], dtype=np.int64)
-    if world > 1 and n:
+    if (world > 1 or _group_formed()) and n:
         import torch
         import torch.distributed as dist
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -276,7 +286,8 @@ def write_unique_counts_distributed(config) -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = None
-    if world > 1:
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ and "MASTER_PORT" in os.environ      # by torch.distributed.run, with any number of ranks
+    if world > 1 or launched:
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -297,7 +308,7 @@ def write_unique_counts_distributed(config) -> None:
     multi = len(config.fasta_filepaths) != 1 or len(config.fmindex_filepaths) != 1
 
     def barrier():
-        if world > 1:
+        if world > 1 or launched:
             import torch.distributed as dist
             dist.barrier()
 
@@ -307,7 +318,7 @@ def write_unique_counts_distributed(config) -> None:
         raise ValueError("The excluded sequences were too strict and nothing was processed: "
                          f"{config.exclude_sequence_ids}")
 
-    gather = world > 1 and os.environ.get("NEWMAP_AMD_GATHER", "0") == "1"
+    gather = (world > 1 or launched) and os.environ.get("NEWMAP_AMD_GATHER", "0") == "1"
     with open(config.fasta_filepaths[0], "rb") as fh:
         gzipped = fh.read(2) == b"\x1f\x8b"
     if not multi and not gather and not gzipped and os.environ.get("NEWMAP_AMD_PYTHON_DRIVER", "") != "1":
@@ -327,10 +338,19 @@ def write_unique_counts_distributed(config) -> None:
         # searched again by the exact guard on rank 0 (newmap/search.py:699-722; csrc/nm_hash.h)
         flags = unverified_records(index, info, world)
         failure = None
-        if rank == 0 and any(flags):
+        # the records to guard are dealt over the ranks (every rank knows all flags): a multi-Gbp FASTA that is not the indexed
+        # genome costs ~100 LF steps per position, and ranks waiting for ONE rank's guard would sit in the collective below
+        # for longer than its watchdog allows
+        order = 0
+        mine = [0] * len(flags)
+        for i, f in enumerate(flags):
+            if f:
+                mine[i] = int(order % max(world, 1) == rank)
+                order += 1
+        if any(mine):
             try:
                 index.guard_fasta(config.fasta_filepaths[0], config.kmer_lengths, config.is_binary_search, config.use_reverse_complement,
-                                  config.kmer_batch_size, config.include_sequence_ids, config.exclude_sequence_ids, flags)
+                                  config.kmer_batch_size, config.include_sequence_ids, config.exclude_sequence_ids, mine)
             except Exception as e:
                 failure = e
         _raise_together(world, rank, failure)

@@ -297,17 +297,17 @@ def _write_unique_counts_python(config: SearchConfig):
     processed_any = False
     summary = _Summary(min_kmer_length, max_kmer_length)
     current_id, current_path = None, None
-    # the record being searched: its fingerprint joined from the segments' (csrc/nm_hash.h) and the segments themselves, kept
-    # until its end -- a record that is not one of the indexed ones goes through the exact guard (newmap/search.py:699-722)
-    rec_fp, rec_pos, rec_joinable, rec_segments = 0, 0, True, []
+    # the record being searched: its fingerprint joined from the segments' (csrc/nm_hash.h).  A record that is not one of the
+    # indexed ones goes through the exact guard (newmap/search.py:699-722) in a second pass over the FASTA, as in the native
+    # driver: nothing of a record is kept beyond its current segment (--kmer-batch-size bounds the memory, as in the reference)
+    rec_fp, rec_pos, rec_joinable, rec_no = 0, 0, True, 0
+    unverified: set = set()
 
     def end_of_record():
-        nonlocal rec_fp, rec_pos, rec_joinable, rec_segments
-        if rec_segments and not (rec_joinable and index.has_record(rec_pos, rec_fp)):
-            for data, num_kmers in rec_segments:
-                index.guard_segment(data, num_kmers, config.kmer_lengths, config.is_binary_search, config.use_reverse_complement,
-                                    config.initial_search_length)
-        rec_fp, rec_pos, rec_joinable, rec_segments = 0, 0, True, []
+        nonlocal rec_fp, rec_pos, rec_joinable
+        if rec_pos and not (rec_joinable and index.has_record(rec_pos, rec_fp)):
+            unverified.add(rec_no)
+        rec_fp, rec_pos, rec_joinable = 0, 0, True
 
     with ExitStack() as stack:
         fasta = stack.enter_context(optional_gzip_open(config.fasta_filepaths[0], "rb"))
@@ -316,6 +316,7 @@ def _write_unique_counts_python(config: SearchConfig):
         for seg in sequence_segments(fasta, requested, lookahead):
             if seg.id != current_id:
                 if not _wanted(config, seg.id):
+                    rec_no += int(seg.epilogue)                       # (records are numbered as they come, wanted or not)
                     continue
                 if current_id is not None:
                     summary.report(config, current_id)
@@ -344,11 +345,23 @@ def _write_unique_counts_python(config: SearchConfig):
                 from .engine import fingerprint_join
                 rec_fp = (rec_fp + fingerprint_join(0, rec_pos, index.last_fingerprint())) & 0xFFFFFFFFFFFFFFFF
             rec_pos += num_kmers
-            rec_segments.append((seg.data, num_kmers))
             if seg.epilogue:
                 end_of_record()
+                rec_no += 1
         if current_id is not None:
             summary.report(config, current_id)
+        if unverified:                                                # the exact guard, record by record, segment by segment
+            fasta.seek(0)
+            n, cur_id = 0, None
+            for seg in sequence_segments(fasta, requested, lookahead):
+                # (the first pass skips the later segments of an unwanted id the same way: `seg.id != current_id` stays true for them)
+                wanted = seg.id == cur_id or _wanted(config, seg.id)
+                if wanted:
+                    cur_id = seg.id
+                    if n in unverified:
+                        index.guard_segment(seg.data, get_num_kmers(seg, max_kmer_length), config.kmer_lengths, config.is_binary_search,
+                                            config.use_reverse_complement, config.initial_search_length)
+                n += int(seg.epilogue)
     if not processed_any:                                             # :368-380
         _nothing_processed(config)
 

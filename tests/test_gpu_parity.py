@@ -358,6 +358,16 @@ def test_open_errors(tmp_path, eng):
         eng.Index(idx, -1)                      # no CPU path
     with pytest.raises(RuntimeError):
         eng.Index(idx, 99)
+    # the switches that cut work out of the kernels (wrong results, timing experiments) are not in this library
+    from newmap_amd import _lib
+    with eng.Index(idx, 0) as ix:
+        for bits in (0x100, 0x200, 0x300):
+            with pytest.raises(ValueError, match="measurement build"):
+                _lib.raise_for(ix._L.nm_set_option(ix.handle, _lib.NM_OPT_SEED_POLICY, bits))
+        for bits in (0, 1, 2, 0x800, 0x1000, 0x2000):     # cache policies and A/B switches: same results
+            _lib.raise_for(ix._L.nm_set_option(ix.handle, _lib.NM_OPT_SEED_POLICY, bits))
+        with pytest.raises(ValueError):
+            ix.set_sweep(3)
 
 
 def test_empty_and_tiny_inputs(tmp_path, eng):

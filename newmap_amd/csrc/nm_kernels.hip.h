@@ -660,14 +660,14 @@ __global__ __launch_bounds__(NM_SITE_BLOCK) void k_sites(nm_view ix, const uint8
 // ---- which kernel finishes the open positions of a launch: decided on the device, per word and per launch -------------------
 // k_open_words sorts the words of the need bitmap by their number of open positions.  Dense words (repeat family members:
 // stretches of open positions whose least unique strings end at common points) go to the sweep, which shares the walks
-// (k_sweep); in sparse words (fewer than 8 open positions: the scattered repeated windows of ordinary sequence, what the repeat
+// (k_sweep); in sparse words (fewer than 24 open positions: the scattered repeated windows of ordinary sequence, what the repeat
 // probes leave at the ends of tandem arrays) every position walks for itself, two bases per step (k_resolve on the bitmap of
 // those words).  A launch whose open positions lie mostly in sparse words is k_resolve's altogether: the few dense words it
 // has are long chains (the last kmax positions of a tandem array: one walk of up to kmax steps, then a step per position) that
 // would keep the launch waiting for their latency.  Both kernels are launched; what has nothing to do returns at once.
 #define NM_WORK_TAKEN 6             /* entries the waves of k_sweep have taken */
 #define NM_WORK_LIST 8              /* [8 + c]: number of words of class c that k_open_words listed, [12 + c]: their open positions */
-#define NM_SWEEP_CLASSES 4u         /* words by number of open positions: >= 48, >= 24, >= 8, fewer -- the long chains start first */
+#define NM_SWEEP_CLASSES 4u         /* words by number of open positions: >= 48, >= 32, >= 24 (the long chains start first), sparse or scattered */
 __device__ __forceinline__ bool nm_sweep_mode(const unsigned long long *work) {
     return work[NM_WORK_LIST + 4] + work[NM_WORK_LIST + 5] + work[NM_WORK_LIST + 6] >= work[NM_WORK_LIST + 7];  // most open positions lie in dense words
 }
@@ -816,9 +816,15 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
 #else
 #define NM_SWEEP_ATTR
 #endif
+// a word is the sweep's when it has 24 open positions or more and at least half of them have an open right neighbour (a
+// position is decided by one step only from the string its right neighbour left).  Fewer, or scattered, open positions -- the
+// repeated windows of ordinary sequence, short runs each -- walk for themselves: their walks are a few steps long and
+// k_resolve's single-interval steps are cheaper than the sweep's (measured on the uniform 3 Gbp genome with the small
+// tables: the native driver 0.28 s with k_resolve, 0.33 s when words of 8 open positions went to the sweep).
 __device__ __forceinline__ uint32_t nm_sweep_class(uint64_t bits) {
-    const uint32_t n = nm_popc64(bits);
-    return n >= 48 ? 0u : (n >= 24 ? 1u : (n >= 8 ? 2u : 3u));
+    const uint32_t n = nm_popc64(bits), chained = nm_popc64(bits & (bits >> 1));
+    if (n < 24 || 2 * chained < n) return 3u;
+    return n >= 48 ? 0u : (n >= 32 ? 1u : 2u);
 }
 // list[c * n_need + i] = i-th word of class c (in word order within a block: neighbouring words go to neighbouring lanes).
 // The class is that of the positions the repeat probes leave: what lies inside a stretch repeated over more than kmax bases is

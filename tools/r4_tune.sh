@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: routing between k_sweep and k_resolve on one box: parity subset, soak, hs, c5, headline
+# round 4: routing between k_sweep and k_resolve on one box: soak, hs, c5, headline, native driver with and without the sweep's launches
 set -o pipefail
 O=gpurun_out/r4b; mkdir -p $O
 run() { # name, env..., -- bench args
@@ -10,15 +10,15 @@ run() { # name, env..., -- bench args
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 k=d['kernels']
-print(sys.argv[2], round(d['value']/1e9,2), 'G/s', {n:round(v['total_ms'],1) for n,v in k.items()}, d["pipeline"]["resolve"].get("sweep"), flush=True)
+print(sys.argv[2], round(d['value']/1e9,2), 'G/s', {n[:12]:round(v['total_ms'],1) for n,v in k.items()}, d['pipeline']['resolve'].get('sweep'), flush=True)
 PY
 }
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "min_unique_equals_oracle or fixed_k_equals_oracle or human_shaped_stand_in or config5_tandem or repeat_probes_change or zero_count or fixtures" > $O/pytest_subset.log 2>&1 || { tail -30 $O/pytest_subset.log; exit 1; }
-tail -1 $O/pytest_subset.log
-timeout -k 10 600 python tools/fuzz_gpu.py --rounds 25 --seed 47 > $O/fuzz.log 2>&1 || { tail -30 $O/fuzz.log; exit 1; }
+timeout -k 10 600 python tools/fuzz_gpu.py --rounds 25 --seed 51 > $O/fuzz.log 2>&1 || { tail -30 $O/fuzz.log; exit 1; }
 tail -1 $O/fuzz.log
 run hs_default X=1 -- --config hs || exit 1
 run c5_default X=1 -- --config c5 --batch 100000000 --streams 3
-#run c5_nosweep NEWMAP_AMD_SWEEP=0 -- --config c5 --batch 100000000 --streams 3
 run ns_default X=1 -- --config ns
-#run ns_nosweep NEWMAP_AMD_SWEEP=0 -- --config ns
+for sw in 1 0 1 0; do
+  NEWMAP_AMD_SWEEP=$sw python tools/driver_sweep.py --workers 10 > $O/drv_sweep$sw.jsonl 2> $O/drv_sweep$sw.err
+  echo "sweep=$sw $(cat $O/drv_sweep$sw.jsonl)"; grep "\[driver\]" $O/drv_sweep$sw.err | tail -1
+done

@@ -735,6 +735,71 @@ def test_config5_full_size_properties(tmp_path, eng, monkeypatch):
         assert np.array_equal(forced, whole)
 
 
+def test_human_shaped_full_size_oracle_windows(tmp_path, eng):
+    """The human-shaped stand-in of configs[3]'s genome at FULL size (synth.human_like_dna, 3.09 Gbp in 24 records: repeat
+    families at 2 - 20 % divergence on both strands, segmental duplications, soft-masked half, N runs; lower case is searched,
+    newmap/search.py:23) on a device-built index -- what k_sweep and the routing of the open words were built for.  ORACLE
+    contact by the scan counter, ONE pass over all 24 records for every claim of: range mode 20:200 on three windows (the
+    start of chr1 behind its telomere gap, a repeat-rich stretch inside it, the end of chr21 with the tail rule) and list
+    mode k = 36 (newmap/search.py:551-644: k where the 36-mer occurs once, 0 where it is repeated or holds an N) on two;
+    beside it the sweep against k_resolve on 30 M positions, range and list."""
+    from newmap_amd import synth
+    from newmap_amd._c_newmap_generate_index import generate_fm_index
+    recs = synth.config_genome("hs")
+    assert len(recs) == 24 and sum(r.size for _, r in recs) > 3_000_000_000
+    fa = tmp_path / "hs.fa"
+    synth.write_fasta(fa, recs)
+    idx = tmp_path / "hs.awfmi"
+    generate_fm_index(str(fa), str(idx), 8, 12, device=0)
+    chr1, chr21 = recs[0][1].tobytes(), recs[20][1].tobytes()
+    all_records = [r[1] for r in recs]
+    kmin, kmax, W = 20, 200, 120_000
+    first = next(i for i in range(0, len(chr1), 1000) if chr1[i:i + 1000].upper().count(b"N") == 0)    # behind the telomere gap
+    with eng.Index(idx, 0) as ix:
+        ix.set_segment_guard(False)                          # (pieces of records: the record check has its own tests)
+        ix.set_sweep(True)                                   # from the first launch on (the default waits for the handle's first open positions)
+        n = 30_000_000
+        a0 = 60_000_000
+        whole, _ = ix.min_unique_segment(chr1[a0:a0 + n + kmax - 1], n, kmin, kmax)
+        assert ix.info()["last_range_kernel"] == 5
+        ow = ix.open_words()
+        assert sum(ow["positions"][:3]) > 5 * ow["positions"][3] > 0      # most open positions lie in dense words: the sweep's launch
+        zeros = float(np.mean(whole == 0))
+        assert 0.01 < zeros < 0.5 and ((whole == 0) | ((whole >= kmin) & (whole <= kmax))).all()
+        listed, _ = ix.fixed_k_segment(chr1[a0:a0 + n + 35], n, [36])
+        ix.set_sweep(False)                                  # every open position walks for itself (k_resolve): the same elements
+        plain, _ = ix.min_unique_segment(chr1[a0:a0 + n + kmax - 1], n, kmin, kmax)
+        assert np.array_equal(plain, whole)
+        plain_l, _ = ix.fixed_k_segment(chr1[a0:a0 + n + 35], n, [36])
+        assert np.array_equal(plain_l, listed)
+        ix.set_sweep(True)
+        head, _ = ix.min_unique_segment(chr1[first:first + W + kmax - 1], W, kmin, kmax)
+        tail, _ = ix.min_unique_segment(chr21, len(chr21), kmin, kmax)
+        # the densest stretch of open positions of the 30 M: where the sweep did most of its work
+        dens = np.add.reduceat((whole > 40).astype(np.int64), np.arange(0, n - W, W))
+        hot = int(np.argmax(dens)) * W
+    # ---- the oracle's scan counter: every claim of the windows in one pass over the genome
+    wins = [(chr1[first:first + W + kmax - 1], head), (chr1[a0 + hot:a0 + hot + W + kmax - 1], whole[hot:hot + W]), (chr21[-W:], tail[-W:])]
+    blob, starts, lens, rels = [], [], [], []
+    base = 0
+    for seg, out in wins:
+        st, ln, rel = rd.closed_form_claims(seg, out, kmin, kmax)
+        blob.append(seg); starts.append(st + base); lens.append(ln); rels.append(rel)
+        base += len(seg)
+    for o in (hot, 0):                                       # list mode k = 36: unique 36-mer <=> 36, repeated <=> 0, an N inside <=> 0
+        seg, out = chr1[a0 + o:a0 + o + W + 35], listed[o:o + W]
+        amb = ~np.isin(np.frombuffer(seg, np.uint8), np.frombuffer(b"ACGTacgt", np.uint8))
+        room_ok = np.convolve(amb.astype(np.int64), np.ones(36, np.int64))[35:35 + W] == 0          # no ambiguous byte in seg[p : p + 36]
+        assert not out[~room_ok].any() and np.isin(out, (0, 36)).all()
+        st = np.flatnonzero(room_ok)
+        blob.append(seg); starts.append(st + base); lens.append(np.full(st.size, 36, np.int64)); rels.append((out[st] == 0).astype(np.int8))
+        base += len(seg)
+    starts, lens, rels = np.concatenate(starts), np.concatenate(lens), np.concatenate(rels)
+    tot = rd.scan_total_counts(all_records, b"".join(blob), starts, lens, kmin)
+    assert ((tot == 1) == (rels == 0)).all(), "a reported length is not the least unique one"
+    assert (tot[rels == 1] >= 2).all() and starts.size > 4 * W
+
+
 # ------------------------------------------------------------------ BASELINE configs, scaled down
 def _records_fasta(recs):
     out = []

@@ -72,6 +72,10 @@ int nm_index_build_device(const char *fasta_path, const char *index_path, uint8_
  * table of that length on first use.  Replaces createIndex()
  * (src/newmap-count.c:9-17) -- but returns an error instead of continuing with a bad handle. */
 int nm_index_open(const char *index_path, int device, int seed_len_override, nm_index **out);
+/* The same with a budget: the automatic table sizes (seed_len_override -2 / -3) treat `hbm_budget_bytes` as all the HBM there is
+ * for this index (file contents included), so that the 2 - 4 index files of one search (newmap/search.py:656-697) co-reside,
+ * each with tables for its share.  0 = what the device reports free at the time of the call (nm_index_open). */
+int nm_index_open_budget(const char *index_path, int device, int seed_len_override, uint64_t hbm_budget_bytes, nm_index **out);
 void nm_index_close(nm_index *ix);
 
 /* index facts: 0 n (BWT length), 1 forward text length, 2 separators, 3 records, 4 raw bases,
@@ -241,6 +245,7 @@ int nm_dev_free(int device, void *p);
 int nm_dev_upload(int device, void *dst, const void *src, uint64_t bytes);
 int nm_dev_download(int device, void *dst, const void *src, uint64_t bytes);
 int nm_dev_sync(int device);
+uint64_t nm_dev_free_bytes(int device);                 /* free HBM right now (0 on error): budgets for nm_index_open_budget */
 int nm_device_count(void);
 
 /* ------------------------------------------------------------------ record fingerprints -----

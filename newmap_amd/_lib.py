@@ -31,7 +31,7 @@ NM_OPT_LF2 = 16
 NM_OPT_SWEEP = 17
 
 EXPORTS = [
-    "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_close",
+    "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_open_budget", "nm_dev_free_bytes", "nm_index_close",
     "nm_index_info", "nm_count_kmers", "nm_count_from_sequence", "nm_min_unique_segment",
     "nm_fixed_k_segment", "nm_upper_bound_segment", "nm_min_unique_segment_dev",
     "nm_fixed_k_segment_dev", "nm_set_option", "nm_dev_alloc", "nm_dev_free", "nm_dev_upload",
@@ -108,6 +108,10 @@ def lib():
     L.nm_index_build_device.argtypes = [c.c_char_p, c.c_char_p, u8, u8, i32]
     L.nm_index_open.restype = i32
     L.nm_index_open.argtypes = [c.c_char_p, i32, i32, pp]
+    L.nm_dev_free_bytes.restype = u64
+    L.nm_dev_free_bytes.argtypes = [i32]
+    L.nm_index_open_budget.restype = i32
+    L.nm_index_open_budget.argtypes = [c.c_char_p, i32, i32, u64, pp]
     L.nm_index_close.restype = None
     L.nm_index_close.argtypes = [vp]
     L.nm_index_info.restype = u64

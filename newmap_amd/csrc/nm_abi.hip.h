@@ -369,6 +369,12 @@ extern "C" int nm_dev_sync(int device) {
     return NM_OK;
 }
 
+extern "C" uint64_t nm_dev_free_bytes(int device) {                       // 0 on error
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    return (uint64_t)free_b;
+}
+
 // record fingerprints (nm_hash.h) ---------------------------------------------------------------
 
 extern "C" int nm_index_has_record(const nm_index *ix, uint64_t length, uint64_t hash) {

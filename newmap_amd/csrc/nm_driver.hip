@@ -469,17 +469,43 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
     if (fd < 0) { nm_set_error("could not open %s: %s", fasta_path, strerror(errno)); return NM_E_FILE_OPEN; }
     struct stat st;
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return -1; }
-    const size_t size = (size_t)st.st_size;
+    size_t size = (size_t)st.st_size;
     unsigned char magic[2] = {0, 0};
-    if (size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { close(fd); return -1; }
     const unsigned char *base = nullptr;
-    if (size) {
-        void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) { close(fd); return -1; }
-        (void)madvise(m, size, MADV_WILLNEED);
-        base = (const unsigned char *)m;
+    unsigned char *inflated = nullptr;                        // gzip input (newmap/util.py:10-18): inflated once into memory, then the same front-end
+    if (size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        close(fd);
+        gzFile gz = gzopen(fasta_path, "rb");
+        if (!gz) return -1;
+        (void)gzbuffer(gz, 1u << 20);
+        size_t cap = size * 4 + (1u << 20), used = 0;
+        inflated = (unsigned char *)malloc(cap);
+        while (inflated) {
+            if (cap - used < (1u << 24)) {
+                cap += cap / 2 + (1u << 24);
+                unsigned char *grown = (unsigned char *)realloc(inflated, cap);
+                if (!grown) { free(inflated); inflated = nullptr; break; }
+                inflated = grown;
+            }
+            const size_t want = cap - used < (1u << 30) ? cap - used : (size_t)(1u << 30);
+            const int got = gzread(gz, inflated + used, (unsigned)want);
+            if (got < 0) { free(inflated); inflated = nullptr; gzclose(gz); nm_set_error("could not inflate %s", fasta_path); return NM_E_FILE_OPEN; }
+            if (got == 0) break;
+            used += (size_t)got;
+        }
+        gzclose(gz);
+        if (!inflated) { nm_set_error("out of memory inflating %s", fasta_path); return NM_E_ALLOC; }
+        base = inflated;
+        size = used;
+    } else {
+        if (size) {
+            void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); return -1; }
+            (void)madvise(m, size, MADV_WILLNEED);
+            base = (const unsigned char *)m;
+        }
+        close(fd);
     }
-    close(fd);
     const unsigned threads = host_threads();
     FastDriver d;
     d.ix = ix;
@@ -493,7 +519,7 @@ int fast_run(nm_index *ix, const char *fasta_path, const char *out_dir, const ui
     const char *suffix = d.elem_bytes == 1 ? "uint8" : (d.elem_bytes == 2 ? "uint16" : "uint32");
     d.batch = batch >= 64 ? batch & ~63ull : batch;          // (segments start at multiples of 64 bases of their record: their fingerprints join, nm_hash.h)
     d.lookahead = d.kmax - 1;                                            // newmap/search.py:229
-    auto unmap = [&]() { if (base) munmap((void *)base, size); };
+    auto unmap = [&]() { if (inflated) free(inflated); else if (base) munmap((void *)base, size); };
 
     // ---- records, their pieces, the bases in front of each piece (nm_fasta_scan.hpp; threaded)
     d.recs = nm_fasta::scan(base, size, threads);
@@ -908,7 +934,7 @@ static int search_fasta_impl(nm_index *ix, const char *fasta_path, const char *o
         if (rc != -1) return rc;
     }
     if (world > 1) {
-        nm_set_error("the sharded native driver reads byte ranges of an uncompressed FASTA file: decompress %s first", fasta_path);
+        nm_set_error("the sharded native driver needs a FASTA file it can map or inflate: %s", fasta_path);
         return NM_E_ARGUMENT;
     }
     Driver d;

@@ -90,11 +90,23 @@ static int nm_build_seed_table(nm_index *ix, uint32_t s, void **d_table, uint32_
 
 // core length of the quad table: as long as the seed, at most 60 % of the HBM still free once the seed table is
 // in place (4^m x 128 bytes: 137 GB for m = 15)
+// Free HBM as the table sizing sees it: what the device reports, capped by what is left of the caller's budget for THIS index
+// (nm_index_open_budget: several indexes of one search co-reside -- newmap/search.py:656-697 sums the counts of every index
+// file -- each sized for its share).  0 = no budget.
+static thread_local uint64_t g_open_budget = 0;
+static hipError_t nm_free_hbm(const nm_index *ix, size_t *free_b, size_t *total_b) {
+    const hipError_t e = hipMemGetInfo(free_b, total_b);
+    if (e == hipSuccess && g_open_budget) {
+        const uint64_t left = g_open_budget > ix->device_bytes ? g_open_budget - ix->device_bytes : 0;
+        if (*free_b > left) *free_b = (size_t)left;
+    }
+    return e;
+}
+
 static uint32_t nm_auto_quad_len(const nm_index *ix, uint32_t s) {
-    (void)ix;
     uint32_t m = s;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    if (nm_free_hbm(ix, &free_b, &total_b) != hipSuccess) return 0;
     free_b -= free_b < (8ULL << (2 * s)) ? free_b : (8ULL << (2 * s));      // the seed table comes first
     while (m >= 8 && (128ULL << (2 * m)) > free_b / 5 * 3) m--;
     return m >= 8 ? m : 0;
@@ -109,7 +121,7 @@ static uint32_t nm_auto_seed_len(const nm_index *ix) {
     s = s + bonus > 16 ? 16 : s + bonus;
     if (s < 4) s = 4;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+    if (nm_free_hbm(ix, &free_b, &total_b) == hipSuccess)
         while (s > 4 && (8ULL << (2 * s)) > free_b / 4) s--;   // never more than a quarter of free HBM
     return s;
 }
@@ -150,7 +162,7 @@ static int nm_build_lf2(nm_index *ix) {
     const uint64_t n_blocks = ix->h.n / 64 + 1, n_chunks = (n_blocks + NM_LF2_CHUNK - 1) / NM_LF2_CHUNK;
     const uint64_t bytes = n_blocks * 16 * sizeof(nm_lf_entry);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + (16ull << 30) > free_b) return NM_OK;
+    if (nm_free_hbm(ix, &free_b, &total_b) != hipSuccess || bytes + (16ull << 30) > free_b) return NM_OK;
     double t0 = nm_now();
     void *table = nullptr;
     uint64_t *d_sums = nullptr;
@@ -207,7 +219,7 @@ static int nm_build_dict(nm_index *ix) {
     if (x <= s) return NM_OK;
     double td = nm_now();
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return NM_OK;
+    if (nm_free_hbm(ix, &free_b, &total_b) != hipSuccess) return NM_OK;
     // room for the lists: a repeated L-mer has two occurrences at least (n / 2 strings), and a text without much repetition
     // has about 4^L (1 - e^-l (1 + l)), l = n / 4^L, of them at the first level -- twice that is allocated, the rest of the
     // memory stays untouched (a genome with more repeated strings than that goes without a dictionary)
@@ -300,6 +312,14 @@ static int nm_view_for(nm_index *ix, uint32_t shortest, nm_view *v) {
     v->seed = (const uint64_t *)ix->d_seed2;
     v->seed_len = s2;
     return NM_OK;
+}
+
+extern "C" int nm_index_open(const char *index_path, int device, int seed_len_override, nm_index **out);
+extern "C" int nm_index_open_budget(const char *index_path, int device, int seed_len_override, uint64_t hbm_budget_bytes, nm_index **out) {
+    g_open_budget = hbm_budget_bytes;
+    const int rc = nm_index_open(index_path, device, seed_len_override, out);
+    g_open_budget = 0;
+    return rc;
 }
 
 extern "C" int nm_index_open(const char *index_path, int device, int seed_len_override, nm_index **out) {
@@ -534,7 +554,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
                 quad_small_m = 0;
                 size_t free_b = 0, total_b = 0;
                 const uint64_t first = (8ULL << (2 * s)) + (128ULL << (2 * quad_m)), want = 128ULL << 28;
-                if (!small_tables && quad_m > 14 && repeated(14) <= 0.15 && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                if (!small_tables && quad_m > 14 && repeated(14) <= 0.15 && nm_free_hbm(ix, &free_b, &total_b) == hipSuccess &&
                     free_b > first && want <= (free_b - first) / 2)
                     quad_small_m = 14;
             }

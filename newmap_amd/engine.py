@@ -37,11 +37,12 @@ def _as_u8(buf) -> np.ndarray:
 class Index:
     """Device-resident index.  Replaces the per-call load of src/newmap-count.c:9-17,135-136."""
 
-    def __init__(self, index_path, device: int | None = None, seed_length: int | str | None = None):
+    def __init__(self, index_path, device: int | None = None, seed_length: int | str | None = None, hbm_budget: int | None = None):
         """seed_length: None / "auto" = tables sized for throughput (seed ceil(log4 n)+2 <= 16 bases, quad table of
         cores as long as the free HBM allows: up to 180 GB), "auto-small" = the same kernels on tables of at
         most 20 GB (what the one-shot CLI uses), "file" = the --seed-length recorded by `newmap index`,
-        0 = no seed table, 1..16 = that length."""
+        0 = no seed table, 1..16 = that length.  hbm_budget (bytes): what the automatic sizes may take of the HBM for THIS
+        index, all of it included -- the index files of one search share the device (nm_index_open_budget)."""
         self._L = _lib.lib()
         self.path = Path(index_path)
         self.device = default_device() if device is None else int(device)
@@ -51,7 +52,10 @@ class Index:
         if code is None:
             code = int(seed_length)
         h = ctypes.c_void_p()
-        rc = self._L.nm_index_open(os.fsencode(self.path), self.device, code, ctypes.byref(h))
+        if hbm_budget:
+            rc = self._L.nm_index_open_budget(os.fsencode(self.path), self.device, code, int(hbm_budget), ctypes.byref(h))
+        else:
+            rc = self._L.nm_index_open(os.fsencode(self.path), self.device, code, ctypes.byref(h))
         _lib.raise_for(rc)
         self._h = h
         self._lock = threading.Lock()
@@ -407,7 +411,8 @@ _cache: dict[tuple, Index] = {}
 _cache_lock = threading.Lock()
 
 
-def cached_index(index_path, device: int | None = None) -> Index:
+def cached_index(index_path, device: int | None = None, hbm_budget: int | None = None) -> Index:
+    """the resident handle of an index file; hbm_budget: see Index (used when the file is opened, not for a cached handle)"""
     p = Path(index_path)
     try:
         st = p.stat()
@@ -420,9 +425,22 @@ def cached_index(index_path, device: int | None = None) -> Index:
         if ix is None or not ix._h:
             for k in [k for k in _cache if k[0] == key[0] and k[3] == dev]:
                 _cache.pop(k).close()
-            ix = Index(p, dev)
+            ix = Index(p, dev, None, hbm_budget)
             _cache[key] = ix
         return ix
+
+
+def cached_indexes(index_paths, device: int | None = None) -> list:
+    """the resident handles of the index files of ONE search (newmap/search.py:656-697 sums the counts of every file): files
+    that have to be opened share the HBM that is free now in equal budgets, so that each gets tables for its share instead
+    of the first one taking all of it"""
+    paths = list(index_paths)
+    if len(paths) <= 1:
+        return [cached_index(p, device) for p in paths]
+    dev = default_device() if device is None else device
+    free = int(_lib.lib().nm_dev_free_bytes(dev))
+    budget = int(free * 0.9 / len(paths)) if free else None
+    return [cached_index(p, device, budget) for p in paths]
 
 
 def close_all():

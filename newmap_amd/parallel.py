@@ -13,7 +13,7 @@ index, so positions shard with no data-path collective:
     ranges of its units out of the FASTA, searches them on its GPU and writes them straight into the per-record
     `<id>.unique.<dtype>` files at their offsets -- each GPU drains over its own PCIe link, nothing crosses xGMI and no
     rank holds the whole FASTA;
-  * gzip input: the ranks read the records in Python and write their shares the same way (`write_ranges_direct`);
+  * gzip input takes the same path (every rank inflates the file once into memory and strips its own ranges);
     jobs whose ranks do not share a file system (NEWMAP_AMD_GATHER=1): ONE collective at the end gathers the padded
     per-rank results on rank 0 (RCCL), which writes the files.
 
@@ -319,9 +319,7 @@ def write_unique_counts_distributed(config) -> None:
                          f"{config.exclude_sequence_ids}")
 
     gather = (world > 1 or launched) and os.environ.get("NEWMAP_AMD_GATHER", "0") == "1"
-    with open(config.fasta_filepaths[0], "rb") as fh:
-        gzipped = fh.read(2) == b"\x1f\x8b"
-    if not multi and not gather and not gzipped and os.environ.get("NEWMAP_AMD_PYTHON_DRIVER", "") != "1":
+    if not multi and not gather and os.environ.get("NEWMAP_AMD_PYTHON_DRIVER", "") != "1":
         # every rank runs the native driver on its own interleaved share of the position space
         index = cached_index(config.fmindex_filepaths[0], local_rank if config.device is None else config.device)
         index.set_initial_search_length(config.initial_search_length)
@@ -374,8 +372,9 @@ def write_unique_counts_distributed(config) -> None:
             raise ValueError(f"{path}: the sharded lock-step search needs the record lengths of {config.fasta_filepaths[0]} "
                              "(run a single process for files that differ)")
         companions.append(other[:len(records)])
-    index = cached_index(config.fmindex_filepaths[0], local_rank if config.device is None else config.device)
-    indexes = [index] + [cached_index(p, local_rank if config.device is None else config.device) for p in config.fmindex_filepaths[1:]]
+    from .engine import cached_indexes
+    indexes = cached_indexes(config.fmindex_filepaths, local_rank if config.device is None else config.device)
+    index = indexes[0]
 
     def compute(seg, count: int) -> np.ndarray:
         if multi:

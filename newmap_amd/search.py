@@ -17,7 +17,7 @@ from typing import Callable, Sequence
 
 from ._lazy import np        # numpy, imported at its first use: the one-shot CLI's native path never needs it (0.15 s)
 
-from .engine import Index, cached_index
+from .engine import Index, cached_index, cached_indexes
 from .fasta import SequenceSegment, sequence_segments
 from .util import INDEX_EXTENSION, optional_gzip_open, verbose_print
 
@@ -118,7 +118,7 @@ def binary_search(config: SearchConfig, sequence_segments: Sequence[SequenceSegm
     """newmap/search.py:383-548 -> (unique_lengths, ambiguous_positions_skipped), one launch."""
     if len(sequence_segments) > 1 or len(config.fmindex_filepaths) > 1:
         from .engine import search_segment_multi
-        indexes = [cached_index(p, config.device) for p in config.fmindex_filepaths]
+        indexes = cached_indexes(config.fmindex_filepaths, config.device)
         return search_segment_multi(indexes, [s.data for s in sequence_segments],
                                     get_num_kmers(sequence_segments[0], max_kmer_length),
                                     [min_kmer_length, max_kmer_length], True, config.use_reverse_complement, data_type)
@@ -136,7 +136,7 @@ def linear_search(config: SearchConfig, sequence_segments: Sequence[SequenceSegm
     """newmap/search.py:551-644 -> (unique_lengths, ambiguous_positions_skipped), one launch."""
     if len(sequence_segments) > 1 or len(config.fmindex_filepaths) > 1:
         from .engine import search_segment_multi
-        indexes = [cached_index(p, config.device) for p in config.fmindex_filepaths]
+        indexes = cached_indexes(config.fmindex_filepaths, config.device)
         return search_segment_multi(indexes, [s.data for s in sequence_segments], num_kmers, config.kmer_lengths,
                                     False, config.use_reverse_complement, data_type)
     seg = sequence_segments[0]
@@ -250,7 +250,7 @@ def _write_unique_counts_multi(config: SearchConfig):
     max_kmer_length, min_kmer_length = max(config.kmer_lengths), min(config.kmer_lengths)
     data_type, suffix = output_type(max_kmer_length)
     _check_range(config, min_kmer_length, max_kmer_length)
-    indexes = [cached_index(p, config.device) for p in config.fmindex_filepaths]
+    indexes = cached_indexes(config.fmindex_filepaths, config.device)
     lookahead = max_kmer_length - 1
     requested = config.kmer_batch_size + lookahead
     processed_any = False

@@ -312,13 +312,16 @@ def test_record_fingerprints_and_native_driver_guard(tmp_path, eng, monkeypatch)
                     monkeypatch.delenv(k_)
 
         for env in ({"NEWMAP_AMD_DRIVER_FUSE": "0"}, {"NEWMAP_AMD_STREAMING_DRIVER": "1"}, {}):
-            for batch in (10_000_000, 64 * 777, 1000):                   # (1000: segments not at words of the record -> guard, no raise)
-                if not env and batch == 1000:
+            # (the drivers round their working batch down to a multiple of 64 bases: segments start at words of their record and
+            #  their fingerprints join, whatever --kmer-batch-size is -- 1000 works like 960; below 64 nothing can be rounded:
+            #  the segments do not join and the record goes through the exact guard, which does not raise for an indexed record)
+            for batch in (10_000_000, 64 * 777, 1000, 50):
+                if not env and batch == 50:
                     continue                                             # (fused into one unit per record: nothing to join)
                 before = ix.guard_segments()
                 total, out_dir = run(fa, "same", [20, 200], True, batch, **env)
                 assert total["positions"] == len(r1) + len(r2)
-                assert (ix.guard_segments() == before) == (batch != 1000), (env, batch)
+                assert (ix.guard_segments() == before) == (batch != 50), (env, batch)
         same_one = np.fromfile(tmp_path / "same" / "one.unique.uint8", dtype=np.uint8)
         # a FASTA with the records renamed and reordered is still the indexed genome
         fa2 = tmp_path / "renamed.fa"
@@ -368,6 +371,36 @@ def test_open_errors(tmp_path, eng):
             _lib.raise_for(ix._L.nm_set_option(ix.handle, _lib.NM_OPT_SEED_POLICY, bits))
         with pytest.raises(ValueError):
             ix.set_sweep(3)
+
+
+def test_indexes_of_one_search_share_the_hbm(tmp_path, eng):
+    """newmap/search.py:656-697 sums the counts of every index file: the handles of one search are resident together.  Two
+    100 Mbp indexes opened for one search ("auto" tables, equal budgets of the free HBM: engine.cached_indexes) BOTH get
+    their quad tables, seed tables and LF blocks; a budget that leaves room for the small tables only gives those; a
+    budgeted handle's results are the unbudgeted handle's."""
+    from newmap_amd import synth
+    recs = [synth.uniform_dna(100_000_000, 41), synth.uniform_dna(100_000_000, 42)]
+    paths = []
+    for i, r in enumerate(recs):
+        fa = tmp_path / f"g{i}.fa"
+        synth.write_fasta(fa, [(f"g{i}", r)])
+        idx = tmp_path / f"g{i}.awfmi"
+        from newmap_amd._c_newmap_generate_index import generate_fm_index
+        generate_fm_index(str(fa), str(idx), 8, 12, device=0)
+        paths.append(idx)
+    a, b = eng.cached_indexes(paths, 0)
+    ia, ib = a.info(), b.info()
+    for info in (ia, ib):
+        assert info["quad_core_length"] >= 13 and info["quad_small_core_length"] >= 8 and info["seed_length"] >= 15 and info["lf_blocks"] == 1
+    assert ia["device_bytes"] + ib["device_bytes"] < 200e9
+    seg = recs[1][:5_000_199].tobytes()
+    want, _ = b.min_unique_segment(seg, 5_000_000, 20, 200)
+    eng.close_all()
+    with eng.Index(paths[1], 0, "auto", hbm_budget=6 << 30) as tight:       # rank + strand + LF blocks of a 100 Mbp index are ~0.5 GB
+        info = tight.info()
+        assert info["device_bytes"] < (6 << 30) and 0 < info["quad_core_length"] < ia["quad_core_length"]
+        got, _ = tight.min_unique_segment(seg, 5_000_000, 20, 200)
+    assert np.array_equal(got, want)
 
 
 def test_empty_and_tiny_inputs(tmp_path, eng):
@@ -1167,6 +1200,23 @@ def test_native_driver_front_ends_and_shards(tmp_path, mixed_genome, eng, monkey
                 monkeypatch.delenv("NEWMAP_AMD_SHARD_CHUNK")
                 assert files(tmp_path / (name + "_w3")) == b, name
                 assert sum(p["positions"] for p in parts) == t_fast["positions"] and sum(p["unique"] for p in parts) == t_fast["unique"]
+    # gzip input (newmap/util.py:10-18) through the same front-ends: inflated once, then stripped in parallel; one process and
+    # the shares of three ranks give the plain file's bytes
+    import gzip
+    for fa, idx, tag in ((fa_odd, idx_odd, "odd"), (g["fa"], g["idx"], "mixed")):
+        gz = tmp_path / f"{tag}.fa.gz"
+        gz.write_bytes(gzip.compress(Path(fa).read_bytes(), 1))
+        with eng.Index(idx, 0) as ix:
+            for ks, is_range, batch in (([20, 200], True, 100_000), ([30, 16, 40], False, 1300)):
+                name = f"{tag}_gz_{ks[0]}_{int(is_range)}"
+                plain = run(ix, fa, tmp_path / (name + "_p"), ks, is_range, batch)
+                one = run(ix, gz, tmp_path / (name + "_g"), ks, is_range, batch)
+                assert files(tmp_path / (name + "_g")) == files(tmp_path / (name + "_p")) and one["positions"] == plain["positions"], name
+                monkeypatch.setenv("NEWMAP_AMD_SHARD_CHUNK", "1999")
+                parts = [run(ix, gz, tmp_path / (name + "_g3"), ks, is_range, batch, rank=r, world=3) for r in range(3)]
+                monkeypatch.delenv("NEWMAP_AMD_SHARD_CHUNK")
+                assert files(tmp_path / (name + "_g3")) == files(tmp_path / (name + "_p")), name
+                assert sum(p_["positions"] for p_ in parts) == plain["positions"]
     with eng.Index(idx_odd, 0) as ix:                       # include / exclude and a mismatching FASTA through the parallel front-end
         t = run(ix, fa_odd, tmp_path / "inc", [12, 60], True, 700)
         assert t["records"] == 5                            # "", r1 (its last run), r2, r3, r4

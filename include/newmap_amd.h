@@ -179,6 +179,8 @@ enum {
     NM_OPT_SWEEP = 17,             /* the positions the sites leave open: 1 (default) = launches list the words that hold them and k_sweep takes
                                       the launch where they are dense (neighbours share their walks), once the handle has met open positions;
                                       2 = from the first launch on (tests); 0 = every position walks for itself (k_resolve), for A/B */
+    NM_OPT_LCP = 18,               /* A/B: the sweep reads the index's LCP bytes where the end of a chain moves (default 1 where the index file
+                                      holds them and the handle is a resident one) or walks */
     NM_OPT_LF2 = 16,               /* A/B: walks take two bases per step on the two-base LF blocks (default 1 where they were built) */
     NM_OPT_SEGMENT_GUARD = 15,     /* default 1: nm_min_unique_segment / nm_fixed_k_segment (host buffers: the seam of binary_search /
                                       linear_search) run the exact zero-count guard unless the segment is a whole indexed record;

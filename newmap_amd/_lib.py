@@ -29,6 +29,7 @@ NM_OPT_INITIAL_LENGTH = 14
 NM_OPT_SEGMENT_GUARD = 15
 NM_OPT_LF2 = 16
 NM_OPT_SWEEP = 17
+NM_OPT_LCP = 18
 
 EXPORTS = [
     "nm_last_error", "nm_version", "nm_index_build", "nm_index_open", "nm_index_open_budget", "nm_dev_free_bytes", "nm_index_close",

@@ -153,6 +153,20 @@ int read_fasta(const char *path, FastaText &ft) {
     return NM_OK;
 }
 
+thread_local uint8_t *g_lcp_buffer = nullptr;
+thread_local bool g_lcp_done = false;
+
+// bases the suffixes at p and q share (a separator matches nothing), capped
+static inline uint8_t lcp_capped(const uint8_t *T, uint64_t p, uint64_t q) {
+    uint32_t h = 0;
+    while (h < NM_LCP_CAP) {
+        const uint8_t a = T[p + h];
+        if (a < SYM_A || a != T[q + h]) break;               // (T ends with SYM_END: the loop stops inside the text)
+        h++;
+    }
+    return (uint8_t)h;
+}
+
 template <class I>
 int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_ratio, uint8_t seed_len,
                     nm_sa32_provider provider = nullptr, void *provider_ctx = nullptr, nm_bwt_provider bwt_provider = nullptr) {
@@ -180,6 +194,13 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
     double tv = nm::pd_now();
     const int nt = nm::pd_threads();
     nm::PdBuf<uint8_t> bw(n);                                  // BWT symbol (low bits) | "suffix starts in the RC half" (bit 7)
+    // LCP bytes (nm_format.h): NEWMAP_AMD_LCP=0 builds an index without them
+    const char *lcp_env = getenv("NEWMAP_AMD_LCP");
+    const bool want_lcp = !(lcp_env && lcp_env[0] == '0');
+    nm::PdBuf<uint8_t> lcp(want_lcp ? n + 1 : 1);
+    g_lcp_buffer = want_lcp ? lcp.data() : nullptr;
+    g_lcp_done = false;
+    struct LcpReset { ~LcpReset() { g_lcp_buffer = nullptr; } } lcp_reset;
     bool have_bw = false;
     if (bwt_provider) {
         // suffix sort AND the gather of the BWT on the device (nm_build_device.hip): only n bytes come back
@@ -204,7 +225,16 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
         } else if (use_pd) nm::pd_suffix_array<I>(T.data(), n, SA.data());
         else nm::sais<uint8_t, I>(T.data(), SA.data(), (I)n, (I)6);
         if (verbose) { fprintf(stderr, "[build] suffix array (%s, %d threads): %.2fs\n", provider ? "device prefix doubling" : (use_pd ? "prefix doubling" : "SA-IS"), nm::pd_threads(), nm::pd_now() - tv); tv = nm::pd_now(); }
+        if (want_lcp && !g_lcp_done) {                         // (a device provider has filled them from its own copy of the array)
+            lcp[0] = 0;
+#pragma omp parallel for schedule(dynamic, 1 << 16) num_threads(nm::pd_threads())
+            for (int64_t j = 1; j < (int64_t)n; j++) lcp[(uint64_t)j] = lcp_capped(T.data(), (uint64_t)SA[(uint64_t)j], (uint64_t)SA[(uint64_t)j - 1]);
+            g_lcp_done = true;
+            if (verbose) { fprintf(stderr, "[build] LCP bytes on the host: %.2fs\n", nm::pd_now() - tv); tv = nm::pd_now(); }
+        }
     }
+    const bool have_lcp = want_lcp && g_lcp_done;
+    if (have_lcp) { lcp[0] = 0; lcp[n] = 0; }
 
     nm_file_header h;
     memset(&h, 0, sizeof h);
@@ -316,6 +346,7 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
     h.off_records = h.off_sep + sep.size() * sizeof(uint64_t);
     if (ft.records.size() != h.n_records) { nm_set_error("internal error: record count mismatch"); return NM_E_FILE_WRITE; }
     h.file_bytes = h.off_records + ft.records.size() * sizeof(nm_record_entry);
+    if (have_lcp) { h.off_lcp = h.file_bytes; h.file_bytes += n + 1; }
 
     FILE *fp = fopen(index_path, "wb");        // overwrite, like the reference at its pinned version
     if (!fp) { nm_set_error("Could not write index file %s: %s", index_path, strerror(errno)); return NM_E_FILE_WRITE; }
@@ -323,7 +354,8 @@ int build_and_write(const FastaText &ft, const char *index_path, uint8_t sa_rati
               fwrite(rank.data(), sizeof(nm_rank_block), rank.size(), fp) == rank.size() &&
               fwrite(strand.data(), sizeof(nm_strand_block), strand.size(), fp) == strand.size() &&
               (sep.empty() || fwrite(sep.data(), sizeof(uint64_t), sep.size(), fp) == sep.size()) &&
-              (ft.records.empty() || fwrite(ft.records.data(), sizeof(nm_record_entry), ft.records.size(), fp) == ft.records.size());
+              (ft.records.empty() || fwrite(ft.records.data(), sizeof(nm_record_entry), ft.records.size(), fp) == ft.records.size()) &&
+              (!have_lcp || fwrite(lcp.data(), 1, n + 1, fp) == n + 1);
     ok = (fclose(fp) == 0) && ok;
     if (!ok) { nm_set_error("Could not write index file %s", index_path); return NM_E_FILE_WRITE; }
     return NM_OK;
@@ -359,6 +391,9 @@ int nm_index_build_impl(const char *fasta_path, const char *index_path, uint8_t 
         return NM_E_FILE_WRITE;
     }
 }
+
+uint8_t *nm_build_lcp_buffer(void) { return g_lcp_buffer; }
+void nm_build_lcp_done(void) { g_lcp_done = true; }
 
 extern "C" int nm_index_build(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len) {
     return nm_index_build_impl(fasta_path, index_path, sa_ratio, seed_len, nullptr, nullptr);

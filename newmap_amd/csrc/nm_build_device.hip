@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/newmap_amd.h"
+#include "nm_format.h"
 #include "nm_internal.h"
 
 #define HIP_TRY(expr)                                                                         \
@@ -80,6 +81,24 @@ __global__ __launch_bounds__(SA_BLOCK) void k_sa_keys(const uint32_t *__restrict
 }
 
 namespace {
+// LCP bytes (nm_format.h: off_lcp): lcp[j] = bases the suffixes of rows j - 1 and j share, capped; a separator (symbols below 2)
+// matches nothing.  One lane per row, the text and the finished suffix array resident.
+template <class IDX>
+__global__ __launch_bounds__(SA_BLOCK) void k_lcp_bytes(const uint8_t *__restrict__ T, const IDX *__restrict__ SA, unsigned long long first,
+                                                        unsigned long long n, uint8_t *__restrict__ lcp) {
+    const unsigned long long j = first + blockIdx.x * (unsigned long long)SA_BLOCK + threadIdx.x;
+    if (j > n) return;
+    if (j == 0 || j == n) { lcp[j] = 0; return; }
+    const unsigned long long p = (unsigned long long)SA[j], q = (unsigned long long)SA[j - 1];
+    unsigned h = 0;
+    while (h < NM_LCP_CAP) {
+        const uint8_t a = T[p + h];
+        if (a < 2 || a != T[q + h]) break;                 // (the text ends with symbol 0: the loop stops inside it)
+        h++;
+    }
+    lcp[j] = (uint8_t)h;
+}
+
 struct DBuf {
     void *p = nullptr;
     ~DBuf() { reset(); }
@@ -152,6 +171,14 @@ int device_suffix_array(const uint8_t *T, uint64_t n64, int32_t *SA, void *ctx_)
         TRYH(rocprim::radix_sort_pairs(dTmp.p, tb, keys, vals, n, 0, key_bits, st));
     }
     TRYH(hipMemcpyAsync(SA, vals.current(), (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (uint8_t *lcp_host = nm_build_lcp_buffer()) {        // the LCP bytes while text and suffix array are here (dK0 is free now: n + 1 bytes of it)
+        uint8_t *d_lcp = (uint8_t *)(keys.current() == (uint64_t *)dK0.p ? dK1.p : dK0.p);
+        hipLaunchKernelGGL((k_lcp_bytes<uint32_t>), dim3((unsigned)(((uint64_t)n + 1 + SA_BLOCK - 1) / SA_BLOCK)), dim3(SA_BLOCK), 0, st, (const uint8_t *)dT.p,
+                           (const uint32_t *)vals.current(), 0ULL, (unsigned long long)n, d_lcp);
+        TRYH(hipMemcpyAsync(lcp_host, d_lcp, (uint64_t)n + 1, hipMemcpyDeviceToHost, st));
+        TRYH(hipStreamSynchronize(st));
+        nm_build_lcp_done();
+    }
     TRYH(hipStreamSynchronize(st));
     TRYH(hipGetLastError());
     (void)hipStreamDestroy(st);
@@ -495,6 +522,20 @@ int device_bwt_large(const uint8_t *T, uint64_t n, uint64_t nf, uint8_t *bw, voi
         TRYB(hipMemcpyAsync(bw + a, (const uint8_t *)dBw.p + a, len, hipMemcpyDeviceToHost, st));
     }
     TRYB(hipStreamSynchronize(st));
+    if (uint8_t *lcp_host = nm_build_lcp_buffer()) {        // the LCP bytes while text and suffix array are here
+        dBw.reset();
+        DBuf dLcp;
+        if ((rc = dev_alloc(dLcp, n + 1)) != NM_OK) return fail(NM_E_ALLOC);
+        for (u64 first = 0; first <= n; first += slice)
+            hipLaunchKernelGGL((k_lcp_bytes<u64>), grid(n + 1 - first < slice ? n + 1 - first : slice), dim3(SA_BLOCK), 0, st, d_T, (const u64 *)SA, first, (u64)n,
+                               (uint8_t *)dLcp.p);
+        for (u64 a = 0; a < n + 1; a += 1ULL << 30) {
+            const u64 len = n + 1 - a < (1ULL << 30) ? n + 1 - a : (1ULL << 30);
+            TRYB(hipMemcpyAsync(lcp_host + a, (const uint8_t *)dLcp.p + a, len, hipMemcpyDeviceToHost, st));
+        }
+        TRYB(hipStreamSynchronize(st));
+        nm_build_lcp_done();
+    }
     TRYB(hipGetLastError());
     (void)hipStreamDestroy(st);
     return NM_OK;

@@ -62,6 +62,7 @@ struct nm_view {                // the index as the kernels see it
     const uint64_t *dict;       // repeat dictionary (below): 2^dict_bits buckets of 128 bytes, nullptr = none
     uint32_t dict_len;          // the length x of the strings it holds
     uint32_t dict_bits;
+    const uint8_t *lcp;         // LCP bytes (nm_format.h: off_lcp), n + 1 of them, nullptr = the index file has none
 };
 
 struct nm_tally {               // counter build only
@@ -1349,6 +1350,7 @@ NM_HD void nm_bi_extend(const nm_view &ix, nm_bi &x, uint32_t c, nm_tally &t) {
 #define NM_SW_SEED2 2u             /* read the seed entries of the window and of its reverse complement (slots in iv.k, iv.l) */
 #define NM_SW_WALK 3u
 #define NM_SW_LEFT 4u
+#define NM_SW_LCP 5u               /* read the LCP bytes around the one row (iv.k) that is left of the chain's string */
 #define NM_SW_VALID 1u             /* flags: iv holds the rows of S[64 word + qo .. 64 word + Fo), two or more */
 #define NM_SW_EXACT 2u             /*        and S[64 word + qo .. 64 word + Fo + 1) occurs once */
 #define NM_SW_EMIT 1u              /* step result: element `out_v` of position `out_p` is decided */
@@ -1445,11 +1447,13 @@ NM_HD uint32_t nm_sweep_step(const nm_view &ix, const nm_enc_word *enc, const nm
     const bool reload = walk && j >= 64;                   // (a walk longer than its window: the next 64 bases)
     const bool window = mode == NM_SW_SEED || reload;
     const uint64_t wat = reload ? p + st.k : p;            // first base of the window to read
+    const uint64_t lcp0 = st.iv.k > 12 ? (st.iv.k - 12) & ~3ULL : 0ULL;      // LCP: the 32 bytes from row lcp0 on (12 .. 15 rows before the row, 16 .. 19 after)
     const void *pa, *pb;
     if (window) { pa = enc + (wat >> 6); pb = enc + (wat >> 6) + 1; }
     else if (ext) { pa = ix.rank + (row >> 6); pb = ix.rank + (end >> 6); }
+    else if (mode == NM_SW_LCP) { pa = ix.lcp + lcp0; pb = pa; }
     else { pa = ix.seed + (st.iv.l & ~3ULL); pb = ix.seed + (st.iv.k & ~3ULL); }      // SEED2: the aligned four entries that hold the slot
-    const bool one = ext && !reload && same;               // (the second rank block only where the interval leaves the first)
+    const bool one = (ext && !reload && same) || mode == NM_SW_LCP;          // (the second rank block only where the interval leaves the first)
     nm_q4_raw ra, rb;
     NM_Q4_ZERO(rb);
     NM_Q4_ISSUE(ra, pa);
@@ -1474,6 +1478,45 @@ NM_HD uint32_t nm_sweep_step(const nm_view &ix, const nm_enc_word *enc, const nm
             st.mode = NM_SW_WALK;
         }
         return 0;
+    }
+    if (mode == NM_SW_LCP) {
+        // The chain's string, one base longer to the left -- S[p .. F), len = F - p bases -- has ONE row among the rows the chain
+        // holds: r = iv.k.  The longest prefix the suffix of r shares with another suffix is the larger of its two LCP bytes, l.
+        //   l < len: the string really occurs once; one base more than l and a prefix of it occurs once -- the least unique length
+        //            of the position, no walk -- and the rows around r whose bytes reach l are the rows of that prefix.
+        //   l >= len: the string occurs twice after all (the chain held only SOME of its rows, see below): the end has not
+        //            moved, the position is decided as by a step that found two rows; the rows whose bytes reach len are its rows.
+        // The chain goes on from those rows -- from as many of them as the 32 bytes read here show: a subset of a string's rows
+        // can only under-count, and an under-count ends up here again, where the bytes put it right.  (The reverse complement's
+        // rows are not known any more: only walks, which start from the seed table, need them.)
+        const uint64_t r = st.iv.k;
+        const uint32_t len = st.Fo - st.po, was = st.k;    // (the flags of the chain the step came from, kept in k)
+        auto byte_at = [&](uint64_t row_) -> uint32_t {
+            const uint32_t o = (uint32_t)(row_ - lcp0);
+            const uint64_t wd = (o >> 3) == 0 ? A.x[0] : ((o >> 3) == 1 ? A.x[1] : ((o >> 3) == 2 ? A.x[2] : A.x[3]));
+            return (uint32_t)(wd >> (8 * (o & 7u))) & 0xFFu;
+        };
+        const uint32_t b0 = byte_at(r), b1 = byte_at(r + 1);
+        const uint32_t l = b0 > b1 ? b0 : b1;
+        t.blocks++;
+        if (l >= NM_LCP_CAP && (len > NM_LCP_CAP || a.kmax > NM_LCP_CAP)) {      // a capped byte that decides nothing here: the position walks for itself
+            st.flags = 0;
+            st.mode = NM_SW_SEED;
+            return 0;
+        }
+        const bool moved = l < len;                        // (l capped: len <= 255 here, so l >= len; kmax <= 255: every length in question is above kmax)
+        const uint32_t reach = moved ? l : len;
+        uint64_t lo = r, hi = r + 1;
+        while (lo > lcp0 && byte_at(lo) >= reach) lo--;
+        while (hi < lcp0 + 31 && byte_at(hi) >= reach) hi++;
+        st.iv.k = lo; st.iv.l = 0; st.iv.s = hi - lo;
+        st.qo = st.po;
+        if (moved) { st.Fo = st.po + l; st.flags = NM_SW_VALID | NM_SW_EXACT; }
+        else st.flags = was;
+        st.mode = NM_SW_IDLE;
+        out_v = nm_sweep_element(enc, a, p, moved ? l + 1 : ((was & NM_SW_EXACT) ? len + 1 : NM_SW_NONE));
+        if (st.iv.s < 2) st.flags = 0;                     // (cannot happen: one neighbour's byte reaches `reach`; then the next position walks)
+        return NM_SW_EMIT;
     }
     if (mode == NM_SW_SEED2) {
         uint64_t rlo, rhi, flo, fhi;
@@ -1515,9 +1558,10 @@ NM_HD uint32_t nm_sweep_step(const nm_view &ix, const nm_enc_word *enc, const nm
         out_v = nm_sweep_element(enc, a, p, (st.flags & NM_SW_EXACT) ? st.Fo + 1 - st.po : NM_SW_NONE);
         return NM_SW_EMIT;
     }
-    if (!walk) {                                           // LEFT: the end moved, this position walks for itself
+    if (!walk) {                                           // LEFT: the end moved
+        if (ix.lcp && x.s == 1) { st.iv.k = x.k; st.k = st.flags; st.flags = 0; st.mode = NM_SW_LCP; return 0; }      // one row left: its LCP bytes say where the new end is
         st.flags = 0;
-        st.mode = NM_SW_SEED;
+        st.mode = NM_SW_SEED;                              // (no LCP bytes in this index, or a string that is absent): the position walks for itself
         return 0;
     }
     st.mode = NM_SW_IDLE;

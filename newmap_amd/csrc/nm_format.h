@@ -23,6 +23,9 @@
 // Strand structure: 64 suffix-array positions per 16-byte block: u64 count of RC-half suffixes
 // before the block, u64 bits (1 = suffix starts in the RC half).  Used by forward-only counts
 // (count_kmers*, --norc).
+// LCP bytes (optional section behind the record list, off_lcp): per row the number of bases its suffix shares with the suffix
+// of the row before it, capped at 255.  A row that holds the ONLY occurrence of a string tells with its two bytes how
+// long that string has to be to occur once (nm_core.h "the sweep").
 #ifndef NM_FORMAT_H
 #define NM_FORMAT_H
 
@@ -33,6 +36,7 @@
 #define NM_SUPER_SHIFT 31
 #define NM_MAX_SUPER 16            /* up to 2^35 BWT positions */
 #define NM_SEP_FLAG 0x80000000u
+#define NM_LCP_CAP 255u
 
 struct nm_rank_block {             /* 32 bytes, 64 BWT positions */
     uint32_t cnt[4];
@@ -73,7 +77,9 @@ struct nm_file_header {            /* 1024 bytes */
     uint64_t n_super;
     uint64_t super_cnt[NM_MAX_SUPER][4];   /* A,C,G,T before each superblock */
     uint64_t off_records;          /* n_records entries of nm_record_entry (format 2, nm_hash.h) */
-    uint8_t  reserved[1024 - 8 - 8 - 8 * 3 - 32 - 8 * 5 - 8 * 4 - 8 - 8 - NM_MAX_SUPER * 32 - 8];
+    uint64_t off_lcp;              /* 0 = none; else n + 1 bytes: lcp[j] = bases the suffixes of rows j - 1 and j share, capped at
+                                      NM_LCP_CAP (lcp[0] = lcp[n] = 0): what the sweep reads when the end of a chain moves */
+    uint8_t  reserved[1024 - 8 - 8 - 8 * 3 - 32 - 8 * 5 - 8 * 4 - 8 - 8 - NM_MAX_SUPER * 32 - 8 - 8];
 };
 
 struct nm_record_entry {           /* one FASTA record with data: its length in bytes and the fingerprint of nm_hash.h */

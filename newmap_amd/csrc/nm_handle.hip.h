@@ -44,6 +44,7 @@ struct nm_index {
     void *d_lfb = nullptr;                // LF blocks
     void *d_dict = nullptr;               // repeat dictionary (nm_core.h)
     void *d_lf2 = nullptr;                // two-base LF blocks
+    void *d_lcp = nullptr;                // LCP bytes of the index file (nm_format.h), resident handles only
     uint64_t dict_entries = 0;
     void *d_hash_tab = nullptr;           // tables of the record fingerprint (nm_hash.h)
     std::vector<nm_record_entry> records; // (length, fingerprint) of the indexed records, sorted

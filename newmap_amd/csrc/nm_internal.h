@@ -13,6 +13,10 @@ typedef int (*nm_sa32_provider)(const uint8_t *T, uint64_t n, int32_t *SA, void 
 // (8 bytes per symbol) never leaves the device.  A provider that cannot take the text returns NM_E_ALLOC /
 // NM_E_TOO_LARGE and the host sorter takes over.
 typedef int (*nm_bwt_provider)(const uint8_t *T, uint64_t n, uint64_t n_fwd, uint8_t *bw, void *ctx);
+// LCP bytes of the index being built (nm_format.h: off_lcp): a provider that has the suffix array on the device fills the host
+// buffer (n + 1 bytes, nullptr = not wanted) and says so; otherwise the builder computes them from its own suffix array
+uint8_t *nm_build_lcp_buffer(void);
+void nm_build_lcp_done(void);
 int nm_index_build_impl(const char *fasta_path, const char *index_path, uint8_t sa_ratio, uint8_t seed_len,
                         nm_sa32_provider provider, void *provider_ctx, nm_bwt_provider big_provider = nullptr);
 #ifdef __cplusplus

@@ -405,7 +405,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
                hipEventCreateWithFlags(&stage.sent[1], hipEventDisableTiming) == hipSuccess;
     if (!stage.ok) (void)hipGetLastError();
     auto upload = [&](void **dptr, uint64_t off, uint64_t bytes) -> int {
-        if (hipMalloc(dptr, bytes ? bytes : 8) != hipSuccess) { nm_set_error("hipMalloc of %llu bytes failed", (unsigned long long)bytes); return NM_E_ALLOC; }
+        if (hipMalloc(dptr, (bytes ? bytes : 8) + 64) != hipSuccess) { nm_set_error("hipMalloc of %llu bytes failed", (unsigned long long)bytes); return NM_E_ALLOC; }   // (+ 64: the sweep reads 32 LCP bytes at a time)
         ix->device_bytes += bytes;
         if (!stage.ok) {                                               // (no pinned memory to be had: one pageable buffer)
             if (fseeko(fp, (off_t)off, SEEK_SET) != 0) { nm_set_error("seek failed in %s", index_path); return NM_E_FILE_FORMAT; }
@@ -452,6 +452,13 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     if ((rc = upload(&ix->d_rank, h.off_rank, rank_bytes)) != NM_OK) return fail(rc);
     if ((rc = upload(&ix->d_strand, h.off_strand, strand_bytes)) != NM_OK) return fail(rc);
     if ((rc = upload(&ix->d_sep, h.off_sep, h.n_sep * sizeof(uint64_t))) != NM_OK) return fail(rc);
+    // the LCP bytes (optional section; resident handles only: the one-shot CLI's run is bound by the host, and n more bytes
+    // to read and upload are not earned back by one search).  NEWMAP_AMD_LCP=0: not loaded (A/B)
+    {
+        const char *lcp_env = getenv("NEWMAP_AMD_LCP");
+        if (h.off_lcp && seed_len_override == -2 && !(lcp_env && lcp_env[0] == '0') &&
+            (rc = upload(&ix->d_lcp, h.off_lcp, h.n + 1)) != NM_OK) return fail(rc);
+    }
     if (hipStreamSynchronize(ix->stream) != hipSuccess) { nm_set_error("upload of %s failed", index_path); return fail(NM_E_DEVICE); }
     stage.release();
     (void)sep_bytes;
@@ -502,6 +509,7 @@ extern "C" int nm_index_open(const char *index_path, int device, int seed_len_ov
     v.dict = nullptr;
     v.dict_len = v.dict_bits = 0;
     v.lf2 = nullptr;
+    v.lcp = (const uint8_t *)ix->d_lcp;
 
     if (seed_len_override < -1 && h.n >= 2) {
         const char *off = getenv("NEWMAP_AMD_LF_BLOCKS");
@@ -602,7 +610,7 @@ extern "C" void nm_index_close(nm_index *ix) {
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     (void)hipDeviceSynchronize();                              // launches on caller streams and side streams included
-    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->d_hash_tab, ix->d_dict, ix->d_lf2, ix->seq.p,
+    void *ptrs[] = {ix->d_rank, ix->d_strand, ix->d_sep, ix->d_seed, ix->d_seed2, ix->d_quad, ix->d_quad_small, ix->d_lfb, ix->d_super, ix->d_hash_tab, ix->d_dict, ix->d_lf2, ix->d_lcp, ix->seq.p,
                     ix->out.p, ix->status.p, ix->starts.p, ix->lens.p};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -644,6 +652,7 @@ extern "C" uint64_t nm_index_info(const nm_index *ix, int what) {
         case 22: return ix->initial_len;
         case 23: return ix->guard_segments;
         case 26: return ix->view.lf2 ? 1 : 0;
+        case 35: return ix->d_lcp != nullptr;               // LCP bytes resident
         case 24: return ix->view.dict_len;
         case 25: return ix->dict_entries;
         case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: {      // k_open_words of the last launch: words / open positions by class
@@ -701,6 +710,7 @@ extern "C" int nm_set_option(nm_index *ix, int option, int64_t value) {
         return NM_OK;
     }
     if (option == NM_OPT_LF2) { ix->view.lf2 = value ? (const nm_lf_entry *)ix->d_lf2 : nullptr; return NM_OK; }
+    if (option == NM_OPT_LCP) { ix->view.lcp = value ? (const uint8_t *)ix->d_lcp : nullptr; return NM_OK; }
     if (option == NM_OPT_SWEEP) {
         if (value < 0 || value > 2) { nm_set_error("sweep must be 0 (k_resolve only), 1 (once the handle has met open positions) or 2 (always)"); return NM_E_ARGUMENT; }
         ix->sweep = (int)value;

@@ -104,6 +104,7 @@ class Index:
         d["dict_length"] = int(self._L.nm_index_info(self.handle, 24))
         d["dict_entries"] = int(self._L.nm_index_info(self.handle, 25))
         d["lf2_blocks"] = int(self._L.nm_index_info(self.handle, 26))
+        d["lcp_bytes"] = int(self._L.nm_index_info(self.handle, 35))
         return d
 
     def probe_tally(self) -> dict:
@@ -155,6 +156,11 @@ class Index:
         (k_sweep; True = from the first launch on, 1 = the default: once the handle has met open positions) or each walks
         for itself (k_resolve; False)"""
         _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_SWEEP, 2 if on is True else int(on)))
+
+    def set_lcp(self, on: bool):
+        """A/B: where the end of a chain of the sweep moves, the index's LCP bytes give the new end (default, when the index
+        file holds them) or the position walks for itself"""
+        _lib.raise_for(self._L.nm_set_option(self.handle, _lib.NM_OPT_LCP, int(bool(on))))
 
     def set_dictionary(self, on: bool):
         """A/B: open positions of the sites ask the repeat dictionary (default, when one was built and kmin allows) or the

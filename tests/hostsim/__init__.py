@@ -34,6 +34,10 @@ def lib():
     L.hs_check_bi.restype = u64
     L.hs_check_bi.argtypes = [vp, vp, u64, u64, u64]
     L.hs_set_sweep.argtypes = [i32]
+    L.hs_enable_lcp.restype = i32
+    L.hs_enable_lcp.argtypes = [vp, i32]
+    L.hs_lcp_byte.restype = ctypes.c_int64
+    L.hs_lcp_byte.argtypes = [vp, u64]
     L.hs_check_lfb.restype = u64
     L.hs_check_lfb.argtypes = [vp]
     L.hs_check_levels.restype = u64
@@ -117,6 +121,13 @@ class HostSim:
     def set_sweep(self, on=True):
         """sites() finishes the open positions with the sweep (k_sweep) instead of one walk per position (k_resolve)"""
         self.L.hs_set_sweep(int(on))
+
+    def enable_lcp(self, on=True) -> bool:
+        """the sweep reads the index file's LCP bytes where the end of a chain moves (False: it walks); returns whether the file has them"""
+        return bool(self.L.hs_enable_lcp(self.h, int(on)))
+
+    def lcp_byte(self, row: int) -> int:
+        return int(self.L.hs_lcp_byte(self.h, row))
 
     def check_lfb(self):
         return int(self.L.hs_check_lfb(self.h))

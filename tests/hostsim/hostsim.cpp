@@ -24,6 +24,7 @@ struct hs_index {
     std::vector<uint64_t> sep, seed, superC;
     std::vector<nm_lf_entry> lfb, lf2;
     std::vector<uint64_t> quad, quad2, dict;
+    std::vector<uint8_t> lcp;
     nm_view v;
     bool big;
 };
@@ -55,6 +56,10 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
              fread(ix->strand.data(), sizeof(nm_strand_block), ix->strand.size(), fp) == ix->strand.size() &&
              fread(ix->sep.data(), 8, ix->sep.size(), fp) == ix->sep.size();
     }
+    if (ok && ix->h.off_lcp) {                                // LCP bytes (optional section)
+        ix->lcp.resize(ix->h.n + 1 + 64);                     // (+ slack: the sweep reads 32 bytes at a time)
+        ok = fseeko(fp, (off_t)ix->h.off_lcp, SEEK_SET) == 0 && fread(ix->lcp.data(), 1, ix->h.n + 1, fp) == ix->h.n + 1;
+    }
     fclose(fp);
     if (!ok) { delete ix; return nullptr; }
     const nm_file_header &h = ix->h;
@@ -69,7 +74,7 @@ hs_index *hs_open(const char *path, int seed_len_override, int force_big) {
     v.rank = ix->rank.data(); v.strand = ix->strand.data(); v.sep = ix->sep.data();
     v.seed = nullptr; v.superC = ix->superC.data(); v.n = h.n; v.n_sep = h.n_sep;
     for (int c = 0; c < 4; c++) v.C[c] = C[c];
-    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.lfb = nullptr; v.lf2 = nullptr; v.dict = nullptr; v.dict_len = v.dict_bits = 0; v.quad = nullptr; v.quad_m = 0; v.quad2 = nullptr; v.quad2_m = 0;
+    v.seed_len = 0; v.n_super = (uint32_t)h.n_super; v.seed_policy = 0; v.lfb = nullptr; v.lf2 = nullptr; v.dict = nullptr; v.dict_len = v.dict_bits = 0; v.lcp = nullptr; v.quad = nullptr; v.quad_m = 0; v.quad2 = nullptr; v.quad2_m = 0;
     uint32_t s = seed_len_override < 0 ? h.seed_len : (uint32_t)seed_len_override;
     if (s > 12) s = 12;                     // keep the simulated table small
     if (s && h.n >= 2) {
@@ -184,6 +189,10 @@ uint64_t hs_check_bi(hs_index *ix, const uint8_t *seq, uint64_t seq_len, uint64_
 }
 static int g_sweep = 0;
 void hs_set_sweep(int on) { g_sweep = on; }
+// the sweep reads the index file's LCP bytes (on) or walks where the end of a chain moves; returns 0 if the file has none
+int hs_enable_lcp(hs_index *ix, int on) { ix->v.lcp = on && !ix->lcp.empty() ? ix->lcp.data() : nullptr; return ix->lcp.empty() ? 0 : 1; }
+// lcp[row] of the index file against a direct comparison of the two suffixes' k-mers is left to the Python side: the bytes
+int64_t hs_lcp_byte(hs_index *ix, uint64_t row) { return row < ix->lcp.size() && !ix->lcp.empty() ? (int64_t)ix->lcp[row] : -1; }
 // LF blocks against the packed rank blocks at every row
 uint64_t hs_check_lfb(hs_index *ix) {
     nm_view packed = ix->v;

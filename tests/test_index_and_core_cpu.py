@@ -794,19 +794,22 @@ def test_sweep_equals_oracle_and_shares_walks(tmp_path, m, force_big):
     assert sim.check_bi(r1, 2000) == 0 and sim.check_bi(b"", 300) == 0
     oracle = rd.OracleIndex([r1, r2])
     w = m + 4
-    lines = [0, 0]
+    lines = [0, 0, 0]                                      # rank-block reads: k_resolve, the sweep with walks, the sweep with the LCP bytes
+    assert sim.enable_lcp(False)                           # (the index file holds LCP bytes; first without them)
     try:
         for rec in (r1, r2):
-            for kmin, kmax in ((w, 40), (w + 2, 30), (20, 200), (24, 150), (70, 255), (12, 14)):
+            for kmin, kmax in ((w, 40), (w + 2, 30), (20, 200), (24, 150), (70, 255), (12, 14), (30, 300)):
                 dtype, _ = rd.output_dtype(kmax)
                 want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
                 for probes in (0, 1, 2):
                     for chance_max, walk_max in ((256, 64), (0, 0)):
-                        for sweep in (False, True):
-                            sim.set_sweep(sweep)
+                        for sweep in (0, 1, 2):
+                            sim.set_sweep(sweep > 0)
+                            sim.enable_lcp(sweep == 2)
                             got, status, code, _, _ = sim.sites(rec, len(rec), kmin, kmax, 59, probes, dtype=dtype, chance_max=chance_max, walk_max=walk_max)
                             assert code == 0 and np.array_equal(got, want), (kmin, kmax, probes, sweep, np.flatnonzero(got != want)[:10])
                             lines[sweep] += int(status[4])
+            sim.enable_lcp(True)
             # a prefix: the last word is cut, the lookahead is left behind
             sim.set_sweep(True)
             for cut in (1, 65, 517, len(rec) - 20):
@@ -824,6 +827,7 @@ def test_sweep_equals_oracle_and_shares_walks(tmp_path, m, force_big):
                         got, _, code, _, _ = sim.sites(rec, head, ks[0], kmax, 59, probes, ks=ks, dtype=dtype, chance_max=chance_max, walk_max=walk_max)
                         assert code == 0 and np.array_equal(got, want[:head]), (ks, probes)
         assert lines[1] * 2 < lines[0]                     # (on a 3 Gbp genome walks are 20 - 40 bases longer and the gap is wider)
+        assert lines[2] * 10 < lines[1] * 9                # the LCP bytes: fewer reads again (a moved end costs one line, not a walk; the walks of this 20 kbp genome are a few steps long)
         # a FASTA that is not the indexed genome: an absent k-mer is reported, as by the walks
         foreign = bytearray(r1[:3000])
         foreign[1500:1520] = b"ACGTTGCAACGTTGCAACGT"

@@ -153,7 +153,7 @@ def run(name, ks, is_range, batch, world=1, exclude=(b"skip",), fasta_path=fa):
 os.environ["NEWMAP_AMD_DRIVER_SLOTS"] = "8"
 for fuse in ("0", "1"):
     os.environ["NEWMAP_AMD_DRIVER_FUSE"] = fuse
-    for ks, is_range, batch, world in (([20, 200], True, 64 * 100, 1), ([36], False, 5000, 1), ([20, 60], True, 64 * 37, 3), ([20, 200], True, 10_000_000, 1)):
+    for ks, is_range, batch, world in (([20, 200], True, 64 * 100, 1), ([36], False, 5000, 1), ([20, 60], True, 64 * 37, 3), ([20, 200], True, 10_000_000, 1), ([36], False, 50, 1)):
         if world > 1: os.environ["NEWMAP_AMD_SHARD_CHUNK"] = "30000"
         rc, out = run(f"o_{{fuse}}_{{batch}}_{{world}}", ks, is_range, batch, world)
         os.environ.pop("NEWMAP_AMD_SHARD_CHUNK", None)
@@ -165,7 +165,7 @@ for fuse in ("0", "1"):
         for rid, w in want.items():
             got = np.fromfile(os.path.join(out, rid.decode() + ".unique.uint8"), np.uint8)
             assert np.array_equal(got, w), (fuse, ks, batch, world, rid)
-assert L.nm_index_info(ix, 23) > 0       # (batches that are no multiple of 64 cannot be joined: those records went through the guard)
+assert L.nm_index_info(ix, 23) > 0       # (a batch below 64 cannot be rounded to a multiple of 64 and its segments do not join: those records went through the guard; 5000 works like 4992)
 before = L.nm_index_info(ix, 23)
 os.environ["NEWMAP_AMD_DRIVER_FUSE"] = "1"
 rc, out = run("same", [20, 200], True, 64 * 1000)

@@ -96,6 +96,7 @@ def main():
                     fast.set_dictionary(bool(rng.random() < 0.7))
                     fast.set_lf2(bool(rng.random() < 0.8))
                     fast.set_sweep(bool(rng.random() < 0.8))
+                    fast.set_lcp(bool(rng.random() < 0.8))
                     kmin = int(rng.choice([w, w + 1, 20, 24, 36, 60, 61, 62, 64, 100, 124, 125, 190, 252, 253, int(rng.integers(1, 200))]))
                     kmax = int(kmin + rng.choice([0, 1, 5, 40, 130, 231, int(rng.integers(0, 3000))]))
                     batch = int(rng.choice([1 << 30, 10_007, 65_536, int(rng.integers(500, 200_000))]))

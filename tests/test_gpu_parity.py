@@ -653,7 +653,7 @@ def test_config3_full_size_properties(tmp_path, eng, monkeypatch):
     by its scan counter instead (_oracle_windows: three windows of 300 k positions per range, every claim of the output
     checked against totals counted over all 24 records).  Beside it, the properties the
     domain offers: (1) minimality of sampled elements re-derived through the count seam, (2) batch independence
-    (10 M launches == 100 M launches), (3) the sites == the one-lane-per-position kernel on a 10 M stretch (independent
+    (10 M launches == a 100 M launch, on its first 40 M), (3) the sites == the one-lane-per-position kernel on a 10 M stretch (independent
     schedules of the arithmetic), with either quad table and with the coarse probes forced, (4) structural facts (the
     last kmin-1 positions are 0; every element is 0 or in [kmin, kmax])."""
     from newmap_amd import synth
@@ -675,8 +675,8 @@ def test_config3_full_size_properties(tmp_path, eng, monkeypatch):
             whole, amb = ix.min_unique_segment(chr1[:100_000_000 + kmax - 1], 100_000_000, kmin, kmax)
             assert amb == 0 and ix.info()["last_range_kernel"] == 5
             assert ((whole == 0) | ((whole >= kmin) & (whole <= kmax))).all()
-            parts = [ix.min_unique_segment(chr1[o:o + 10_000_000 + kmax - 1], 10_000_000, kmin, kmax)[0] for o in range(0, 100_000_000, 10_000_000)]
-            assert np.array_equal(np.concatenate(parts), whole)
+            parts = [ix.min_unique_segment(chr1[o:o + 10_000_000 + kmax - 1], 10_000_000, kmin, kmax)[0] for o in range(0, 40_000_000, 10_000_000)]
+            assert np.array_equal(np.concatenate(parts), whole[:40_000_000])
             found, none = _seam_minimality(ix, chr1[:100_000_000 + kmax], whole, kmin, kmax, rng, 30_000)
             assert found > 29_000
             small, _ = ix.min_unique_segment(chr21, len(chr21), kmin, kmax)          # a whole record: the tail rule
@@ -744,8 +744,8 @@ def test_config5_full_size_properties(tmp_path, eng, monkeypatch):
         assert 0.3 < zeros < 0.7
         assert ix.probe_tally()["settled"] > 0.8 * zeros * n
         ix.set_count_steps(False)
-        parts = [ix.min_unique_segment(rec[o:o + 10_000_000 + kmax - 1], 10_000_000, kmin, kmax)[0] for o in range(0, n, 10_000_000)]
-        assert np.array_equal(np.concatenate(parts), whole)
+        parts = [ix.min_unique_segment(rec[o:o + 10_000_000 + kmax - 1], 10_000_000, kmin, kmax)[0] for o in range(0, 40_000_000, 10_000_000)]
+        assert np.array_equal(np.concatenate(parts), whole[:40_000_000])
         found, none = _seam_minimality(ix, rec[:n + kmax], whole, kmin, kmax, rng, 40_000)
         assert found > 10_000 and none > 10_000
         # the oracle on three windows (tandem arrays, their ends, spacers): totals from one scan of the whole 1 Gbp record

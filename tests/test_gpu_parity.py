@@ -738,6 +738,7 @@ def test_config5_full_size_properties(tmp_path, eng, monkeypatch):
     with eng.Index(idx, 0) as ix:
         ix.set_segment_guard(False)                          # (pieces of the record: the record check has its own tests)
         ix.set_count_steps(True)                             # (the probes' tally of settled positions is kept by the counter build)
+        ix.set_sweep(True)                                   # (probes, open-word lists from the first launch on: the default waits until the handle has met open positions)
         whole, amb = ix.min_unique_segment(rec[:n + kmax - 1], n, kmin, kmax)
         assert amb == 0 and ix.info()["last_range_kernel"] == 5
         zeros = np.count_nonzero(whole == 0) / n
@@ -1104,6 +1105,7 @@ def test_coarse_probes_forced_big_and_small(mixed_genome, eng, monkeypatch):
     want = rd.closed_form_min_unique(rec, g["oracle"], 20, 100)
     with eng.Index(g["idx"], 0) as ix:
         ix.set_count_steps(True)
+        ix.set_sweep(True)                                   # (probes from the first launch on)
         for big in (False, True):
             ix.set_force_big(big)
             for kernel in (0, 1):

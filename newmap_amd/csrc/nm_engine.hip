@@ -7,8 +7,11 @@
 //   k_period_runs           tandem arrays: the period is read off the encoded words, ONE walk per run of strides settles it
 //   k_repeat_probe(_coarse) one walk per 64 (512) positions where the bitmap is dense: settles long repeats,
 //                           fixes the lengths between equal ends
-//   k_resolve               the positions k_sites left open: probe words, else seed table + walk
-//                           (the four together: newmap/search.py:383-548)
+//   k_open_words            sorts the words of the need bitmap: dense ones for the sweep (longest chains first), sparse ones for the walks
+//   k_sweep                 open positions right to left, neighbours sharing their walks: one step to the left on the rows the right
+//                           neighbour left; where the end moves, the index's LCP bytes (nm_core.h "the sweep")
+//   k_resolve               the positions k_sites left open (all of them, or the sparse words): probe words, else seed table + walk
+//                           (the six together: newmap/search.py:383-548)
 //   k_min_unique            range mode, one lane per genome position (--norc, kmin below the table's window, A/B)
 //   k_fixed_k               list mode,  one lane per genome position (newmap/search.py:551-644)
 //   k_guard                 the exact zero-count check of newmap/search.py:699-722 for records that are not indexed ones

@@ -1391,6 +1391,7 @@ NM_HD nm_q4 nm_load_q4(const void *p) {
 typedef nm_q4 nm_q4_raw;
 #define NM_Q4_ZERO(r) ((r).x[0] = (r).x[1] = (r).x[2] = (r).x[3] = 0)
 #define NM_Q4_ISSUE(r, p) ((r) = nm_load_q4(p))
+#define NM_Q2_ISSUE(r, p) ((r).x[0] = ((const uint64_t *)(p))[0], (r).x[1] = ((const uint64_t *)(p))[1], (r).x[2] = (r).x[3] = 0)
 #define NM_Q4_WAIT2(a, b) ((void)0)
 #define NM_Q4_VALUE(r) (r)
 #endif
@@ -1448,16 +1449,27 @@ NM_HD uint32_t nm_sweep_step(const nm_view &ix, const nm_enc_word *enc, const nm
     const bool window = mode == NM_SW_SEED || reload;
     const uint64_t wat = reload ? p + st.k : p;            // first base of the window to read
     const uint64_t lcp0 = st.iv.k > 12 ? (st.iv.k - 12) & ~3ULL : 0ULL;      // LCP: the 32 bytes from row lcp0 on (12 .. 15 rows before the row, 16 .. 19 after)
+    // a step to the LEFT needs the rows of the string alone (its reverse complement's only matter to a walk, and a walk starts
+    // from the seed table): where the LF blocks were built it is a plain LF step on ONE 16-byte entry per end -- half the
+    // requests of a rank block, a third of the arithmetic
+    const uint32_t lcode = (uint32_t)((st.wlo >> st.po) & 1ULL) | ((uint32_t)((st.whi >> st.po) & 1ULL) << 1);
+    const bool left_lf = mode == NM_SW_LEFT && ix.lfb != nullptr;
     const void *pa, *pb;
     if (window) { pa = enc + (wat >> 6); pb = enc + (wat >> 6) + 1; }
+    else if (left_lf) { pa = ix.lfb + ((row >> 6) * 4 + lcode); pb = ix.lfb + ((end >> 6) * 4 + lcode); }
     else if (ext) { pa = ix.rank + (row >> 6); pb = ix.rank + (end >> 6); }
     else if (mode == NM_SW_LCP) { pa = ix.lcp + lcp0; pb = pa; }
     else { pa = ix.seed + (st.iv.l & ~3ULL); pb = ix.seed + (st.iv.k & ~3ULL); }      // SEED2: the aligned four entries that hold the slot
     const bool one = (ext && !reload && same) || mode == NM_SW_LCP;          // (the second rank block only where the interval leaves the first)
     nm_q4_raw ra, rb;
     NM_Q4_ZERO(rb);
-    NM_Q4_ISSUE(ra, pa);
-    if (!one) NM_Q4_ISSUE(rb, pb);
+    if (left_lf) {
+        NM_Q2_ISSUE(ra, pa);
+        if (!one) NM_Q2_ISSUE(rb, pb);
+    } else {
+        NM_Q4_ISSUE(ra, pa);
+        if (!one) NM_Q4_ISSUE(rb, pb);
+    }
     NM_Q4_WAIT2(ra, rb);                                   // ONE wait per turn, after every read of the turn is on its way
     const nm_q4 A = NM_Q4_VALUE(ra), B = NM_Q4_VALUE(rb);
     // ---- and what they mean
@@ -1534,8 +1546,7 @@ NM_HD uint32_t nm_sweep_step(const nm_view &ix, const nm_enc_word *enc, const nm
         return 0;
     }
     // ONE extension: to the right (WALK: appending a base = prepending its complement to the reverse complement) or to the left
-    const uint32_t code = walk ? 3u - nm_window_code(st.w, j)
-                               : ((uint32_t)((st.wlo >> st.po) & 1ULL) | ((uint32_t)((st.whi >> st.po) & 1ULL) << 1));
+    const uint32_t code = walk ? 3u - nm_window_code(st.w, j) : lcode;
     if (walk && (st.k >= a.kmax || ((st.w.amb >> j) & 1ULL))) {      // nothing up to kmax / up to U_p occurs once
         st.qo = st.po; st.Fo = st.po + st.k;
         st.flags = NM_SW_VALID;
@@ -1547,9 +1558,16 @@ NM_HD uint32_t nm_sweep_step(const nm_view &ix, const nm_enc_word *enc, const nm
     x.k = row; x.l = walk ? st.iv.k : st.iv.l; x.s = st.iv.s;
     t.steps++;
     t.blocks += same ? 1u : 2u;
-    const uint64_t *cp = BIG ? a.sc + (row >> NM_SUPER_SHIFT) * 4 : ix.C;
-    const uint64_t cs[4] = {cp[0], cp[1], cp[2], cp[3]};
-    nm_bi_extend_blk<BIG>(ix, x, code, nm_blk_of(A), nm_blk_of(one ? A : B), cs);
+    if (left_lf) {
+        const nm_q4 &Bh = one ? A : B;
+        const uint64_t lo2 = A.x[0] + nm_popc64(A.x[1] & ((1ULL << (row & 63)) - 1ULL));
+        const uint64_t hi2 = Bh.x[0] + nm_popc64(Bh.x[1] & ((1ULL << (end & 63)) - 1ULL));
+        x.k = lo2; x.l = 0; x.s = hi2 - lo2;
+    } else {
+        const uint64_t *cp = BIG ? a.sc + (row >> NM_SUPER_SHIFT) * 4 : ix.C;
+        const uint64_t cs[4] = {cp[0], cp[1], cp[2], cp[3]};
+        nm_bi_extend_blk<BIG>(ix, x, code, nm_blk_of(A), nm_blk_of(one ? A : B), cs);
+    }
     if (x.s >= 2) {
         st.iv.k = walk ? x.l : x.k; st.iv.l = walk ? x.k : x.l; st.iv.s = x.s;
         if (walk) { st.k++; return 0; }

@@ -52,6 +52,7 @@ typedef unsigned int nm_u32x4 __attribute__((ext_vector_type(4)));
 struct nm_q4_raw { nm_u32x4 lo, hi; };
 #define NM_Q4_ZERO(r) ((r).lo = (r).hi = nm_u32x4{0u, 0u, 0u, 0u})
 #define NM_Q4_ISSUE(r, p) asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"((r).lo), "=&v"((r).hi) : "v"(p) : "memory")
+#define NM_Q2_ISSUE(r, p) do { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"((r).lo) : "v"(p) : "memory"); (r).hi = nm_u32x4{0u, 0u, 0u, 0u}; } while (0)
 #define NM_Q4_WAIT2(a, b) asm volatile("s_waitcnt vmcnt(0)" : "+v"((a).lo), "+v"((a).hi), "+v"((b).lo), "+v"((b).hi) : : "memory")
 #define NM_Q4_VALUE(r) nm_q4_of_raw(r)
 struct nm_q4;

@@ -794,7 +794,7 @@ def test_sweep_equals_oracle_and_shares_walks(tmp_path, m, force_big):
     assert sim.check_bi(r1, 2000) == 0 and sim.check_bi(b"", 300) == 0
     oracle = rd.OracleIndex([r1, r2])
     w = m + 4
-    lines = [0, 0, 0]                                      # rank-block reads: k_resolve, the sweep with walks, the sweep with the LCP bytes
+    lines = [0, 0, 0, 0]                                   # block reads: k_resolve, the sweep with walks, with the LCP bytes, with LF entries for its steps to the left
     assert sim.enable_lcp(False)                           # (the index file holds LCP bytes; first without them)
     try:
         for rec in (r1, r2):
@@ -803,13 +803,15 @@ def test_sweep_equals_oracle_and_shares_walks(tmp_path, m, force_big):
                 want = rd.closed_form_min_unique(rec, oracle, kmin, kmax, True)
                 for probes in (0, 1, 2):
                     for chance_max, walk_max in ((256, 64), (0, 0)):
-                        for sweep in (0, 1, 2):
+                        for sweep in (0, 1, 2, 3):
                             sim.set_sweep(sweep > 0)
-                            sim.enable_lcp(sweep == 2)
+                            sim.enable_lcp(sweep >= 2)
+                            sim.enable_lfb(sweep == 3)                        # (k_resolve and the walks on packed rank blocks otherwise)
                             got, status, code, _, _ = sim.sites(rec, len(rec), kmin, kmax, 59, probes, dtype=dtype, chance_max=chance_max, walk_max=walk_max)
                             assert code == 0 and np.array_equal(got, want), (kmin, kmax, probes, sweep, np.flatnonzero(got != want)[:10])
                             lines[sweep] += int(status[4])
             sim.enable_lcp(True)
+            sim.enable_lfb(True)
             # a prefix: the last word is cut, the lookahead is left behind
             sim.set_sweep(True)
             for cut in (1, 65, 517, len(rec) - 20):

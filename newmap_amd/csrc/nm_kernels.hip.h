@@ -907,6 +907,18 @@ __global__ __launch_bounds__(NM_SWEEP_BLOCK) NM_SWEEP_ATTR void k_sweep(nm_view 
         if (tid < ix.n_super * 4) s_super[tid] = ix.superC[tid];
         __syncthreads();
     }
+    // The elements of a word are collected in LDS and written back as ONE 64-byte line when the word is done (uint8 output, the
+    // usual case; else element by element).  A byte store per turn kept every turn waiting: the reads of a turn are waited for
+    // with vmcnt(0), which on this hardware also counts the stores before them -- scattered single bytes, each a partial write
+    // of a line -- and a turn then lasted ~20 us whatever it read.
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[NM_SWEEP_BLOCK][80];
+    const bool can_buffer = elem_bytes == 1 && (((uintptr_t)out) & 15u) == 0;
+    bool buffered = false;
+    uint64_t out_word = 0;
+    auto put = [&](uint64_t p_, uint32_t v_) {
+        if (buffered && (p_ >> 6) == out_word) s_out[tid][p_ & 63] = (uint8_t)v_;
+        else nm_store(out, elem_bytes, p_, v_);
+    };
     uint32_t w_base = 0, w_next = 0, w_end = 0;            // (the same in every lane of the wave)
     nm_sweep_args args;
     args.kmin = kmin; args.kmax = kmax; args.seq_len = seq_len; args.list = LIST ? list : nullptr; args.n_list = n_list;
@@ -923,6 +935,12 @@ __global__ __launch_bounds__(NM_SWEEP_BLOCK) NM_SWEEP_ATTR void k_sweep(nm_view 
         // whose words were short, simply find less left) and stages them -- all its lanes read, once per chunk, what a
         // lane taking a word would otherwise wait for in the middle of everybody's chain
         const bool want = st.mode == NM_SW_IDLE && !st.bits;
+        if (want && buffered) {                            // the word is done: its line goes back
+            const nm_u64x2 *row = reinterpret_cast<const nm_u64x2 *>(&s_out[tid][0]);
+            nm_u64x2 *dst = reinterpret_cast<nm_u64x2 *>((uint8_t *)out + out_word * 64);
+            dst[0] = row[0]; dst[1] = row[1]; dst[2] = row[2]; dst[3] = row[3];
+            buffered = false;
+        }
         const uint64_t wmask = __ballot(want);
         if (wmask) {
             if (w_next == w_end) {
@@ -953,6 +971,13 @@ __global__ __launch_bounds__(NM_SWEEP_BLOCK) NM_SWEEP_ATTR void k_sweep(nm_view 
                     const uint32_t i = slot - w_base;
                     const uint64_t cur = s_cur[wv][i];
                     uint64_t bits = s_bits[wv][i];
+                    if (can_buffer && cur * 64 + 64 <= num_kmers) {        // what k_sites stored for the word's 64 positions
+                        const nm_u64x2 *src = reinterpret_cast<const nm_u64x2 *>((const uint8_t *)out + cur * 64);
+                        nm_u64x2 *row = reinterpret_cast<nm_u64x2 *>(&s_out[tid][0]);
+                        row[0] = src[0]; row[1] = src[1]; row[2] = src[2]; row[3] = src[3];
+                        buffered = true;
+                        out_word = cur;
+                    }
                     if (probe) {
                         const uint32_t wj = s_pj[wv][i], wj1 = s_pj1[wv][i];
                         const uint32_t zeros = wj & 0xFFu;         // positions repeated over more than kmax bases: element 0, as stored
@@ -962,7 +987,7 @@ __global__ __launch_bounds__(NM_SWEEP_BLOCK) NM_SWEEP_ATTR void k_sweep(nm_view 
                             for (; bits; bits &= bits - 1) {
                                 const uint32_t o = (uint32_t)__builtin_ctzll(bits);
                                 const uint32_t v = nm_sweep_element(enc, args, cur * 64 + o, kj - o);
-                                if (v) nm_store(out, elem_bytes, cur * 64 + o, v);
+                                if (v) put(cur * 64 + o, v);
                             }
                         }
                     }
@@ -983,9 +1008,8 @@ __global__ __launch_bounds__(NM_SWEEP_BLOCK) NM_SWEEP_ATTR void k_sweep(nm_view 
             if (LIST) v = nm_fixed_k_one<BIG, true>(ix, enc, p, seq_len, list, n_list, amb0, err, t);   // (which listed k-mer is absent decides: the plain form)
             if (err) { any_err = true; if (p < err_pos) err_pos = p; }
         }
-        if (ret & NM_SW_EMIT) nm_store(out, elem_bytes, p, v);
+        if (ret & NM_SW_EMIT) put(p, v);
     }
-    (void)num_kmers;
     if (__ballot(any_err)) {
         if (any_err) atomicMin((unsigned long long *)&status[2], (unsigned long long)err_pos);
         if ((tid & 63) == 0) atomicOr((unsigned long long *)&status[1], 1ULL);

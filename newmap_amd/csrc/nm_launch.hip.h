@@ -196,11 +196,12 @@ static int launch_sites(nm_index *ix, const nm_view &view_in, const void *d_seq,
         else        { if (ix->count_steps) NM_LAUNCH_SITES(true, false); else NM_LAUNCH_SITES(false, false); }
 #undef NM_LAUNCH_SITES
     }
-    // (a handle that has never met open positions -- k_resolve's latch -- is spared the probe launch too: 8 K blocks that read a flag
-    //  and return are 15 - 20 us of a 0.65 ms launch of the uniform headline; NM_OPT_SWEEP = 2, tests: always)
-    const bool open_met = ix->sweep == 2 || !ix->h_repeats_seen || ((volatile uint32_t *)ix->h_repeats_seen)[1] != 0;
+    // (the probes are launched whatever the handle has met so far: their blocks read a flag and return when k_sites left nothing
+    //  open, 4 us of a launch; holding them back until the "open positions met" latch is visible cost the FIRST pass over a
+    //  tandem-rich genome -- its launches are queued before the first of them has run -- 300 ms per 100 M positions of walks
+    //  that the probes settle in 3: measured and reverted, round 4)
     if (beside) HIP_TRY(hipStreamWaitEvent(st, ix->cur->ev_join, 0));
-    else if (ix->repeat_probes && open_met && (rc = nm_launch_probes<BIG>(ix, view, n, kmax, st, &probe, need)) != NM_OK) return rc;
+    else if (ix->repeat_probes && (rc = nm_launch_probes<BIG>(ix, view, n, kmax, st, &probe, need)) != NM_OK) return rc;
     // what is still open: the sweep (neighbouring positions share their walks, nm_core.h) or, for A/B, one walk per position
     // (default: once the handle has met open positions -- k_resolve's latch; NM_OPT_SWEEP = 2: from the first launch on)
     const bool sweep = ix->sweep == 2 || (ix->sweep == 1 && ix->h_repeats_seen && ((volatile uint32_t *)ix->h_repeats_seen)[1] != 0);

@@ -9,7 +9,7 @@
 #   tools/gpu_final.sh f NAME   the CLI process end to end, the A/B soak
 part=$1
 O=gpurun_out/${2:-final}
-P=profiles/round4
+P=$O/profiles_round4        # (only gpurun_out/ comes back from the box: copy from here into profiles/round4/ afterwards)
 mkdir -p $O $P
 case $part in
 a)

@@ -40,6 +40,12 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# HIP deals the streams of a process over GPU_MAX_HW_QUEUES hardware queues (default 4), round-robin by creation: a handle's
+# own stream, the side streams of its lanes, torch's streams and the native driver's five share them, and two streams that land
+# on one queue run their kernels one after the other.  Measured (profiles/round4/ab_hw_queues.json): the nested human-shaped
+# block, whose two streams are the 20th-odd of the process, 29.4 G positions/s with 4 queues, 36.0 G with 8 (its stand-alone
+# run: 37 G either way); the headline is unchanged.  Set before anything initialises HIP.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BATCH = 1 << 28                # positions per launch: one launch per record (the largest has 249 M) or per 64 M chunk.  The

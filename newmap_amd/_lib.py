@@ -8,6 +8,10 @@ import sys
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
+# streams of one process share GPU_MAX_HW_QUEUES hardware queues (HIP's default: 4); the engine's lanes, side streams and the
+# native driver's five streams overlap only when they land on different queues (bench.py).  Takes effect
+# when set before the process's first HIP call; a caller's own setting is kept.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 LIB_PATH = Path(os.environ["NEWMAP_AMD_LIB"]) if os.environ.get("NEWMAP_AMD_LIB") else _HERE / "libnewmap_amd.so"    # (NEWMAP_AMD_LIB: tools/ load the measurement build)
 
 NM_OK = 0

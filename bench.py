@@ -87,9 +87,11 @@ def parse(argv=None):
                     help="device tables: auto (default: sized for throughput), auto-small (<= 20 GB, what the one-shot CLI uses), "
                          "file (the index's seed length, 12), or a seed length 0..16")
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3, 4, 5],
+    ap.add_argument("--streams", type=int, default=None, choices=[1, 2, 3, 4, 5],
                     help="the segments of a pass are launched round-robin on this many HIP streams (the handle keeps one set of launch "
-                         "scratch per stream, so neighbouring segments overlap); passes of one segment use one stream")
+                         "scratch per stream, so neighbouring segments overlap); passes of one segment use one stream.  Default: 2, and 5 on "
+                         "the human-shaped genome, whose launches end in the latency-bound tail of k_sweep (measured: 35.9 / 39.5 / 41.6 / 43.4 G "
+                         "positions/s on 2 / 3 / 4 / 5 streams; the uniform headline 204.5 / 200.8 / 194.1 / 194.6 G)")
     ap.add_argument("--index-builder", choices=["host", "device"], default="device",
                     help="suffix sort on the GPU (default) or on the host cores (same index file; not timed in `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,7 +102,11 @@ def parse(argv=None):
     ap.add_argument("--no-spread", action="store_true", help="skip the separately synchronised passes behind `pass_ms` (kernel traces)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     ap.add_argument("--workdir", default=os.environ.get("NEWMAP_AMD_BENCH_DIR", "/tmp/newmap_amd_bench"))
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    args.streams_given = args.streams is not None
+    if args.streams is None:
+        args.streams = 5 if args.config == "hs" else 2
+    return args
 
 
 def self_launch(args) -> int:
@@ -724,7 +730,11 @@ def hs_block(args, rank, dev, barrier, dist, rehearse):
     KMIN, KMAX = wl.krange
     fa, idx_path, prep = prepare_index(args, wl, rank, barrier)
     units = parallel.units_for_ranges(wl.lengths, [(0, wl.total)], max(args.batch, 1), KMAX)
-    run = Run(args, wl, idx_path, units, rank, 1, dev, barrier, dist, rehearse, args.seed_length)
+    import copy
+    hs_args = copy.copy(args)
+    if not args.streams_given:
+        hs_args.streams = 5                                 # (see --streams)
+    run = Run(hs_args, wl, idx_path, units, rank, 1, dev, barrier, dist, rehearse, args.seed_length)
     wl.drop()
     steps = max(3, min(args.steps, 5))
     elapsed, kinds = run.timed(steps, 1)

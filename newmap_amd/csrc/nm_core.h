@@ -1333,18 +1333,23 @@ NM_HD void nm_bi_extend(const nm_view &ix, nm_bi &x, uint32_t c, nm_tally &t) {
 // when the walk found it (EXACT), or F = the end of what a walk may read (kmax bases, an ambiguous byte).  ONE step to the
 // left gives the rows of S[q - 1 .. F).  Two rows or more: S[q - 1 .. F + 1) contains the string that occurs once and
 // S[q - 1 .. F) does not occur once, so e(q - 1) = e(q): the position is decided by that one step (not EXACT: nothing
-// up to F occurs once, element 0 as for q).  One row: the end moved left, and the position walks for itself (seed table,
-// then base by base to the right, both intervals kept) and leaves a new string behind.  Where a stretch of a repeat
-// family member differs from its nearest relative every 5 - 20 bases, a walk is paid once per such run of positions and
-// one step for each of the others -- the reference pays ~7 probes of 20 - 200 bases for every position on its own
+// up to F occurs once, element 0 as for q).  One row: the end moved left.  Where to is read off the index's LCP bytes
+// (nm_format.h; mode NM_SW_LCP below): the row that is left holds the only occurrence of S[q - 1 .. F), the larger of its two
+// bytes is the longest prefix its suffix shares with any other, one base more is the least unique length, and the rows whose
+// bytes reach it carry the chain on.  Without the bytes (an index file written before them, a handle of the one-shot CLI, a
+// capped byte with kmax > 255) the position walks for itself -- seed table, then base by base to the right, BOTH intervals
+// kept, because the chain afterwards grows the string to the left -- as the first open position of every word does.
+// Where a stretch of a repeat family member differs from its nearest relative every 5 - 20 bases, a position costs one step
+// and a moved end one more read -- the reference pays ~7 probes of 20 - 200 bases for every position on its own
 // (newmap/search.py:464-544).  Results are those of nm_min_unique_one / nm_fixed_k_one.
 // One lane sweeps one word of the need bitmap (64 positions).  A chain is a sequence of DEPENDENT reads of lines no other lane
 // wants, so a turn of the state machine is shaped by two things: its latency -- ONE round of reads per turn, whatever the
-// lane is doing (an extension: the rank blocks of the interval's two ends; the seed window; the two seed entries), so that
-// the lanes of a wave stay in step -- and the number of load instructions, each of which costs the L1 one cycle per lane
-// when every lane reads its own line (measured: with eight loads per turn the kernel ran at the L1's pace, 12 us per turn).
-// Hence the bases come from registers (the word's own planes, the walk's window), the superblock constants from `sc`
-// (the caller's copy: LDS on the device), and the second rank block is read only where the interval leaves the first.
+// lane is doing (a step to the left: the LF entries of the interval's two ends; a walk's step: their rank blocks; the 32 LCP
+// bytes around a row; the seed window; the two seed entries), so that the lanes of a wave stay in step -- and the number of
+// load instructions, each of which costs the L1 one cycle per lane when every lane reads its own line (measured: with
+// eight loads per turn the kernel ran at the L1's pace).  Hence the bases come from registers (the word's own planes, the
+// walk's window), the superblock constants from `sc` (the caller's copy: LDS on the device), and the second block is read
+// only where the interval leaves the first.
 #define NM_SW_IDLE 0u
 #define NM_SW_SEED 1u              /* read the window of the position's first bases */
 #define NM_SW_SEED2 2u             /* read the seed entries of the window and of its reverse complement (slots in iv.k, iv.l) */

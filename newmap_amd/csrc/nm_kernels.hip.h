@@ -798,12 +798,13 @@ __global__ __launch_bounds__(NM_RES_BLOCK) void k_resolve(nm_view ix, const nm_e
 }
 
 // ---- k_open_words + k_sweep: the positions k_sites left open, neighbours sharing their walks (nm_core.h "the sweep") -------
-// Stands in for k_resolve (NM_OPT_SWEEP, default).  k_open_words lists the words of the need bitmap that hold open positions
-// (work[NM_WORK_LIST] = their number); k_sweep gives every lane one listed word at a time -- a word = one chain from its last
-// open position down to its first -- so that waves are dense whatever the open positions' distribution over the segment
-// (repeats come in clusters: with a block per stretch of the bitmap the longest block set the launch's duration).  Every
-// turn of the loop is ONE extension step for every lane that has work.  What the repeat probes decide is stored when a
-// word is taken, as in k_resolve.
+// k_open_words lists the words of the need bitmap that hold open positions, by class (above), and writes the bitmap of the
+// sparse ones; k_sweep gives every lane one listed dense word at a time -- a word = one chain from its last open position down
+// to its first -- the longest chains first, dealt to the waves in chunks (one atomic per chunk, the chunk staged in LDS), so
+// that waves are dense whatever the open positions' distribution over the segment (repeats come in clusters: with a block per
+// stretch of the bitmap the longest block set the launch's duration).  Every turn of the loop is ONE extension step for every
+// lane that has work.  What the repeat probes decide is stored when a word is taken, as in k_resolve; a word's elements are
+// collected in LDS and go back as one 64-byte line.
 #define NM_SWEEP_CHUNK 128u         /* entries a wave takes at a time */
 #define NM_SWEEP_BLOCK 256
 #define NM_SWEEP_MAX_BLOCKS 2048u   /* 256 CUs x 8 blocks: the waves take words until the lists are used up */

@@ -493,7 +493,7 @@ def test_segments_on_several_streams_overlap_safely(tmp_path):
     uniform = synth.uniform_dna(700_000, 78).tobytes()
     text = b">t\n" + tandem + b"\n>u\n" + uniform + b"\n"
     fa, idx = _build_index(tmp_path, text, "lanes")
-    oracle = rd.OracleIndex([tandem, uniform])
+    oracle = rd.OracleIndex([tandem, uniform], max_depth=300)     # (tandem arrays: suffixes ordered by their first 300 symbols, counts up to kmax exact -- tests/test_oracle_golden.py pins it to the full order)
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(5)
     for rec, (kmin, kmax) in ((tandem, (20, 255)), (uniform, (20, 200)), (tandem, (24, 60))):
@@ -870,7 +870,7 @@ def test_config5_tandem_repeats_20_255(tmp_path, eng):
     recs = synth.config_genome("c5", 0.5)
     fa, idx = _build_index(tmp_path, _records_fasta(recs), "c5")
     rec = recs[0][1].tobytes()
-    oracle = rd.OracleIndex([rec])
+    oracle = rd.OracleIndex([rec], max_depth=300)          # (as above: the full suffix order of a tandem-rich text is most of this test's time)
     want = rd.closed_form_min_unique(rec, oracle, 20, 255)
     with eng.Index(idx, 0) as ix:
         got, amb = ix.min_unique_segment(rec, len(rec), 20, 255)

@@ -136,6 +136,30 @@ def test_sa_and_fm_counters_agree_on_random_queries():
     assert np.array_equal(a, b) and a.min() >= 1
 
 
+def test_depth_limited_suffix_order_counts_like_the_full_one():
+    """OracleIndex(max_depth=D) orders the suffixes by their first D symbols only (a tandem array of tens of kilobases makes
+    the comparison sort of whole suffixes quadratic): counts of k-mers of at most D symbols, and with them the closed form and
+    the reference schedule for kmax < D, are those of the full order -- the GPU suite's tandem-rich genomes use it."""
+    from newmap_amd import synth
+    rng = np.random.default_rng(11)
+    tandem = synth.tandem_dna(60_000, 5).tobytes()
+    other = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20_000)]) + tandem[10_000:13_000]
+    full = rd.OracleIndex([tandem, other])
+    cut = rd.OracleIndex([tandem, other], max_depth=300)
+    for rec in (tandem, other):
+        for kmin, kmax in ((20, 255), (24, 60), (12, 299)):
+            assert np.array_equal(rd.closed_form_min_unique(rec, full, kmin, kmax), rd.closed_form_min_unique(rec, cut, kmin, kmax))
+        starts = rng.integers(0, len(rec) - 300, 4000)
+        lens = rng.integers(1, 301, 4000)
+        assert np.array_equal(full.count_from_sequence(rec, starts, lens), cut.count_from_sequence(rec, starts, lens))
+    seg = rd.Segment(b"t", tandem[:5000], True)
+    a, _ = rd.linear_search_segment(full, seg, [36, 100], 100, np.uint8)
+    b, _ = rd.linear_search_segment(cut, seg, [36, 100], 100, np.uint8)
+    assert np.array_equal(a, b)
+    with pytest.raises(MemoryError):
+        cut.enable_fm(4)                                   # (the FM port needs the full order)
+
+
 def test_multi_fasta_multi_index_matches_reference_driver():
     """lock-step FASTA files x several indexes (newmap/search.py:251-265,656-697)"""
     import json

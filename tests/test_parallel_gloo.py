@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 (and 3) gloo jobs run the sharding plan and the final
+"""The N>1 path on CPU: world_size-2, -3 and -8 gloo jobs run the sharding plan and the final
 gather of newmap_amd.parallel with the per-unit compute injected (the oracle's closed form -- test
 only; on a GPU box the compute is the HIP engine, covered by tests/test_gpu_parity.py)."""
 import os
@@ -110,7 +110,7 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_search_equals_single_process(tmp_path, world):
     import torch.multiprocessing as mp
     from oracle import ref_driver as rd
